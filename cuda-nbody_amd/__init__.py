@@ -1,0 +1,314 @@
+"""cuda-nbody_amd -- MI355X-native all-pairs N-body hot path behind the reference's own seams.
+
+The product is the C-ABI shared library ``libnbody_hip.so`` (include/nbody_hip.h) built from the hand-written
+gfx950 HIP kernels in ``csrc/``, plus the C++23 host mirror of the reference's ``BodySystemCUDA`` /
+``ComputeCUDA`` / ``Compute`` / CLI in ``host/``.  This Python module is the thin ctypes binding used by
+tests/, bench.py and __graft_entry__.py: it mirrors the reference's ``BodySystemCUDADefault<T>`` interface
+(/root/reference/src/nbody/bodysystemcuda.hpp:38-72, bodysystemcuda_default.cu:19-55) call for call.
+
+There is NO CPU fallback: if libnbody_hip.so is missing or a HIP call fails, this module raises.
+
+The directory name carries a hyphen, so import it with ``__graft_entry__.load_package()``.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from dataclasses import dataclass
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get("NBODY_HIP_LIB", os.path.join(HERE, "libnbody_hip.so"))
+
+NB_MODE_STRICT, NB_MODE_FAST = 0, 1
+NB_SHARD_ACC_IN, NB_SHARD_FINALIZE = 1, 2
+
+# enum class NBodyConfig, src/nbody/nbody_config.hpp:3
+NBODY_CONFIG_RANDOM, NBODY_CONFIG_SHELL, NBODY_CONFIG_EXPAND = 0, 1, 2
+
+
+@dataclass
+class NBodyParams:
+    """struct NBodyParams, src/nbody/params.hpp:8-16 (camera_origin dropped: display only)."""
+    time_step: float = 0.016
+    cluster_scale: float = 1.54
+    velocity_scale: float = 8.0
+    softening: float = 0.1
+    damping: float = 1.0
+
+
+# Compute::demo_params, src/nbody/compute.hpp:90-97
+DEMO_PARAMS = (
+    NBodyParams(0.016, 1.54, 8.0, 0.1, 1.0),
+    NBodyParams(0.016, 0.68, 20.0, 0.1, 1.0),
+    NBodyParams(0.0006, 0.16, 1000.0, 1.0, 1.0),
+    NBodyParams(0.0006, 0.16, 1000.0, 1.0, 1.0),
+    NBodyParams(0.0019, 0.32, 276.0, 1.0, 1.0),
+    NBodyParams(0.0016, 0.32, 272.0, 0.145, 1.0),
+    NBodyParams(0.016, 6.04, 0.0, 1.0, 1.0),
+)
+
+
+class NBodyHipError(RuntimeError):
+    def __init__(self, code: int, what: str):
+        super().__init__(f"{what}: {code}")
+        self.code = code
+
+
+class DeviceInfo(ctypes.Structure):
+    _fields_ = [("name", ctypes.c_char * 256), ("arch", ctypes.c_char * 64), ("compute_units", ctypes.c_int),
+                ("wavefront_size", ctypes.c_int), ("clock_khz", ctypes.c_int), ("can_map_host_memory", ctypes.c_int),
+                ("lds_bytes_per_cu", ctypes.c_int), ("total_memory", ctypes.c_size_t)]
+
+
+class LaunchPlan(ctypes.Structure):
+    _fields_ = [("bodies_per_lane", ctypes.c_int), ("lanes_per_body", ctypes.c_int), ("tile_bodies", ctypes.c_int),
+                ("block_threads", ctypes.c_int), ("grid_blocks", ctypes.c_uint), ("lds_bytes", ctypes.c_uint)]
+
+
+# name -> (restype, argtypes); this table is also what tests/test_capi_symbols.py checks against the header
+_vp, _ci, _cu, _cf, _cd, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_uint, ctypes.c_float, ctypes.c_double, ctypes.c_size_t
+_P = ctypes.POINTER
+SIGNATURES = {
+    "nb_error_string": (ctypes.c_char_p, [_ci]),
+    "nb_version": (ctypes.c_char_p, []),
+    "nb_device_count": (_ci, [_P(_ci)]),
+    "nb_set_device": (_ci, [_ci]),
+    "nb_get_device": (_ci, [_P(_ci)]),
+    "nb_device_info": (_ci, [_ci, _P(DeviceInfo)]),
+    "nb_alloc": (_ci, [_P(_vp), _sz]),
+    "nb_free": (_ci, [_vp]),
+    "nb_memset": (_ci, [_vp, _ci, _sz, _vp]),
+    "nb_h2d": (_ci, [_vp, _vp, _sz, _vp]),
+    "nb_d2h": (_ci, [_vp, _vp, _sz, _vp]),
+    "nb_d2d": (_ci, [_vp, _vp, _sz, _vp]),
+    "nb_host_alloc_mapped": (_ci, [_P(_vp), _P(_vp), _sz]),
+    "nb_host_free": (_ci, [_vp]),
+    "nb_stream_create": (_ci, [_P(_vp)]),
+    "nb_stream_destroy": (_ci, [_vp]),
+    "nb_stream_synchronize": (_ci, [_vp]),
+    "nb_stream_wait_event": (_ci, [_vp, _vp]),
+    "nb_event_create": (_ci, [_P(_vp)]),
+    "nb_event_destroy": (_ci, [_vp]),
+    "nb_event_record": (_ci, [_vp, _vp]),
+    "nb_event_synchronize": (_ci, [_vp]),
+    "nb_event_elapsed_ms": (_ci, [_P(_cf), _vp, _vp]),
+    "nb_device_synchronize": (_ci, []),
+    "nb_set_softening_sq_f32": (_ci, [_cf]),
+    "nb_set_softening_sq_f64": (_ci, [_cd]),
+    "nb_get_softening_sq_f32": (_ci, [_P(_cf)]),
+    "nb_get_softening_sq_f64": (_ci, [_P(_cd)]),
+    "nb_integrate_f32": (_ci, [_vp, _vp, _vp, _cf, _cf, _cu, _ci, _ci, _vp]),
+    "nb_integrate_f64": (_ci, [_vp, _vp, _vp, _cd, _cd, _cu, _ci, _ci, _vp]),
+    "nb_integrate_shard_f32": (_ci, [_vp, _vp, _vp, _vp, _cu, _cu, _cu, _cu, _cu, _cf, _cf, _ci, _ci, _vp]),
+    "nb_integrate_shard_f64": (_ci, [_vp, _vp, _vp, _vp, _cu, _cu, _cu, _cu, _cu, _cd, _cd, _ci, _ci, _vp]),
+    "nb_plan_f32": (_ci, [_cu, _cu, _P(LaunchPlan)]),
+    "nb_plan_f64": (_ci, [_cu, _cu, _P(LaunchPlan)]),
+    "nb_set_plan_override": (_ci, [_ci, _ci, _ci]),
+}
+
+_lib = None
+
+
+def lib() -> ctypes.CDLL:
+    """Load libnbody_hip.so (fails loudly when the HIP extension has not been built)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise FileNotFoundError(f"{LIB_PATH} not found: build it with `make -C {os.path.join(HERE, 'csrc')}` "
+                                    "(or __graft_entry__.build()); there is no CPU fallback")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (restype, argtypes) in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError if the symbol is not exported
+            fn.restype, fn.argtypes = restype, argtypes
+        _lib = handle
+    return _lib
+
+
+def check(code: int, what: str = "nbody_hip") -> None:
+    if code != 0:
+        name = lib().nb_error_string(code)
+        raise NBodyHipError(code, f"{what}: {name.decode() if name else '?'}")
+
+
+def device_count() -> int:
+    n = _ci(0)
+    check(lib().nb_device_count(ctypes.byref(n)), "nb_device_count")
+    return n.value
+
+
+def device_info(device: int = 0) -> DeviceInfo:
+    info = DeviceInfo()
+    check(lib().nb_device_info(device, ctypes.byref(info)), "nb_device_info")
+    return info
+
+
+def plan(i_count: int, j_count: int, dtype=np.float32) -> LaunchPlan:
+    p = LaunchPlan()
+    fn = lib().nb_plan_f32 if np.dtype(dtype) == np.float32 else lib().nb_plan_f64
+    check(fn(i_count, j_count, ctypes.byref(p)), "nb_plan")
+    return p
+
+
+def set_plan_override(bodies_per_lane: int = 0, lanes_per_body: int = 0, tile_bodies: int = 0) -> None:
+    check(lib().nb_set_plan_override(bodies_per_lane, lanes_per_body, tile_bodies), "nb_set_plan_override")
+
+
+def set_softening_squared(value) -> None:
+    """set_softening_squared(float|double), src/nbody/bodysystemcuda.cu:46-60 (overload chosen by dtype)."""
+    if isinstance(value, np.float64) or type(value) is float:
+        check(lib().nb_set_softening_sq_f64(float(value)), "nb_set_softening_sq_f64")
+    else:
+        check(lib().nb_set_softening_sq_f32(np.float32(value)), "nb_set_softening_sq_f32")
+
+
+class DeviceBuffer:
+    """A caller-owned device array (what thrust::device_vector<T> is to the reference)."""
+
+    def __init__(self, nbytes: int):
+        self.ptr = _vp()
+        self.nbytes = nbytes
+        check(lib().nb_alloc(ctypes.byref(self.ptr), nbytes), "nb_alloc")
+        check(lib().nb_memset(self.ptr, 0, nbytes, None), "nb_memset")
+
+    def upload(self, host: np.ndarray) -> None:
+        assert host.flags.c_contiguous and host.nbytes <= self.nbytes
+        check(lib().nb_h2d(self.ptr, host.ctypes.data_as(_vp), host.nbytes, None), "nb_h2d")
+
+    def download(self, host: np.ndarray) -> np.ndarray:
+        assert host.flags.c_contiguous and host.nbytes <= self.nbytes
+        check(lib().nb_d2h(host.ctypes.data_as(_vp), self.ptr, host.nbytes, None), "nb_d2h")
+        return host
+
+    def free(self) -> None:
+        if self.ptr:
+            lib().nb_free(self.ptr)
+            self.ptr = _vp()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def integrate_nbody_system(new_positions, old_positions, velocities, current_read: int, delta_time, damping,
+                           num_bodies: int, block_size: int, dtype=np.float32, mode: int = NB_MODE_FAST, stream=None) -> None:
+    """integrateNbodySystem<T>, src/nbody/integrate_nbody_cuda.hpp:5 (same argument order; `current_read` is
+    unused there too).  Pointers are raw device addresses (int / c_void_p)."""
+    del current_read
+    if np.dtype(dtype) == np.float32:
+        rc = lib().nb_integrate_f32(new_positions, old_positions, velocities, np.float32(delta_time), np.float32(damping),
+                                    num_bodies, block_size, mode, stream)
+    else:
+        rc = lib().nb_integrate_f64(new_positions, old_positions, velocities, float(delta_time), float(damping),
+                                    num_bodies, block_size, mode, stream)
+    check(rc, "integrateNbodySystem")
+
+
+class BodySystemHIP:
+    """Mirror of BodySystemCUDADefault<T> (src/nbody/bodysystemcuda_default.hpp:28-36, .cu:8-55) on HIP.
+
+    Two ping-pong position arrays + one velocity array of 4N T on the device; ``update`` writes
+    pos[1-read] from pos[read] and swaps; ``set_*`` resets read=0/write=1; ``get_*`` are blocking D2H copies.
+    ``reset`` needs initial conditions: pass ``randomise`` (a callable (config, n, cluster, velocity, dtype) ->
+    (pos, vel)); the C++ host mirror owns the real randomise_bodies restatement.
+    """
+
+    def __init__(self, nb_bodies: int, block_size: int = 256, params: NBodyParams | None = None, dtype=np.float32,
+                 positions: np.ndarray | None = None, velocities: np.ndarray | None = None, mode: int = NB_MODE_FAST):
+        self.dtype = np.dtype(dtype)
+        if self.dtype not in (np.dtype(np.float32), np.dtype(np.float64)):
+            raise TypeError("float32 or float64")
+        self.nb_bodies = int(nb_bodies)
+        self.block_size = int(block_size)
+        self.mode = mode
+        params = params or NBodyParams()
+        self.damping = self.dtype.type(np.float32(params.damping))  # float -> T, bodysystemcuda.cpp:56
+        self.current_read, self.current_write = 0, 1
+        nbytes = 4 * self.nb_bodies * self.dtype.itemsize
+        self._pos = [DeviceBuffer(nbytes), DeviceBuffer(nbytes)]
+        self._vel = DeviceBuffer(nbytes)
+        self._host_pos = np.zeros(4 * self.nb_bodies, dtype=self.dtype)
+        self._host_vel = np.zeros(4 * self.nb_bodies, dtype=self.dtype)
+        self._set_softening(params.softening)
+        if positions is not None:
+            self.set_position(positions)
+            self.set_velocity(velocities)
+
+    def _set_softening(self, softening) -> None:
+        # bodysystemcuda.cpp:42-46: softening2 = T(softening) * T(softening)
+        s = self.dtype.type(np.float32(softening))
+        self._softening_sq = s * s
+
+    def _apply_softening(self) -> None:
+        if self.dtype == np.float32:
+            check(lib().nb_set_softening_sq_f32(self._softening_sq), "nb_set_softening_sq_f32")
+        else:
+            check(lib().nb_set_softening_sq_f64(float(self._softening_sq)), "nb_set_softening_sq_f64")
+
+    def update_params(self, params: NBodyParams) -> None:
+        self._set_softening(params.softening)
+        self.damping = self.dtype.type(np.float32(params.damping))
+
+    def reset(self, params: NBodyParams, config: int, randomise) -> None:
+        pos, vel = randomise(config, self.nb_bodies, params.cluster_scale, params.velocity_scale, self.dtype)
+        self.set_position(pos)
+        self.set_velocity(vel)
+
+    def update(self, delta_time, stream=None) -> None:
+        self._apply_softening()
+        integrate_nbody_system(self._pos[1 - self.current_read].ptr, self._pos[self.current_read].ptr, self._vel.ptr,
+                               self.current_read, delta_time, self.damping, self.nb_bodies, self.block_size,
+                               self.dtype, self.mode, stream)
+        self.current_read, self.current_write = self.current_write, self.current_read
+
+    def get_position(self) -> np.ndarray:
+        return self._pos[self.current_read].download(self._host_pos)
+
+    def get_velocity(self) -> np.ndarray:
+        return self._vel.download(self._host_vel)
+
+    def set_position(self, data: np.ndarray) -> None:
+        data = np.ascontiguousarray(data, dtype=self.dtype)
+        assert data.size == 4 * self.nb_bodies
+        self.current_read, self.current_write = 0, 1
+        self._pos[0].upload(data)
+
+    def set_velocity(self, data: np.ndarray) -> None:
+        data = np.ascontiguousarray(data, dtype=self.dtype)
+        assert data.size == 4 * self.nb_bodies
+        self.current_read, self.current_write = 0, 1
+        self._vel.upload(data)
+
+    def synchronize(self) -> None:
+        check(lib().nb_device_synchronize(), "nb_device_synchronize")
+
+    def free(self) -> None:
+        for b in self._pos + [self._vel]:
+            b.free()
+
+
+class Event:
+    def __init__(self):
+        self.h = _vp()
+        check(lib().nb_event_create(ctypes.byref(self.h)), "nb_event_create")
+
+    def record(self, stream=None) -> None:
+        check(lib().nb_event_record(self.h, stream), "nb_event_record")
+
+    def synchronize(self) -> None:
+        check(lib().nb_event_synchronize(self.h), "nb_event_synchronize")
+
+    def elapsed_ms(self, stop: "Event") -> float:
+        ms = _cf(0)
+        check(lib().nb_event_elapsed_ms(ctypes.byref(ms), self.h, stop.h), "nb_event_elapsed_ms")
+        return ms.value
+
+    def __del__(self):
+        try:
+            if self.h:
+                lib().nb_event_destroy(self.h)
+        except Exception:
+            pass

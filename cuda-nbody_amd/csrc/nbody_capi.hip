@@ -1,0 +1,234 @@
+// nbody_capi.hip -- implementation of include/nbody_hip.h (the C-ABI drop-in boundary).  gfx950 only.
+//
+// Thin by design: argument validation, per-precision softening state, launch-plan selection and the
+// HIP runtime calls the reference makes through CUDA/thrust/cuda-api-wrappers.  No allocation, no
+// synchronisation and no host<->device traffic inside the integrate entry points (graph-capturable).
+#include "../../include/nbody_hip.h"
+
+#include "nbody_kernels.h"
+
+#include <atomic>
+#include <cstdint>
+#include <cstring>
+
+namespace {
+
+// The reference keeps softening^2 in two __constant__ symbols (bodysystemcuda.cu:43-44); here it is host
+// state passed to every launch as a kernel argument (no hipMemcpyToSymbol, nothing to synchronise).
+std::atomic<float>  g_softening_sq_f32{0.0f};
+std::atomic<double> g_softening_sq_f64{0.0};
+
+std::atomic<int> g_ovr_i{0}, g_ovr_s{0}, g_ovr_tile{0};
+
+int cu_count_cached() {
+    static std::atomic<int> cached[64] = {};
+    int                     dev        = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    int v = cached[dev].load(std::memory_order_relaxed);
+    if (v == 0) {
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        cached[dev].store(v, std::memory_order_relaxed);
+    }
+    return v;
+}
+
+inline hipStream_t as_stream(nb_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+inline hipEvent_t  as_event(nb_event_t e) { return reinterpret_cast<hipEvent_t>(e); }
+
+template <typename T> bool aligned_vec4(const void* p) { return (reinterpret_cast<std::uintptr_t>(p) % (4 * sizeof(T))) == 0; }
+
+template <typename T>
+int integrate_shard(T* new_pos, const T* old_pos, T* vel, T* acc, unsigned i_begin, unsigned i_count, unsigned j_begin, unsigned j_count, unsigned flags, T dt, T damping, T eps2, int block_size, int mode, nb_stream_t stream) {
+    const bool acc_in   = (flags & NB_SHARD_ACC_IN) != 0;
+    const bool finalize = (flags & NB_SHARD_FINALIZE) != 0;
+    if (!old_pos || i_count == 0) return NB_ERR_INVALID_ARGUMENT;
+    if (finalize && (!new_pos || !vel || new_pos == old_pos)) return NB_ERR_INVALID_ARGUMENT;
+    if ((acc_in || !finalize) && !acc) return NB_ERR_INVALID_ARGUMENT;
+    if (!aligned_vec4<T>(old_pos) || !aligned_vec4<T>(new_pos) || !aligned_vec4<T>(vel) || !aligned_vec4<T>(acc)) return NB_ERR_INVALID_ARGUMENT;
+    if (static_cast<unsigned long long>(i_begin) + i_count > 0xFFFFFFFFull || static_cast<unsigned long long>(j_begin) + j_count > 0xFFFFFFFFull) return NB_ERR_INVALID_ARGUMENT;
+
+    nb::Shard<T> s;
+    s.new_pos = new_pos, s.old_pos = old_pos, s.vel = vel, s.acc = acc;
+    s.i_begin = i_begin, s.i_count = i_count, s.j_begin = j_begin, s.j_count = j_count;
+    s.acc_in = acc_in, s.finalize = finalize;
+    s.dt = dt, s.damping = damping, s.eps2 = eps2;
+
+    if (mode == NB_MODE_STRICT) {
+        if (block_size <= 0) block_size = 256;  // the reference's default --blockSize (nbody.cpp:285)
+        if (block_size % 64 != 0 || block_size > 1024) return NB_ERR_INVALID_ARGUMENT;
+        return static_cast<int>(nb::launch_strict<T>(s, block_size, as_stream(stream)));
+    }
+    if (mode == NB_MODE_FAST) {
+        const nb::Plan p = nb::plan_fast<T>(i_count, j_count, cu_count_cached(), g_ovr_i.load(), g_ovr_s.load(), g_ovr_tile.load());
+        return static_cast<int>(nb::launch_fast<T>(s, p, as_stream(stream)));
+    }
+    return NB_ERR_INVALID_ARGUMENT;
+}
+
+template <typename T> int plan_query(unsigned i_count, unsigned j_count, nb_launch_plan_t* out) {
+    if (!out || i_count == 0) return NB_ERR_INVALID_ARGUMENT;
+    const nb::Plan p     = nb::plan_fast<T>(i_count, j_count, cu_count_cached(), g_ovr_i.load(), g_ovr_s.load(), g_ovr_tile.load());
+    out->bodies_per_lane = p.bodies_per_lane;
+    out->lanes_per_body  = p.lanes_per_body;
+    out->tile_bodies     = p.tile_bodies;
+    out->block_threads   = p.block_threads;
+    out->grid_blocks     = p.grid_blocks;
+    out->lds_bytes       = p.lds_bytes;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* nb_error_string(int code) {
+    switch (code) {
+        case 0: return "success";
+        case NB_ERR_INVALID_ARGUMENT: return "NB_ERR_INVALID_ARGUMENT";
+        case NB_ERR_UNSUPPORTED: return "NB_ERR_UNSUPPORTED";
+        default: return hipGetErrorName(static_cast<hipError_t>(code));
+    }
+}
+
+const char* nb_version(void) { return "mi355x-nbody 0.1 (gfx950)"; }
+
+int nb_device_count(int* count) {
+    if (!count) return NB_ERR_INVALID_ARGUMENT;
+    return static_cast<int>(hipGetDeviceCount(count));
+}
+int nb_set_device(int device) { return static_cast<int>(hipSetDevice(device)); }
+int nb_get_device(int* device) {
+    if (!device) return NB_ERR_INVALID_ARGUMENT;
+    return static_cast<int>(hipGetDevice(device));
+}
+
+int nb_device_info(int device, nb_device_info_t* out) {
+    if (!out) return NB_ERR_INVALID_ARGUMENT;
+    hipDeviceProp_t prop;
+    const auto      err = hipGetDeviceProperties(&prop, device);
+    if (err != hipSuccess) return static_cast<int>(err);
+    std::memset(out, 0, sizeof(*out));
+    std::strncpy(out->name, prop.name, sizeof(out->name) - 1);
+    std::strncpy(out->arch, prop.gcnArchName, sizeof(out->arch) - 1);
+    out->compute_units       = prop.multiProcessorCount;
+    out->wavefront_size      = prop.warpSize;
+    out->clock_khz           = prop.clockRate;
+    out->can_map_host_memory = prop.canMapHostMemory;
+    out->lds_bytes_per_cu    = static_cast<int>(prop.maxSharedMemoryPerMultiProcessor);
+    out->total_memory        = prop.totalGlobalMem;
+    return 0;
+}
+
+int nb_alloc(void** device_ptr, size_t bytes) {
+    if (!device_ptr) return NB_ERR_INVALID_ARGUMENT;
+    return static_cast<int>(hipMalloc(device_ptr, bytes));
+}
+int nb_free(void* device_ptr) { return static_cast<int>(hipFree(device_ptr)); }
+int nb_memset(void* device_ptr, int value, size_t bytes, nb_stream_t stream) { return static_cast<int>(hipMemsetAsync(device_ptr, value, bytes, as_stream(stream))); }
+
+int nb_h2d(void* device_dst, const void* host_src, size_t bytes, nb_stream_t stream) {
+    auto err = hipMemcpyAsync(device_dst, host_src, bytes, hipMemcpyHostToDevice, as_stream(stream));
+    if (err != hipSuccess) return static_cast<int>(err);
+    return static_cast<int>(hipStreamSynchronize(as_stream(stream)));
+}
+int nb_d2h(void* host_dst, const void* device_src, size_t bytes, nb_stream_t stream) {
+    auto err = hipMemcpyAsync(host_dst, device_src, bytes, hipMemcpyDeviceToHost, as_stream(stream));
+    if (err != hipSuccess) return static_cast<int>(err);
+    return static_cast<int>(hipStreamSynchronize(as_stream(stream)));
+}
+int nb_d2d(void* device_dst, const void* device_src, size_t bytes, nb_stream_t stream) {
+    return static_cast<int>(hipMemcpyAsync(device_dst, device_src, bytes, hipMemcpyDeviceToDevice, as_stream(stream)));
+}
+
+int nb_host_alloc_mapped(void** host_ptr, void** device_ptr, size_t bytes) {
+    if (!host_ptr || !device_ptr) return NB_ERR_INVALID_ARGUMENT;
+    auto err = hipHostMalloc(host_ptr, bytes, hipHostMallocMapped | hipHostMallocPortable);
+    if (err != hipSuccess) return static_cast<int>(err);
+    err = hipHostGetDevicePointer(device_ptr, *host_ptr, 0);
+    if (err != hipSuccess) {
+        (void)hipHostFree(*host_ptr);
+        *host_ptr = nullptr;
+    }
+    return static_cast<int>(err);
+}
+int nb_host_free(void* host_ptr) { return static_cast<int>(hipHostFree(host_ptr)); }
+
+int nb_stream_create(nb_stream_t* stream) {
+    if (!stream) return NB_ERR_INVALID_ARGUMENT;
+    hipStream_t s   = nullptr;
+    const auto  err = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+    *stream         = s;
+    return static_cast<int>(err);
+}
+int nb_stream_destroy(nb_stream_t stream) { return static_cast<int>(hipStreamDestroy(as_stream(stream))); }
+int nb_stream_synchronize(nb_stream_t stream) { return static_cast<int>(hipStreamSynchronize(as_stream(stream))); }
+int nb_stream_wait_event(nb_stream_t stream, nb_event_t event) { return static_cast<int>(hipStreamWaitEvent(as_stream(stream), as_event(event), 0)); }
+
+int nb_event_create(nb_event_t* event) {
+    if (!event) return NB_ERR_INVALID_ARGUMENT;
+    hipEvent_t e   = nullptr;
+    const auto err = hipEventCreate(&e);
+    *event         = e;
+    return static_cast<int>(err);
+}
+int nb_event_destroy(nb_event_t event) { return static_cast<int>(hipEventDestroy(as_event(event))); }
+int nb_event_record(nb_event_t event, nb_stream_t stream) { return static_cast<int>(hipEventRecord(as_event(event), as_stream(stream))); }
+int nb_event_synchronize(nb_event_t event) { return static_cast<int>(hipEventSynchronize(as_event(event))); }
+int nb_event_elapsed_ms(float* ms, nb_event_t start, nb_event_t stop) {
+    if (!ms) return NB_ERR_INVALID_ARGUMENT;
+    return static_cast<int>(hipEventElapsedTime(ms, as_event(start), as_event(stop)));
+}
+int nb_device_synchronize(void) { return static_cast<int>(hipDeviceSynchronize()); }
+
+int nb_set_softening_sq_f32(float v) {
+    g_softening_sq_f32.store(v);
+    return 0;
+}
+int nb_set_softening_sq_f64(double v) {
+    g_softening_sq_f64.store(v);
+    return 0;
+}
+int nb_get_softening_sq_f32(float* v) {
+    if (!v) return NB_ERR_INVALID_ARGUMENT;
+    *v = g_softening_sq_f32.load();
+    return 0;
+}
+int nb_get_softening_sq_f64(double* v) {
+    if (!v) return NB_ERR_INVALID_ARGUMENT;
+    *v = g_softening_sq_f64.load();
+    return 0;
+}
+
+int nb_integrate_shard_f32(float* new_positions, const float* old_positions, float* velocities, float* acc, unsigned i_begin, unsigned i_count, unsigned j_begin, unsigned j_count, unsigned flags, float dt, float damping, int block_size, int mode,
+                           nb_stream_t stream) {
+    return integrate_shard<float>(new_positions, old_positions, velocities, acc, i_begin, i_count, j_begin, j_count, flags, dt, damping, g_softening_sq_f32.load(), block_size, mode, stream);
+}
+int nb_integrate_shard_f64(double* new_positions, const double* old_positions, double* velocities, double* acc, unsigned i_begin, unsigned i_count, unsigned j_begin, unsigned j_count, unsigned flags, double dt, double damping, int block_size,
+                           int mode, nb_stream_t stream) {
+    return integrate_shard<double>(new_positions, old_positions, velocities, acc, i_begin, i_count, j_begin, j_count, flags, dt, damping, g_softening_sq_f64.load(), block_size, mode, stream);
+}
+
+int nb_integrate_f32(float* new_positions, const float* old_positions, float* velocities, float dt, float damping, unsigned num_bodies, int block_size, int mode, nb_stream_t stream) {
+    return integrate_shard<float>(new_positions, old_positions, velocities, nullptr, 0, num_bodies, 0, num_bodies, NB_SHARD_FINALIZE, dt, damping, g_softening_sq_f32.load(), block_size, mode, stream);
+}
+int nb_integrate_f64(double* new_positions, const double* old_positions, double* velocities, double dt, double damping, unsigned num_bodies, int block_size, int mode, nb_stream_t stream) {
+    return integrate_shard<double>(new_positions, old_positions, velocities, nullptr, 0, num_bodies, 0, num_bodies, NB_SHARD_FINALIZE, dt, damping, g_softening_sq_f64.load(), block_size, mode, stream);
+}
+
+int nb_plan_f32(unsigned i_count, unsigned j_count, nb_launch_plan_t* plan) { return plan_query<float>(i_count, j_count, plan); }
+int nb_plan_f64(unsigned i_count, unsigned j_count, nb_launch_plan_t* plan) { return plan_query<double>(i_count, j_count, plan); }
+
+int nb_set_plan_override(int bodies_per_lane, int lanes_per_body, int tile_bodies) {
+    auto ok = [](int v, std::initializer_list<int> allowed) {
+        for (int a : allowed)
+            if (v == a) return true;
+        return false;
+    };
+    if (!ok(bodies_per_lane, {0, 1, 2, 4}) || !ok(lanes_per_body, {0, 1, 2, 4}) || !ok(tile_bodies, {0, 256, 512, 1024})) return NB_ERR_INVALID_ARGUMENT;
+    g_ovr_i.store(bodies_per_lane);
+    g_ovr_s.store(lanes_per_body);
+    g_ovr_tile.store(tile_bodies);
+    return 0;
+}
+
+}  // extern "C"

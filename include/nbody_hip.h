@@ -1,0 +1,157 @@
+/*
+ * nbody_hip.h -- C-ABI of the MI355X (gfx950) all-pairs N-body hot path.
+ *
+ * This is the drop-in boundary for the reference's device seam: plain pointers and sizes, no C++,
+ * HIP or torch types.  The library (libnbody_hip.so) keeps the reference's ownership rules: the
+ * CALLER owns every device array and passes raw device pointers; the callee allocates nothing per
+ * call and keeps no state except the two per-precision softening^2 values (process-global, exactly
+ * like the reference's __constant__ pair).
+ *
+ * Every entry point returns 0 on success or a non-zero hipError_t value (NB_ERR_* for argument
+ * errors detected on the host); nb_error_string() names it.  Nothing here prints or exits: the
+ * reference's print+exit(1) / throw behaviour is reproduced by the C++ wrappers in
+ * cuda-nbody_amd/host/integrate_nbody_hip.hpp so a host can keep its own error policy.
+ *
+ * All reference citations are relative to j-horner/cuda-nbody (/root/reference/).
+ *
+ * Data layout (identical to the reference's, src/nbody/bodysystemcuda.cu:148):
+ *   positions  T[4*N]  = {x, y, z, mass} per body   (float4 / double4, 16-/32-byte aligned)
+ *   velocities T[4*N]  = {vx, vy, vz, unused} per body (.w is preserved, never interpreted)
+ */
+#ifndef NBODY_HIP_H
+#define NBODY_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NB_API __attribute__((visibility("default")))
+
+/* Host-side argument errors (outside hipError_t's range). */
+#define NB_ERR_INVALID_ARGUMENT 10001
+#define NB_ERR_UNSUPPORTED      10002
+
+/* Arithmetic mode of the integrate entry points. */
+enum {
+    /* Bit-reproduces the reference's CPU BodySystem path (src/nbody/bodysystemcpu.cpp:140-303): one lane
+     * per body i, j = 0..N-1 in order, the CPU's exact op order, IEEE sqrt and divide, no FMA contraction. */
+    NB_MODE_STRICT = 0,
+    /* The production kernel: bodyBodyInteraction's op sequence (src/nbody/bodysystemcuda.cu:98-123) with
+     * v_rsq / FMA, register-tiled and j-split; summation order differs from the CPU path. */
+    NB_MODE_FAST = 1
+};
+
+/* Flags of nb_integrate_shard_*. */
+enum {
+    NB_SHARD_ACC_IN   = 1, /* start from the partial accelerations in acc[] instead of zero             */
+    NB_SHARD_FINALIZE = 2  /* integrate and store new_pos / vel; otherwise store partial sums to acc[]  */
+};
+
+typedef void* nb_stream_t; /* hipStream_t; NULL = the default stream (what the reference uses)          */
+typedef void* nb_event_t;  /* hipEvent_t                                                                */
+
+typedef struct nb_device_info {
+    char   name[256];      /* marketing name, e.g. "AMD Instinct MI355X"                                */
+    char   arch[64];       /* gcnArchName, e.g. "gfx950:sramecc+:xnack-"                                */
+    int    compute_units;  /* replaces multiprocessor_count(), src/nbody/compute_cuda.cpp:113           */
+    int    wavefront_size;
+    int    clock_khz;
+    int    can_map_host_memory; /* replaces can_map_host_memory(), compute_cuda.cpp:78                  */
+    int    lds_bytes_per_cu;
+    size_t total_memory;
+} nb_device_info_t;
+
+/* ---- errors ------------------------------------------------------------------------------------ */
+NB_API const char* nb_error_string(int code);            /* replaces cudaGetErrorName/String, bodysystemcuda.cu:50,212 */
+
+/* ---- device query (replaces cuda-api-wrappers use in src/nbody/compute_cuda.cpp:16-48,68-96,113) -- */
+NB_API int nb_device_count(int* count);
+NB_API int nb_set_device(int device);
+NB_API int nb_get_device(int* device);
+NB_API int nb_device_info(int device, nb_device_info_t* out);
+
+/* ---- storage (replaces thrust::device_vector + thrust::copy, bodysystemcuda_default.hpp:34-35,
+ *      bodysystemcuda_default.cu:26-55; mapped host memory replaces unique_mapped_span.cpp:11-27) ----- */
+NB_API int nb_alloc(void** device_ptr, size_t bytes);
+NB_API int nb_free(void* device_ptr);
+NB_API int nb_memset(void* device_ptr, int value, size_t bytes, nb_stream_t stream);
+NB_API int nb_h2d(void* device_dst, const void* host_src, size_t bytes, nb_stream_t stream); /* blocking */
+NB_API int nb_d2h(void* host_dst, const void* device_src, size_t bytes, nb_stream_t stream); /* blocking */
+NB_API int nb_d2d(void* device_dst, const void* device_src, size_t bytes, nb_stream_t stream); /* async  */
+NB_API int nb_host_alloc_mapped(void** host_ptr, void** device_ptr, size_t bytes);
+NB_API int nb_host_free(void* host_ptr);
+
+/* ---- streams and events (replaces cuda::event_t, compute_cuda.cpp:66-67,149,188,239,263-271) ------ */
+NB_API int nb_stream_create(nb_stream_t* stream);
+NB_API int nb_stream_destroy(nb_stream_t stream);
+NB_API int nb_stream_synchronize(nb_stream_t stream);
+NB_API int nb_stream_wait_event(nb_stream_t stream, nb_event_t event);
+NB_API int nb_event_create(nb_event_t* event);
+NB_API int nb_event_destroy(nb_event_t event);
+NB_API int nb_event_record(nb_event_t event, nb_stream_t stream);
+NB_API int nb_event_synchronize(nb_event_t event);
+NB_API int nb_event_elapsed_ms(float* ms, nb_event_t start, nb_event_t stop);
+NB_API int nb_device_synchronize(void);                  /* replaces cudaDeviceSynchronize, compute_cuda.cpp:155,180 */
+
+/* ---- softening (replaces set_softening_squared(float|double), decl src/nbody/bodysystemcuda.cpp:37-38,
+ *      def src/nbody/bodysystemcuda.cu:46-60).  Host-side state handed to each launch as a kernel
+ *      argument; one value per precision, as in the reference. ---------------------------------------- */
+NB_API int nb_set_softening_sq_f32(float softening_sq);
+NB_API int nb_set_softening_sq_f64(double softening_sq);
+NB_API int nb_get_softening_sq_f32(float* softening_sq);
+NB_API int nb_get_softening_sq_f64(double* softening_sq);
+
+/* ---- the hot path (replaces integrateNbodySystem<T>, decl src/nbody/integrate_nbody_cuda.hpp:5,
+ *      def src/nbody/bodysystemcuda.cu:186-215, explicit instantiations :218-220).
+ *
+ *  One leapfrog-style step for all N bodies: a_i = sum_j m_j r_ij / (|r_ij|^2 + eps^2)^(3/2)
+ *  (self-interaction included, exactly 0 for eps > 0), v = (v + a*dt)*damping, p += v*dt, written to
+ *  new_positions (must not alias old_positions) and, in place, to velocities.  Asynchronous on
+ *  `stream`.  Unlike the reference kernel (wrong unless N % blockSize == 0, :153-155) any N >= 1 works.
+ *  `block_size` is the reference's --blockSize: in STRICT mode it is the LDS tile / workgroup size
+ *  (multiple of 64, <= 1024); FAST mode treats it as a hint and picks its own tiling. ---------------- */
+NB_API int nb_integrate_f32(float* new_positions, const float* old_positions, float* velocities,
+                            float delta_time, float damping, unsigned num_bodies, int block_size,
+                            int mode, nb_stream_t stream);
+NB_API int nb_integrate_f64(double* new_positions, const double* old_positions, double* velocities,
+                            double delta_time, double damping, unsigned num_bodies, int block_size,
+                            int mode, nb_stream_t stream);
+
+/* ---- sharded form for multi-GPU body sharding (new; the reference is single-GPU).
+ *
+ *  Bodies i in [i_begin, i_begin+i_count) accumulate the pull of bodies j in [j_begin, j_begin+j_count)
+ *  of old_positions (all arrays are full-size and indexed by global body id).  acc is T[4*N] scratch
+ *  holding partial accelerations between calls (flags: NB_SHARD_ACC_IN / NB_SHARD_FINALIZE).
+ *  nb_integrate_* == one shard call with i = j = [0,N), flags = NB_SHARD_FINALIZE.
+ *  In STRICT mode chunks must be issued in ascending j order to keep the CPU path's summation order. */
+NB_API int nb_integrate_shard_f32(float* new_positions, const float* old_positions, float* velocities, float* acc,
+                                  unsigned i_begin, unsigned i_count, unsigned j_begin, unsigned j_count,
+                                  unsigned flags, float delta_time, float damping, int block_size, int mode,
+                                  nb_stream_t stream);
+NB_API int nb_integrate_shard_f64(double* new_positions, const double* old_positions, double* velocities, double* acc,
+                                  unsigned i_begin, unsigned i_count, unsigned j_begin, unsigned j_count,
+                                  unsigned flags, double delta_time, double damping, int block_size, int mode,
+                                  nb_stream_t stream);
+
+/* ---- introspection: the launch geometry the FAST path would use for a shard (tests / DESIGN.md) ---- */
+typedef struct nb_launch_plan {
+    int bodies_per_lane;   /* I  : i-bodies register-tiled per lane                  */
+    int lanes_per_body;    /* S  : lanes of one workgroup that split the j range     */
+    int tile_bodies;       /* LDS tile, bodies                                       */
+    int block_threads;
+    unsigned grid_blocks;
+    unsigned lds_bytes;
+} nb_launch_plan_t;
+NB_API int nb_plan_f32(unsigned i_count, unsigned j_count, nb_launch_plan_t* plan);
+NB_API int nb_plan_f64(unsigned i_count, unsigned j_count, nb_launch_plan_t* plan);
+/* Override the automatic plan (0 = automatic) -- used by the tuning sweep in bench.py --sweep. */
+NB_API int nb_set_plan_override(int bodies_per_lane, int lanes_per_body, int tile_bodies);
+
+NB_API const char* nb_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NBODY_HIP_H */

@@ -1,0 +1,53 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import __graft_entry__ as entry  # noqa: E402
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def O():
+    """The oracle module (test infrastructure)."""
+    mod = entry.load_oracle()
+    mod.build()
+    return mod
+
+
+@pytest.fixture(scope="session")
+def oracle(O):
+    return O.Oracle()
+
+
+@pytest.fixture(scope="session")
+def pkg():
+    return entry.load_package()
+
+
+@pytest.fixture(scope="session")
+def gpu(pkg):
+    """Loads libnbody_hip.so and selects device 0; fails (does not skip) when the extension is missing."""
+    pkg.lib()
+    assert pkg.device_count() >= 1, "no HIP device visible"
+    pkg.check(pkg.lib().nb_set_device(0), "nb_set_device")
+    return pkg
+
+
+GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
+
+
+def load_golden(n, tag):
+    return np.load(os.path.join(GOLDEN_DIR, f"shell_n{n}_{tag}.npz"), allow_pickle=False)
+
+
+def xyz(a):
+    return a.reshape(-1, 4)[:, :3]

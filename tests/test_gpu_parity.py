@@ -1,0 +1,257 @@
+"""GPU parity tests (run with -m gpu on an MI355X).  Everything goes through the C-ABI (libnbody_hip.so via
+ctypes); the CPU oracle is only the checker.
+
+Bars:
+  STRICT mode  : bit-exact (0 ulp) against the oracle / golden vectors at any step count, fp32 and fp64.
+  FAST mode    : floating-point tolerance stated per test.  The system is chaotic (hard part 1):
+                 two legitimate fp32 roundings of the reference's own CPU code already differ by 6e-3 rel
+                 after 100 steps at N=1024, so FAST is held to (a) per-step force error vs an fp64 direct sum,
+                 (b) <= 2e-5 max-rel position error after 10 steps, (c) a 100-step MEDIAN rel error <= 1e-4,
+                 the north_star's figure.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+
+from conftest import load_golden, xyz
+
+pytestmark = pytest.mark.gpu
+
+DT = np.float32(0.016)
+
+
+def run_gpu(pkg, pos0, vel0, steps, mode, dt=DT, block_size=256, params=None):
+    n = pos0.size // 4
+    system = pkg.BodySystemHIP(n, block_size, params or pkg.NBodyParams(), pos0.dtype, pos0, vel0, mode=mode)
+    for _ in range(steps):
+        system.update(pos0.dtype.type(dt))
+    out = system.get_position().copy(), system.get_velocity().copy()
+    system.free()
+    return out
+
+
+# ---------------------------------------------------------------------------------------------- strict
+@pytest.mark.parametrize("tag,dtype", [("f32", np.float32), ("f64", np.float64)])
+@pytest.mark.parametrize("n", [256, 1024])
+def test_strict_matches_golden_bitwise(gpu, n, tag, dtype):
+    g = load_golden(n, tag)
+    system = gpu.BodySystemHIP(n, 256, gpu.NBodyParams(), dtype, g["pos_0"], g["vel_0"], mode=gpu.NB_MODE_STRICT)
+    done = 0
+    for s in (1, 10, 100):
+        for _ in range(s - done):
+            system.update(dtype(DT))
+        done = s
+        assert system.get_position().tobytes() == g[f"pos_{s}"].tobytes(), f"pos differs at step {s}"
+        assert system.get_velocity().tobytes() == g[f"vel_{s}"].tobytes(), f"vel differs at step {s}"
+    system.free()
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("n,block", [(1, 64), (8, 256), (63, 64), (200, 128), (1000, 256), (1024, 1024), (4096, 256), (5000, 512)])
+def test_strict_matches_oracle_bitwise_ragged(gpu, oracle, dtype, n, block):
+    """Any N >= 1 (the reference kernel needs N % blockSize == 0, bodysystemcuda.cu:153-155), variable masses,
+    damping != 1, several --blockSize values: still 0 ulp."""
+    oracle.srand(n)
+    pos0, vel0 = oracle.randomise(1, n, 1.54, 8.0, dtype)
+    pos0.reshape(n, 4)[:, 3] = np.linspace(0.25, 3.0, n).astype(dtype)
+    params = gpu.NBodyParams(softening=0.05, damping=0.995)
+    steps = 3
+    ref_pos, ref_vel = pos0.copy(), vel0.copy()
+    oracle.update(ref_pos, ref_vel, DT, steps=steps, softening=0.05, damping=0.995)
+    pos, vel = run_gpu(gpu, pos0, vel0, steps, gpu.NB_MODE_STRICT, block_size=block, params=params)
+    assert pos.tobytes() == ref_pos.tobytes()
+    assert vel.tobytes() == ref_vel.tobytes()
+
+
+def test_strict_zero_mass_padding_is_bit_neutral(gpu, oracle):
+    """tipsy pads with zero-mass bodies (tipsy.cpp:111-119): they must not perturb the real ones."""
+    pos0, vel0 = oracle.startup_state(1000, np.float32)
+    padded_p = np.concatenate([pos0, np.zeros(4 * 24, np.float32)])
+    padded_v = np.concatenate([vel0, np.zeros(4 * 24, np.float32)])
+    a, _ = run_gpu(gpu, pos0, vel0, 4, gpu.NB_MODE_STRICT)
+    b, _ = run_gpu(gpu, padded_p, padded_v, 4, gpu.NB_MODE_STRICT)
+    assert a.tobytes() == b[:4000].tobytes()
+
+
+# ---------------------------------------------------------------------------------------------- fast
+def rel_err(a, b):
+    """per-body |da| / |b|"""
+    return np.linalg.norm(xyz(a).astype(np.float64) - xyz(b).astype(np.float64), axis=1) / np.linalg.norm(xyz(b).astype(np.float64), axis=1)
+
+
+@pytest.mark.parametrize("n", [256, 1024])
+def test_fast_fp32_vs_golden(gpu, n):
+    g = load_golden(n, "f32")
+    system = gpu.BodySystemHIP(n, 256, gpu.NBodyParams(), np.float32, g["pos_0"], g["vel_0"], mode=gpu.NB_MODE_FAST)
+    done = 0
+    errs = {}
+    for s in (1, 10, 100):
+        for _ in range(s - done):
+            system.update(DT)
+        done = s
+        errs[s] = rel_err(system.get_position(), g[f"pos_{s}"])
+    system.free()
+    assert errs[1].max() <= 2e-6, errs[1].max()
+    assert errs[10].max() <= 2e-5, errs[10].max()
+    assert np.median(errs[100]) <= 1e-4, np.median(errs[100])  # the north_star figure, on the median (chaos)
+
+
+@pytest.mark.parametrize("n", [256, 1024])
+def test_fast_fp64_vs_golden(gpu, n):
+    g = load_golden(n, "f64")
+    system = gpu.BodySystemHIP(n, 256, gpu.NBodyParams(), np.float64, g["pos_0"], g["vel_0"], mode=gpu.NB_MODE_FAST)
+    done = 0
+    errs = {}
+    for s in (1, 10, 100):
+        for _ in range(s - done):
+            system.update(np.float64(DT))
+        done = s
+        errs[s] = rel_err(system.get_position(), g[f"pos_{s}"])
+    system.free()
+    # fp64: Newton-refined v_rsq_f64 vs the CPU's sqrt and divide
+    assert errs[1].max() <= 1e-14, errs[1].max()
+    assert errs[10].max() <= 1e-12, errs[10].max()
+    assert errs[100].max() <= 1e-8, errs[100].max()
+
+
+def gpu_accel(gpu, pos, dtype, i_begin, i_count, j_begin, j_count, mode, acc_in=None):
+    """partial accelerations through nb_integrate_shard_* (no finalize)"""
+    n = pos.size // 4
+    lib = gpu.lib()
+    d_pos, d_acc = gpu.DeviceBuffer(pos.nbytes), gpu.DeviceBuffer(pos.nbytes)
+    d_pos.upload(pos)
+    flags = 0
+    if acc_in is not None:
+        d_acc.upload(acc_in)
+        flags |= gpu.NB_SHARD_ACC_IN
+    fn = lib.nb_integrate_shard_f32 if dtype == np.float32 else lib.nb_integrate_shard_f64
+    gpu.check(fn(None, d_pos.ptr, None, d_acc.ptr, i_begin, i_count, j_begin, j_count, flags, dtype(DT), dtype(1), 256, mode, None))
+    out = d_acc.download(np.zeros(4 * n, dtype=dtype)).copy()
+    d_pos.free(), d_acc.free()
+    return out
+
+
+@pytest.mark.parametrize("plan", [(1, 1, 256), (1, 1, 1024), (2, 1, 1024), (4, 1, 512), (1, 2, 1024), (2, 4, 256), (4, 4, 1024), (1, 4, 512)])
+def test_fast_force_error_every_geometry(gpu, oracle, plan):
+    """Every (bodies/lane, lane-groups, tile) instantiation against an fp64 direct sum, ragged N and ranges."""
+    n = 3000
+    gpu.set_softening_squared(np.float32(0.1) * np.float32(0.1))
+    oracle.srand(3)
+    pos, _ = oracle.randomise(0, n, 1.54, 8.0, np.float32)
+    pos.reshape(n, 4)[:, 3] = np.linspace(0.5, 2.0, n).astype(np.float32)
+    gpu.set_plan_override(*plan)
+    try:
+        acc = gpu_accel(gpu, pos, np.float32, 0, n, 0, n, gpu.NB_MODE_FAST)
+    finally:
+        gpu.set_plan_override(0, 0, 0)
+    ref = oracle.accel_f64(pos, 0, n)
+    err = np.linalg.norm(xyz(acc) - ref, axis=1) / np.linalg.norm(ref, axis=1)
+    assert err.max() < 5e-6, err.max()
+    assert np.all(acc.reshape(n, 4)[:, 3] == 0)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("mode_name", ["strict", "fast"])
+def test_shard_chunks_compose(gpu, oracle, dtype, mode_name):
+    """Multi-GPU form: i-slice x j-chunks chained through acc == one pass over all j.
+    STRICT with ascending chunks: bitwise.  FAST: rounding-level."""
+    mode = gpu.NB_MODE_STRICT if mode_name == "strict" else gpu.NB_MODE_FAST
+    n = 2500
+    eps = dtype(np.float32(0.1))
+    gpu.set_softening_squared(eps * eps)
+    oracle.srand(11)
+    pos, _ = oracle.randomise(1, n, 1.54, 8.0, dtype)
+    whole = gpu_accel(gpu, pos, dtype, 0, n, 0, n, mode)
+    i0, ni = 700, 1300
+    cuts = [0, 640, 1000, 1001, 2500]
+    acc = None
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        acc = gpu_accel(gpu, pos, dtype, i0, ni, a, b - a, mode, acc_in=acc)
+    got, want = acc.reshape(n, 4)[i0:i0 + ni], whole.reshape(n, 4)[i0:i0 + ni]
+    if mode == gpu.NB_MODE_STRICT:
+        assert got.tobytes() == want.tobytes()
+    else:
+        tol = 2e-6 if dtype == np.float32 else 1e-14
+        err = np.linalg.norm(got[:, :3] - want[:, :3], axis=1) / np.linalg.norm(want[:, :3], axis=1)
+        assert err.max() < tol, err.max()
+    # untouched rows stay zero (only the i-slice is written)
+    assert not acc.reshape(n, 4)[:i0].any() and not acc.reshape(n, 4)[i0 + ni:].any()
+
+
+def test_fast_handles_tiny_and_ragged_n(gpu, oracle):
+    for n in (1, 2, 63, 65, 257, 1023, 1025):
+        oracle.srand(n)
+        pos0, vel0 = oracle.randomise(1, n, 1.54, 8.0, np.float32)
+        ref_pos, ref_vel = pos0.copy(), vel0.copy()
+        oracle.update(ref_pos, ref_vel, DT, steps=2)
+        pos, vel = run_gpu(gpu, pos0, vel0, 2, gpu.NB_MODE_FAST)
+        assert rel_err(pos, ref_pos).max() < 2e-6, n
+        assert np.all(pos.reshape(n, 4)[:, 3] == 1) and np.all(vel.reshape(n, 4)[:, 3] == 0)
+
+
+# ---------------------------------------------------------------------------------------------- full size
+@pytest.mark.parametrize("n", [65536, 262144])
+def test_full_size_properties_fp32(gpu, oracle, n):
+    """BASELINE configs 2 and 3 (65 536 / 262 144 bodies): size-independent checks.
+      - sampled bodies' step against an fp64 direct sum over all N bodies (oracle yardstick),
+      - total momentum change ~ 0 (Newton's third law holds pairwise in the sum),
+      - .w untouched, ping-pong leaves the read buffer intact."""
+    pos0, vel0 = oracle.startup_state(n, np.float32)
+    system = gpu.BodySystemHIP(n, 256, gpu.NBodyParams(), np.float32, pos0, vel0, mode=gpu.NB_MODE_FAST)
+    system.update(DT)
+    pos1, vel1 = system.get_position().copy(), system.get_velocity().copy()
+    # old positions still in the other buffer
+    assert system._pos[1 - system.current_read].download(np.zeros_like(pos0)).tobytes() == pos0.tobytes()
+    system.free()
+    sample = np.arange(0, n, n // 64)[:64]
+    ref_acc = np.concatenate([oracle.accel_f64(pos0, int(i), 1) for i in sample])
+    dv = (xyz(vel1)[sample].astype(np.float64) - xyz(vel0)[sample].astype(np.float64)) / float(DT)
+    err = np.linalg.norm(dv - ref_acc, axis=1) / np.linalg.norm(ref_acc, axis=1)
+    assert err.max() < 2e-4, err.max()  # dv = v1 - v0 loses ~|v|/|a dt| digits to cancellation, hence 2e-4
+    m = pos0.reshape(n, 4)[:, 3:4].astype(np.float64)
+    dp = (m * (xyz(vel1).astype(np.float64) - xyz(vel0).astype(np.float64))).sum(axis=0)
+    scale = (m * np.abs(xyz(vel1).astype(np.float64) - xyz(vel0).astype(np.float64))).sum()
+    assert np.abs(dp).max() / scale < 1e-5
+    assert np.all(pos1.reshape(n, 4)[:, 3] == 1) and np.all(vel1.reshape(n, 4)[:, 3] == 0)
+    np.testing.assert_allclose(xyz(pos1), xyz(pos0) + xyz(vel1) * DT, rtol=1e-6, atol=1e-6)
+
+
+def test_full_size_strict_equals_fast_fp64_sampled(gpu, oracle):
+    """BASELINE config 5 (262 144 bodies, fp64): fast vs fp64 direct sum on sampled bodies."""
+    n = 262144
+    pos0, vel0 = oracle.startup_state(n, np.float64)
+    system = gpu.BodySystemHIP(n, 256, gpu.NBodyParams(), np.float64, pos0, vel0, mode=gpu.NB_MODE_FAST)
+    system.update(np.float64(DT))
+    vel1 = system.get_velocity().copy()
+    system.free()
+    sample = np.arange(0, n, n // 16)[:16]
+    eps2 = float(oracle.softening_sq(0.1, np.float64))
+    p = pos0.reshape(n, 4)
+    for i in sample:
+        d = p[:, :3] - p[i, :3]
+        r2 = (d * d).sum(axis=1) + eps2
+        a = (d * (p[:, 3] / (r2 * np.sqrt(r2)))[:, None]).sum(axis=0)
+        dv = (vel1.reshape(n, 4)[i, :3] - vel0.reshape(n, 4)[i, :3]) / float(DT)
+        assert np.linalg.norm(dv - a) / np.linalg.norm(a) < 1e-10
+
+
+def test_errors_are_reported_not_swallowed(gpu):
+    lib = gpu.lib()
+    buf = gpu.DeviceBuffer(4096)
+    # new == old is rejected (the reference's __restrict__ contract)
+    assert lib.nb_integrate_f32(buf.ptr, buf.ptr, buf.ptr, 0.016, 1.0, 64, 256, gpu.NB_MODE_FAST, None) == 10001
+    # bad --blockSize in strict mode
+    other = gpu.DeviceBuffer(4096)
+    assert lib.nb_integrate_f32(other.ptr, buf.ptr, buf.ptr, 0.016, 1.0, 64, 100, gpu.NB_MODE_STRICT, None) == 10001
+    # misaligned float4 pointer
+    assert lib.nb_integrate_f32(ctypes.c_void_p(other.ptr.value + 4), buf.ptr, buf.ptr, 0.016, 1.0, 64, 256, gpu.NB_MODE_FAST, None) == 10001
+    with pytest.raises(gpu.NBodyHipError):
+        gpu.check(10001, "x")
+    buf.free(), other.free()
+
+
+def test_device_is_gfx950(gpu):
+    info = gpu.device_info(0)
+    assert info.arch.decode().startswith("gfx950"), info.arch
+    assert info.wavefront_size == 64 and info.compute_units == 256
