@@ -1,18 +1,25 @@
 // nbody_fast.hip -- the production all-pairs kernels (NB_MODE_FAST).  gfx950 (CDNA4) only.
 //
 // What it computes is the reference kernel's bodyBodyInteraction / computeBodyAccel / integrateBodies
-// (/root/reference/src/nbody/bodysystemcuda.cu:98-184); how it is laid out is MI355X-first:
+// (/root/reference/src/nbody/bodysystemcuda.cu:98-184); how it is laid out is MI355X-first and follows
+// what tools/valu_microbench.hip measured on the chip (profiles/round1_valu_microbench.txt):
 //
-//   * VALU-issue bound (13 VALU ops + 1 double-cost v_rsq_f32 per interaction, no MFMA: a 3-vector
-//     accumulate is not a contraction).  Everything else is arranged so the VALU never waits.
-//   * 256-thread workgroups = 4 wave64.  Each lane register-tiles I bodies i (I x 6 VGPRs of state), so one
-//     broadcast ds_read_b128 of a body j feeds I x 13 VALU ops.
-//   * j bodies stream HBM/L2 -> registers -> LDS in tiles of TILE = 256*LPT float4 (coalesced 16 B/lane
+//   * The loop is VALU-issue bound: no MFMA (a 3-vector accumulate is not a contraction), HBM traffic is
+//     64 B per body per step.  On gfx950 the PACKED fp32 ops (v_pk_add/mul/fma_f32) deliver 1.2-1.4x the
+//     lane-throughput of their scalar forms, and v_rsq_f32 costs ~2.6 FMA slots.  So for fp32 each lane
+//     carries its bodies i in PAIRS, one pair per 64-bit VGPR pair: an interaction pair is
+//     3 v_pk_add + 6 v_pk_fma + 3 v_pk_mul + 2 v_rsq_f32 (14 issue slots for 2 interactions instead of 26),
+//     the j body's x/y/z/m being broadcast into both halves with op_sel, not moved.
+//     fp64 has no packed form: one body per "vector", v_rsq_f64 seed + 2 Newton steps.
+//   * 256-thread workgroups = 4 wave64.  Each lane register-tiles R vectors (I = R*W bodies i, W = 2 fp32 /
+//     1 fp64), so one broadcast ds_read_b128 of a body j feeds I interactions.
+//   * j bodies stream HBM/L2 -> registers -> LDS in tiles of TILE = 256*LPT bodies (coalesced 16 B/lane
 //     global_load_dwordx4), double-buffered: tile t+1 is in flight in registers while tile t is consumed
 //     from LDS; ONE barrier per tile.
-//   * j-split: the S = 256/L lane groups of a workgroup (whole waves, L = 64..256 lanes) walk disjoint
-//     1/S slices of every tile for the SAME bodies i and are reduced through LDS in a fixed order at the
-//     end (deterministic).  This is what fills 256 CUs x 4 SIMDs x >=2 waves when N/I < 131072 lanes.
+//   * j-split: the S lane groups of a workgroup (whole waves, L = 256/S lanes) walk disjoint 1/S slices of
+//     every tile for the SAME bodies i and are folded through LDS in a fixed order at the end
+//     (deterministic).  This is what puts >= 2-4 waves on every SIMD of 256 CUs when N/I < 131072 lanes.
+//   * softening^2 lives in VGPRs: a VALU op with an SGPR source issues ~35 % slower on this chip.
 //   * The shard form (i-range x j-range, optional partial sums in/out) is the same kernel; the single-GPU
 //     step is the shard i = j = [0,N) with finalize.
 //
@@ -27,53 +34,82 @@ namespace {
 
 constexpr int kBlock = 256;
 
-template <typename T> struct V4;
-template <> struct V4<float> { using type = float4; };
-template <> struct V4<double> { using type = double4; };
+typedef float v2f __attribute__((ext_vector_type(2)));
 
-// 1/sqrt(x): fp32 = one v_rsq_f32 (1 ulp); fp64 = v_rsq_f64 seed + 2 Newton-Raphson steps
-// (the reference calls CUDA's rsqrtf / rsqrt here, bodysystemcuda.cu:74-84).
-__device__ __forceinline__ float rsqrt_T(float x) { return __builtin_amdgcn_rsqf(x); }
-__device__ __forceinline__ double rsqrt_T(double x) {
-    double y = __builtin_amdgcn_rsq(x);
-    // y <- y * (1.5 - 0.5*x*y*y), written as y + y*(0.5 - 0.5*x*y*y) for a smaller final rounding error
-    const double hx = 0.5 * x;
-    double       e  = __builtin_fma(-hx * y, y, 0.5);
-    y               = __builtin_fma(y, e, y);
-    e               = __builtin_fma(-hx * y, y, 0.5);
-    y               = __builtin_fma(y, e, y);
-    return y;
-}
+// ---- per-precision traits: the "vector" a lane computes with -------------------------------------------
+template <typename T> struct Lane;
 
-__device__ __forceinline__ float  fma_T(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
-__device__ __forceinline__ double fma_T(double a, double b, double c) { return __builtin_fma(a, b, c); }
+template <> struct Lane<float> {
+    using vec4                 = float4;
+    using vec                  = v2f;  // two bodies i per vector -> v_pk_*_f32
+    static constexpr int W     = 2;
+    static __device__ __forceinline__ vec  splat(float a) { return vec{a, a}; }
+    static __device__ __forceinline__ vec  fma(vec a, vec b, vec c) { return __builtin_elementwise_fma(a, b, c); }
+    static __device__ __forceinline__ vec  rsqrt(vec a) { return vec{__builtin_amdgcn_rsqf(a.x), __builtin_amdgcn_rsqf(a.y)}; }  // 2 x v_rsq_f32 (1 ulp)
+    static __device__ __forceinline__ float get(vec a, int w) { return w == 0 ? a.x : a.y; }
+    static __device__ __forceinline__ void  set(vec& a, int w, float v) {
+        if (w == 0) a.x = v; else a.y = v;
+    }
+    static __device__ __forceinline__ void  keep_in_vgpr(vec& a) { asm volatile("" : "+v"(a)); }
+};
 
-// bodyBodyInteraction, bodysystemcuda.cu:98-123, for one body j against the I bodies i of this lane.
-template <typename T, int I> __device__ __forceinline__ void interact(const typename V4<T>::type bj, const T (&px)[I], const T (&py)[I], const T (&pz)[I], T (&ax)[I], T (&ay)[I], T (&az)[I], const T eps2) {
+template <> struct Lane<double> {
+    using vec4                 = double4;
+    using vec                  = double;
+    static constexpr int W     = 1;
+    static __device__ __forceinline__ vec splat(double a) { return a; }
+    static __device__ __forceinline__ vec fma(vec a, vec b, vec c) { return __builtin_fma(a, b, c); }
+    // the reference calls CUDA's rsqrt(double) (bodysystemcuda.cu:82-84); here v_rsq_f64 seed + 2 Newton-Raphson
+    // steps  y <- y + y*(0.5 - 0.5*x*y*y)
+    static __device__ __forceinline__ vec rsqrt(vec x) {
+        double       y  = __builtin_amdgcn_rsq(x);
+        const double hx = 0.5 * x;
+        double       e  = __builtin_fma(-hx * y, y, 0.5);
+        y               = __builtin_fma(y, e, y);
+        e               = __builtin_fma(-hx * y, y, 0.5);
+        y               = __builtin_fma(y, e, y);
+        return y;
+    }
+    static __device__ __forceinline__ double get(vec a, int) { return a; }
+    static __device__ __forceinline__ void   set(vec& a, int, double v) { a = v; }
+    static __device__ __forceinline__ void   keep_in_vgpr(vec& a) { asm volatile("" : "+v"(a)); }
+};
+
+// bodyBodyInteraction, bodysystemcuda.cu:98-123, for one body j against the R vectors of bodies i of this lane.
+template <typename T, int R>
+__device__ __forceinline__ void interact(const typename Lane<T>::vec4 bj, const typename Lane<T>::vec (&px)[R], const typename Lane<T>::vec (&py)[R], const typename Lane<T>::vec (&pz)[R], typename Lane<T>::vec (&ax)[R],
+                                         typename Lane<T>::vec (&ay)[R], typename Lane<T>::vec (&az)[R], const typename Lane<T>::vec eps2) {
+    using L   = Lane<T>;
+    using vec = typename L::vec;
+    const vec bx = L::splat(bj.x), by = L::splat(bj.y), bz = L::splat(bj.z), bm = L::splat(bj.w);
 #pragma unroll
-    for (int k = 0; k < I; ++k) {
-        const T dx   = bj.x - px[k];
-        const T dy   = bj.y - py[k];
-        const T dz   = bj.z - pz[k];
-        T       d2   = fma_T(dx, dx, eps2);
-        d2           = fma_T(dy, dy, d2);
-        d2           = fma_T(dz, dz, d2);
-        const T inv  = rsqrt_T(d2);
-        const T inv2 = inv * inv;
-        const T s    = (bj.w * inv) * inv2;
-        ax[k]        = fma_T(dx, s, ax[k]);
-        ay[k]        = fma_T(dy, s, ay[k]);
-        az[k]        = fma_T(dz, s, az[k]);
+    for (int r = 0; r < R; ++r) {
+        const vec dx   = bx - px[r];
+        const vec dy   = by - py[r];
+        const vec dz   = bz - pz[r];
+        vec       d2   = L::fma(dx, dx, eps2);
+        d2             = L::fma(dy, dy, d2);
+        d2             = L::fma(dz, dz, d2);
+        const vec inv  = L::rsqrt(d2);
+        const vec inv2 = inv * inv;
+        const vec s    = (bm * inv) * inv2;
+        ax[r]          = L::fma(dx, s, ax[r]);
+        ay[r]          = L::fma(dy, s, ay[r]);
+        az[r]          = L::fma(dz, s, az[r]);
     }
 }
 
-// T: float|double   I: bodies i per lane   S: lane groups splitting j (1,2,4)   LPT: float4 loads per thread per tile
-template <typename T, int I, int S, int LPT> __global__ __launch_bounds__(kBlock) void integrate_bodies_fast(Shard<T> s) {
-    using vec4          = typename V4<T>::type;
-    constexpr int TILE  = kBlock * LPT;      // bodies j per LDS tile
-    constexpr int L     = kBlock / S;        // lanes per group = bodies i per "row"
-    constexpr int SLICE = TILE / S;          // bodies j per group per tile
-    constexpr int BODIES_PER_BLOCK = L * I;  // bodies i per workgroup
+// T: float|double   R: vectors per lane (I = R*W bodies i)   S: lane groups splitting j   LPT: vec4 loads per thread per tile
+template <typename T, int R, int S, int LPT> __global__ __launch_bounds__(kBlock) void integrate_bodies_fast(Shard<T> s) {
+    using LT            = Lane<T>;
+    using vec4          = typename LT::vec4;
+    using vec           = typename LT::vec;
+    constexpr int W     = LT::W;
+    constexpr int I     = R * W;         // bodies i per lane
+    constexpr int TILE  = kBlock * LPT;  // bodies j per LDS tile
+    constexpr int L     = kBlock / S;    // lanes per group
+    constexpr int SLICE = TILE / S;      // bodies j per group per tile
+    constexpr int BODIES_PER_BLOCK = L * I;
     static_assert(L % 64 == 0, "a lane group must be whole waves so the LDS read stays a broadcast");
     static_assert(SLICE % 8 == 0, "inner loop is unrolled by 8");
 
@@ -85,9 +121,9 @@ template <typename T, int I, int S, int LPT> __global__ __launch_bounds__(kBlock
     const int group = tid / L;
     const int lane  = tid - group * L;
 
-    // bodies i of this lane: block_base + k*L + lane  (coalesced across the lanes of a group)
+    // bodies i of this lane: block_base + k*L + lane, k = r*W + w  (coalesced across the lanes of a group)
     const unsigned block_base = blockIdx.x * BODIES_PER_BLOCK;
-    T        px[I], py[I], pz[I], ax[I], ay[I], az[I];
+    vec      px[R], py[R], pz[R], ax[R], ay[R], az[R];
     unsigned idx[I];
     bool     active[I];
 #pragma unroll
@@ -96,17 +132,23 @@ template <typename T, int I, int S, int LPT> __global__ __launch_bounds__(kBlock
         active[k]            = local < s.i_count;
         idx[k]               = s.i_begin + (active[k] ? local : s.i_count - 1);
         const vec4 p         = old_pos[idx[k]];
-        px[k] = p.x, py[k] = p.y, pz[k] = p.z;
-        ax[k] = ay[k] = az[k] = 0;
+        LT::set(px[k / W], k % W, p.x);
+        LT::set(py[k / W], k % W, p.y);
+        LT::set(pz[k / W], k % W, p.z);
     }
+#pragma unroll
+    for (int r = 0; r < R; ++r) ax[r] = ay[r] = az[r] = LT::splat(0);
     if (s.acc_in && group == 0) {
 #pragma unroll
         for (int k = 0; k < I; ++k) {
             const vec4 a = reinterpret_cast<const vec4*>(s.acc)[idx[k]];
-            ax[k] = a.x, ay[k] = a.y, az[k] = a.z;
+            LT::set(ax[k / W], k % W, a.x);
+            LT::set(ay[k / W], k % W, a.y);
+            LT::set(az[k / W], k % W, a.z);
         }
     }
-    const T eps2 = s.eps2;
+    vec eps2 = LT::splat(s.eps2);
+    LT::keep_in_vgpr(eps2);
 
     const unsigned j_end   = s.j_begin + s.j_count;
     const unsigned n_tiles = (s.j_count + TILE - 1) / TILE;
@@ -141,7 +183,7 @@ template <typename T, int I, int S, int LPT> __global__ __launch_bounds__(kBlock
 #pragma unroll 1
         for (int jj = 0; jj < SLICE; jj += 8) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) interact<T, I>(slice[jj + u], px, py, pz, ax, ay, az, eps2);
+            for (int u = 0; u < 8; ++u) interact<T, R>(slice[jj + u], px, py, pz, ax, ay, az, eps2);
         }
 
         if (have_next) store_tile(cur ^ 1, regs);
@@ -154,9 +196,9 @@ template <typename T, int I, int S, int LPT> __global__ __launch_bounds__(kBlock
         if (group > 0) {
 #pragma unroll
             for (int k = 0; k < I; ++k) {
-                red[(((group - 1) * 3 + 0) * I + k) * L + lane] = ax[k];
-                red[(((group - 1) * 3 + 1) * I + k) * L + lane] = ay[k];
-                red[(((group - 1) * 3 + 2) * I + k) * L + lane] = az[k];
+                red[(((group - 1) * 3 + 0) * I + k) * L + lane] = LT::get(ax[k / W], k % W);
+                red[(((group - 1) * 3 + 1) * I + k) * L + lane] = LT::get(ay[k / W], k % W);
+                red[(((group - 1) * 3 + 2) * I + k) * L + lane] = LT::get(az[k / W], k % W);
             }
         }
         __syncthreads();
@@ -165,9 +207,9 @@ template <typename T, int I, int S, int LPT> __global__ __launch_bounds__(kBlock
             for (int g = 1; g < S; ++g) {
 #pragma unroll
                 for (int k = 0; k < I; ++k) {
-                    ax[k] += red[(((g - 1) * 3 + 0) * I + k) * L + lane];
-                    ay[k] += red[(((g - 1) * 3 + 1) * I + k) * L + lane];
-                    az[k] += red[(((g - 1) * 3 + 2) * I + k) * L + lane];
+                    LT::set(ax[k / W], k % W, LT::get(ax[k / W], k % W) + red[(((g - 1) * 3 + 0) * I + k) * L + lane]);
+                    LT::set(ay[k / W], k % W, LT::get(ay[k / W], k % W) + red[(((g - 1) * 3 + 1) * I + k) * L + lane]);
+                    LT::set(az[k / W], k % W, LT::get(az[k / W], k % W) + red[(((g - 1) * 3 + 2) * I + k) * L + lane]);
                 }
             }
         }
@@ -177,69 +219,66 @@ template <typename T, int I, int S, int LPT> __global__ __launch_bounds__(kBlock
 #pragma unroll
     for (int k = 0; k < I; ++k) {
         if (!active[k]) continue;
-        const unsigned i = idx[k];
+        const unsigned i  = idx[k];
+        const T        fx = LT::get(ax[k / W], k % W), fy = LT::get(ay[k / W], k % W), fz = LT::get(az[k / W], k % W);
         if (s.finalize) {
             // integrateBodies, bodysystemcuda.cu:166-183
             vec4 v  = reinterpret_cast<const vec4*>(s.vel)[i];
             vec4 pn = old_pos[i];
-            v.x     = fma_T(ax[k], s.dt, v.x) * s.damping;
-            v.y     = fma_T(ay[k], s.dt, v.y) * s.damping;
-            v.z     = fma_T(az[k], s.dt, v.z) * s.damping;
-            pn.x    = fma_T(v.x, s.dt, pn.x);
-            pn.y    = fma_T(v.y, s.dt, pn.y);
-            pn.z    = fma_T(v.z, s.dt, pn.z);
+            v.x     = __builtin_fma(fx, s.dt, v.x) * s.damping;
+            v.y     = __builtin_fma(fy, s.dt, v.y) * s.damping;
+            v.z     = __builtin_fma(fz, s.dt, v.z) * s.damping;
+            pn.x    = __builtin_fma(v.x, s.dt, pn.x);
+            pn.y    = __builtin_fma(v.y, s.dt, pn.y);
+            pn.z    = __builtin_fma(v.z, s.dt, pn.z);
             reinterpret_cast<vec4*>(s.new_pos)[i] = pn;
             reinterpret_cast<vec4*>(s.vel)[i]     = v;
         } else {
             vec4 a;
-            a.x = ax[k], a.y = ay[k], a.z = az[k], a.w = 0;
+            a.x = fx, a.y = fy, a.z = fz, a.w = 0;
             reinterpret_cast<vec4*>(s.acc)[i] = a;
         }
     }
 }
 
-template <typename T, int I, int S, int LPT> hipError_t launch_one(const Shard<T>& s, const Plan& p, hipStream_t stream) {
-    hipLaunchKernelGGL((integrate_bodies_fast<T, I, S, LPT>), dim3(p.grid_blocks), dim3(kBlock), p.lds_bytes, stream, s);
+template <typename T, int R, int S, int LPT> hipError_t launch_one(const Shard<T>& s, const Plan& p, hipStream_t stream) {
+    hipLaunchKernelGGL((integrate_bodies_fast<T, R, S, LPT>), dim3(p.grid_blocks), dim3(kBlock), p.lds_bytes, stream, s);
     return hipGetLastError();
 }
 
-template <typename T, int I, int S> hipError_t dispatch_lpt(const Shard<T>& s, const Plan& p, hipStream_t stream) {
+template <typename T, int R, int S> hipError_t dispatch_lpt(const Shard<T>& s, const Plan& p, hipStream_t stream) {
     switch (p.tile_bodies / kBlock) {
-        case 1: return launch_one<T, I, S, 1>(s, p, stream);
-        case 2: return launch_one<T, I, S, 2>(s, p, stream);
-        case 4: return launch_one<T, I, S, 4>(s, p, stream);
+        case 1: return launch_one<T, R, S, 1>(s, p, stream);
+        case 2: return launch_one<T, R, S, 2>(s, p, stream);
+        case 4: return launch_one<T, R, S, 4>(s, p, stream);
         default: return hipErrorInvalidValue;
     }
 }
 
-template <typename T, int I> hipError_t dispatch_s(const Shard<T>& s, const Plan& p, hipStream_t stream) {
+template <typename T, int R> hipError_t dispatch_s(const Shard<T>& s, const Plan& p, hipStream_t stream) {
     switch (p.lanes_per_body) {
-        case 1: return dispatch_lpt<T, I, 1>(s, p, stream);
-        case 2: return dispatch_lpt<T, I, 2>(s, p, stream);
-        case 4: return dispatch_lpt<T, I, 4>(s, p, stream);
+        case 1: return dispatch_lpt<T, R, 1>(s, p, stream);
+        case 2: return dispatch_lpt<T, R, 2>(s, p, stream);
+        case 4: return dispatch_lpt<T, R, 4>(s, p, stream);
         default: return hipErrorInvalidValue;
     }
 }
 
 }  // namespace
 
-// Geometry: fill 256 CUs x 4 SIMDs with >= kWavesPerSimd waves if the shard is big enough, preferring
-// register tiling (I) over j-splitting (S) because I amortises the LDS broadcast and S costs a reduction.
+// Geometry.  bodies_per_lane I is a multiple of W (2 for fp32: bodies travel in packed pairs).
+// Fill 256 CUs x 4 SIMDs with >= 4 waves if the shard is big enough; prefer register tiling (I) over
+// j-splitting (S): I amortises the LDS broadcast, S costs an LDS fold at the end.
 template <typename T> Plan plan_fast(unsigned i_count, unsigned j_count, int cu_count, int ovr_i, int ovr_s, int ovr_tile) {
     (void)j_count;
-    const long lanes_wanted = static_cast<long>(cu_count) * 4 * 64 * 4;  // 4 waves per SIMD
-    int        I = 1, S = 1;
-    // largest I (<=2 fp32, 1 fp64) that still leaves enough lanes; then S to make up the rest
-    const int max_i = sizeof(T) == 4 ? 2 : 1;
-    for (int cand = max_i; cand >= 1; cand /= 2) {
-        if (static_cast<long>(i_count) / cand >= lanes_wanted || cand == 1) {
-            I = cand;
-            break;
-        }
-    }
+    constexpr int W            = Lane<T>::W;
+    const long    lanes_wanted = static_cast<long>(cu_count) * 4 * 64 * 4;  // 4 waves per SIMD
+    int           I            = 2 * W;                                      // fp32: 4 bodies (2 pairs); fp64: 2
+    while (I > W && static_cast<long>(i_count) / I * 4 < lanes_wanted) I /= 2;
+    int S = 1;
     while (S < 4 && static_cast<long>(i_count) / I * S < lanes_wanted) S *= 2;
-    int tile = 1024;
-    if (ovr_i > 0) I = ovr_i;
+    int tile = sizeof(T) == 4 ? 1024 : 512;
+    if (ovr_i > 0) I = std::max(ovr_i / W * W, W);
     if (ovr_s > 0) S = ovr_s;
     if (ovr_tile > 0) tile = ovr_tile;
 
@@ -257,7 +296,8 @@ template <typename T> Plan plan_fast(unsigned i_count, unsigned j_count, int cu_
 }
 
 template <typename T> hipError_t launch_fast(const Shard<T>& s, const Plan& p, hipStream_t stream) {
-    switch (p.bodies_per_lane) {
+    constexpr int W = Lane<T>::W;
+    switch (p.bodies_per_lane / W) {
         case 1: return dispatch_s<T, 1>(s, p, stream);
         case 2: return dispatch_s<T, 2>(s, p, stream);
         case 4: return dispatch_s<T, 4>(s, p, stream);

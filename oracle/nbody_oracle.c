@@ -48,6 +48,14 @@ ORACLE_API int  oracle_num_threads(void) {
 #endif
 }
 
+ORACLE_API void oracle_set_num_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 /* ------------------------------------------------------------------------------------------
  * BodySystemCPU<float>::update   src/nbody/bodysystemcpu.cpp:149-243
  *

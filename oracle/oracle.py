@@ -61,6 +61,7 @@ class Oracle:
         lib.oracle_srand.argtypes = [ctypes.c_uint]
         lib.oracle_rand.restype = ci
         lib.oracle_num_threads.restype = ci
+        lib.oracle_set_num_threads.argtypes = [ci]
         for name, fp, ft in (("f32", f32p, cf), ("f64", f64p, cd)):
             getattr(lib, f"oracle_update_{name}").argtypes = [fp, fp, sz, ft, ft, ft, ci]
             getattr(lib, f"oracle_update_{name}").restype = ci
@@ -98,6 +99,9 @@ class Oracle:
 
     def num_threads(self) -> int:
         return int(self.lib.oracle_num_threads())
+
+    def set_num_threads(self, n: int) -> None:
+        self.lib.oracle_set_num_threads(int(n))
 
     def srand(self, seed: int = 1) -> None:
         self.lib.oracle_srand(seed)

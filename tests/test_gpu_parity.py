@@ -132,7 +132,7 @@ def gpu_accel(gpu, pos, dtype, i_begin, i_count, j_begin, j_count, mode, acc_in=
     return out
 
 
-@pytest.mark.parametrize("plan", [(1, 1, 256), (1, 1, 1024), (2, 1, 1024), (4, 1, 512), (1, 2, 1024), (2, 4, 256), (4, 4, 1024), (1, 4, 512)])
+@pytest.mark.parametrize("plan", [(2, 1, 256), (2, 1, 1024), (4, 1, 1024), (8, 1, 512), (2, 2, 1024), (4, 4, 256), (8, 4, 1024), (2, 4, 512), (4, 2, 512), (8, 2, 256)])
 def test_fast_force_error_every_geometry(gpu, oracle, plan):
     """Every (bodies/lane, lane-groups, tile) instantiation against an fp64 direct sum, ragged N and ranges."""
     n = 3000
