@@ -1,0 +1,129 @@
+"""CPU test of the multi-GPU body sharding (cuda-nbody_amd/sharded.py) with world_size 2 (and 4) on gloo.
+
+The per-rank compute callable is bound to the CPU oracle here (test infrastructure standing in for
+nb_integrate_shard_*), so what is under test is the sharding itself: slice ownership, chunk schedule, flag
+chaining (ACC_IN / FINALIZE), the in-place all-gather and the ping-pong -- against the single-process oracle.
+ordered=True (STRICT schedule) must be bit-identical; ordered=False (own chunk first) rounding-level."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _oracle_shard_launch(n, dt, damping, eps2):
+    """Emulates nb_integrate_shard_f32 semantics on CPU tensors with numpy float32, strict op order
+    (the same arithmetic as oracle/nbody_oracle.c update_f32_scalar, restricted to an i-slice x j-chunk)."""
+    f = np.float32
+
+    def launch(new_pos, old_pos, vel, acc, i0, ni, j0, nj, flags):
+        p = old_pos.numpy()
+        a = acc.numpy()
+        sl = slice(i0, i0 + ni)
+        dv = a[sl, :3].copy() if flags & 1 else np.zeros((ni, 3), dtype=f)
+        pi = p[sl, :3]
+        for j in range(j0, j0 + nj):
+            d = p[j, :3][None, :] - pi
+            d2 = d * d
+            r2 = ((f(eps2) + d2[:, 0]) + d2[:, 1]) + d2[:, 2]
+            r = np.sqrt(r2)
+            m_r3 = (p[j, 3] / (r2 * r2)) * r
+            dv = dv + m_r3[:, None] * d
+        if flags & 2:
+            v = vel.numpy()
+            npos = new_pos.numpy()
+            v[sl, :3] = (v[sl, :3] + dv * f(dt)) * f(damping)
+            npos[sl, :3] = p[sl, :3] + v[sl, :3] * f(dt)
+            npos[sl, 3] = p[sl, 3]
+        else:
+            a[sl, :3] = dv
+            a[sl, 3] = 0
+
+    return launch
+
+
+def _worker(rank, world, port, n, steps, ordered, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+
+    import __graft_entry__ as entry
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        O = entry.load_oracle()
+        orc = O.Oracle()
+        pos0, vel0 = orc.startup_state(n, np.float32)
+        sharded = entry.load_package_module("sharded")
+        eps2 = orc.softening_sq(0.1, np.float32)
+        launch = _oracle_shard_launch(n, np.float32(0.016), np.float32(1.0), eps2)
+        system = sharded.ShardedBodySystem(torch.from_numpy(pos0.reshape(n, 4).copy()), torch.from_numpy(vel0.reshape(n, 4).copy()),
+                                           launch, ordered=ordered)
+        for _ in range(steps):
+            system.update()
+        pos = system.positions().numpy().copy()
+        vel = system.velocities().numpy().copy()
+        np.save(os.path.join(out_dir, f"pos_{rank}.npy"), pos)
+        np.save(os.path.join(out_dir, f"vel_{rank}.npy"), vel)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,ordered", [(2, True), (2, False), (4, False)])
+def test_sharded_step_matches_single_process_oracle(tmp_path, oracle, world, ordered):
+    import torch.multiprocessing as mp
+
+    n, steps = 256, 3
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, n, steps, ordered, str(tmp_path)), nprocs=world, join=True)
+    ref_pos, ref_vel = oracle.startup_state(n, np.float32)
+    oracle.update(ref_pos, ref_vel, np.float32(0.016), steps=steps)
+    for rank in range(world):
+        pos = np.load(tmp_path / f"pos_{rank}.npy").reshape(-1)
+        vel = np.load(tmp_path / f"vel_{rank}.npy").reshape(-1)
+        if ordered:
+            assert pos.tobytes() == ref_pos.tobytes(), f"rank {rank}: positions differ from the 1-process oracle"
+            assert vel.tobytes() == ref_vel.tobytes(), f"rank {rank}: velocities differ"
+        else:
+            np.testing.assert_allclose(pos, ref_pos, rtol=2e-5, atol=2e-5)
+            np.testing.assert_allclose(vel, ref_vel, rtol=2e-4, atol=2e-4)
+    # every rank ends with the same full position array
+    a = np.load(tmp_path / "pos_0.npy")
+    for rank in range(1, world):
+        assert a.tobytes() == np.load(tmp_path / f"pos_{rank}.npy").tobytes()
+
+
+def test_chunk_schedule_and_slices():
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as entry
+
+    sh = entry.load_package_module("sharded")
+    assert sh.slice_of(0, 8, 1048576) == (0, 131072)
+    assert sh.slice_of(7, 8, 1048576) == (917504, 131072)
+    with pytest.raises(ValueError):
+        sh.slice_of(0, 3, 1000)
+    # own chunk first, then below, then above; empty chunks dropped
+    assert sh.chunk_schedule(0, 64, 256, False) == [(0, 64, False), (64, 192, True)]
+    assert sh.chunk_schedule(64, 64, 256, False) == [(64, 64, False), (0, 64, True), (128, 128, True)]
+    assert sh.chunk_schedule(192, 64, 256, False) == [(192, 64, False), (0, 192, True)]
+    # strict order: ascending j, everything behind the gather
+    assert sh.chunk_schedule(64, 64, 256, True) == [(0, 64, True), (64, 64, True), (128, 128, True)]
+    assert sh.chunk_schedule(0, 256, 256, False) == [(0, 256, False)]
+    # the chunks always tile [0, n) exactly once
+    for world in (1, 2, 4, 8):
+        for rank in range(world):
+            i0, ni = sh.slice_of(rank, world, 1024)
+            for ordered in (False, True):
+                cover = sorted((j0, j0 + nj) for j0, nj, _ in sh.chunk_schedule(i0, ni, 1024, ordered))
+                assert cover[0][0] == 0 and cover[-1][1] == 1024
+                assert all(a[1] == b[0] for a, b in zip(cover, cover[1:]))

@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Condense a tools/profile.sh run (gpurun_out/prof) into the tracked files under profiles/.
+
+  python tools/summarize_prof.py gpurun_out/prof profiles/round1
+
+writes <prefix>_kernel_stats.csv (rocprofv3 --kernel-trace --stats, verbatim),
+       <prefix>_pmc_summary.json (per-launch means of every counter for the dominant kernel + derived figures).
+HBM traffic follows MI355X_MICROARCH.md "HBM": FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports
+exactly half the bytes of a wide (16 B/lane) coalesced read stream, so reads = 2 * FETCH_SIZE * 1024;
+WRITE_SIZE is exact for 16 B/lane stores.
+"""
+import collections
+import csv
+import glob
+import json
+import shutil
+import sys
+
+src, prefix = sys.argv[1], sys.argv[2]
+KERNEL = sys.argv[3] if len(sys.argv) > 3 else "integrate_bodies_fast"
+
+stats = glob.glob(f"{src}/trace/*/*_kernel_stats.csv")[0]
+shutil.copy(stats, f"{prefix}_kernel_stats.csv")
+kernel_row = next(r for r in csv.DictReader(open(stats)) if KERNEL in r["Name"])
+
+counters = {}
+meta = {}
+for f in glob.glob(f"{src}/pmc_*/*/*_counter_collection.csv"):
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        if KERNEL in r["Kernel_Name"]:
+            agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+            meta = {k: r[k] for k in ("Kernel_Name", "Grid_Size", "Workgroup_Size", "LDS_Block_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "Scratch_Size")}
+    for k, v in agg.items():
+        counters[k] = sum(v) / len(v)
+
+avg_ns = float(kernel_row["AverageNs"])
+out = {"kernel": meta, "launches_profiled": int(kernel_row["Calls"]), "kernel_trace_avg_ms": avg_ns * 1e-6,
+       "kernel_trace_min_ms": float(kernel_row["MinNs"]) * 1e-6, "counters_per_launch_mean": counters, "derived": {}}
+d = out["derived"]
+if "FETCH_SIZE" in counters and "WRITE_SIZE" in counters:
+    d["hbm_read_bytes_per_launch"] = 2 * counters["FETCH_SIZE"] * 1024
+    d["hbm_write_bytes_per_launch"] = counters["WRITE_SIZE"] * 1024
+    d["hbm_bytes_per_launch"] = d["hbm_read_bytes_per_launch"] + d["hbm_write_bytes_per_launch"]
+    d["hbm_GBps"] = d["hbm_bytes_per_launch"] / (avg_ns * 1e-9) / 1e9
+if "GRBM_GUI_ACTIVE" in counters:
+    d["effective_clock_GHz"] = counters["GRBM_GUI_ACTIVE"] / 8 / avg_ns  # summed over the 8 XCDs
+    cycles = counters["GRBM_GUI_ACTIVE"] / 8
+    if "SQ_ACTIVE_INST_VALU" in counters:
+        # SQ_ACTIVE_INST_* count quad-cycles summed over all SIMDs (256 CUs x 4)
+        d["valu_busy_fraction"] = counters["SQ_ACTIVE_INST_VALU"] * 4 / (cycles * 1024)
+if "SQ_INSTS_VALU" in counters:
+    d["valu_wave_instructions_per_launch"] = counters["SQ_INSTS_VALU"]
+json.dump(out, open(f"{prefix}_pmc_summary.json", "w"), indent=1)
+print(json.dumps(out["derived"], indent=1))
+print("kernel avg ms", out["kernel_trace_avg_ms"])
