@@ -1,0 +1,57 @@
+// bodysystemhip.hpp -- abstract GPU body system; the interface of the reference's BodySystemCUDA<T>
+// (/root/reference/src/nbody/bodysystemcuda.hpp:38-72) on HIP: same members, same virtuals, same ping-pong state.
+#pragma once
+
+#include "nbody_config.hpp"
+
+#include <concepts>
+#include <span>
+#include <vector>
+
+struct NBodyParams;
+
+template <std::floating_point T> class BodySystemHIP {
+ public:
+    using Type                    = T;
+    constexpr static auto use_cpu = false;
+
+    BodySystemHIP(unsigned int nb_bodies, unsigned int blockSize, const NBodyParams& params);
+    BodySystemHIP(unsigned int nb_bodies, unsigned int blockSize, const NBodyParams& params, std::vector<T> positions, std::vector<T> velocities);
+
+    auto virtual get_position() const -> std::span<const T> = 0;
+    auto virtual get_velocity() const -> std::span<const T> = 0;
+
+    auto reset(const NBodyParams& params, NBodyConfig config) -> void;
+
+    auto virtual update(T deltaTime) -> void = 0;
+
+    auto update_params(const NBodyParams& active_params) -> void;
+
+    auto virtual set_position(std::span<const T> data) -> void = 0;
+    auto virtual set_velocity(std::span<const T> data) -> void = 0;
+
+    auto nb_bodies() const noexcept { return nb_bodies_; }
+
+    virtual ~BodySystemHIP() = default;
+
+ protected:
+    // the softening constant is process-global per precision (as the reference's __constant__ is); every
+    // update() re-asserts this system's value so two systems with different softening can coexist
+    auto apply_softening() const -> void;
+
+    unsigned int nb_bodies_;
+
+    std::vector<T> host_pos_vec_;
+    std::vector<T> host_vel_vec_;
+
+    T damping_ = 0.995f;
+    T softening_squared_{};
+
+    unsigned int current_read_  = 0u;
+    unsigned int current_write_ = 1u;
+
+    unsigned int block_size_;
+};
+
+extern template class BodySystemHIP<float>;
+extern template class BodySystemHIP<double>;

@@ -1,0 +1,223 @@
+#include "compute_hip.hpp"
+
+#include "bodysystemhip.hpp"
+#include "bodysystemhip_default.hpp"
+#include "bodysystemhip_host_memory.hpp"
+#include "integrate_nbody_hip.hpp"
+#include "params.hpp"
+#include "text.hpp"
+
+#include <cassert>
+#include <cmath>
+#include <cstdio>
+#include <stdexcept>
+#include <string>
+
+namespace {
+
+// device discovery: /root/reference/src/nbody/compute_cuda.cpp:16-48
+auto get_main_device() -> nb_device_info_t {
+    int count = 0;
+    hip_check(nb_device_count(&count), "nb_device_count");
+    if (count == 0) throw std::runtime_error("gpuDeviceInit() HIP error: no devices supporting HIP.\n");
+    int device = 0;
+    hip_check(nb_get_device(&device), "nb_get_device");
+    nb_device_info_t info{};
+    hip_check(nb_device_info(device, &info), "nb_device_info");
+    return info;
+}
+
+}  // namespace
+
+ComputeHIP::ComputeHIP(bool enable_host_mem, int block_size, bool fp64_enabled, std::size_t num_bodies, const NBodyParams& params) : ComputeHIP(enable_host_mem, block_size, fp64_enabled, num_bodies, params, {}, {}, {}, {}) {}
+
+// compute_cuda.cpp:55-150
+ComputeHIP::ComputeHIP(bool enable_host_mem, int block_size, bool fp64_enabled, std::size_t num_bodies, const NBodyParams& params, std::vector<float> positions_fp32, std::vector<float> velocities_fp32,
+                       std::vector<double> positions_fp64, std::vector<double> velocities_fp64)
+    : block_size_(block_size), fp64_enabled_(fp64_enabled), use_host_mem_(enable_host_mem) {
+    const auto device = get_main_device();
+
+    std::printf("> %s HIP device: [%s], %d compute units\n", device.arch, device.name, device.compute_units);
+
+    if (use_host_mem_ && !device.can_map_host_memory) {
+        throw std::invalid_argument(std::string("Device ") + device.name + " cannot map host memory!");
+    }
+    // every gfx9 part has native fp64; kept for interface parity with the reference's CC <= 1.2 check (:89-96)
+    if (fp64_enabled_ && !double_supported_) {
+        throw std::invalid_argument("One or more of the requested devices does not support double precision floating-point");
+    }
+    if (block_size_ <= 0 || block_size_ % 64 != 0 || block_size_ > 1024) {
+        throw std::invalid_argument("--blockSize must be a multiple of the 64-lane wavefront, at most 1024");
+    }
+
+    if (num_bodies != 0u) {
+        nb_bodies_ = num_bodies;
+        // the reference kernel needs N % blockSize == 0 (bodysystemcuda.cu:153-155) so its facade rounds N up
+        // (:103-110).  The HIP kernels take any N, but the rounding is part of the CLI's observable behaviour.
+        if (nb_bodies_ % static_cast<std::size_t>(block_size_)) {
+            const auto rounded = ((nb_bodies_ / block_size_) + 1) * block_size_;
+            std::printf("Warning: \"number of bodies\" specified %zu is not a multiple of %d.\n", nb_bodies_, block_size_);
+            std::printf("Rounding up to the nearest multiple: %zu.\n", rounded);
+            nb_bodies_ = rounded;
+        } else {
+            std::printf("number of bodies = %zu\n", nb_bodies_);
+        }
+    } else {
+        // default: #CUs * 4 * workgroup size (:111-114) = 262 144 on an MI355X with --blockSize 256
+        nb_bodies_ = static_cast<std::size_t>(block_size_) * 4u * static_cast<std::size_t>(device.compute_units);
+    }
+
+    std::printf("> Simulation data stored in %s memory\n", use_host_mem_ ? "system" : "video");
+    std::printf("> %s precision floating point simulation\n", fp64_enabled_ ? "Double" : "Single");
+
+    const auto allocate = [&]<typename System32, typename System64>() {
+        const auto n = static_cast<unsigned int>(nb_bodies_);
+        const auto b = static_cast<unsigned int>(block_size_);
+        if (!positions_fp32.empty()) {
+            nbody_fp32_ = std::make_unique<System32>(n, b, params, std::move(positions_fp32), std::move(velocities_fp32));
+            if (double_supported_) nbody_fp64_ = std::make_unique<System64>(n, b, params, std::move(positions_fp64), std::move(velocities_fp64));
+        } else {
+            nbody_fp32_ = std::make_unique<System32>(n, b, params);
+            if (double_supported_) nbody_fp64_ = std::make_unique<System64>(n, b, params);
+        }
+    };
+    if (use_host_mem_) {
+        allocate.template operator()<BodySystemHIPHostMemory<float>, BodySystemHIPHostMemory<double>>();
+    } else {
+        allocate.template operator()<BodySystemHIPDefault<float>, BodySystemHIPDefault<double>>();
+    }
+
+    start_event_.record();
+}
+
+// fp32 <-> fp64 through the host   (:152-181)
+template <std::floating_point TNew, std::floating_point TOld> auto ComputeHIP::switch_precision(BodySystemHIP<TNew>& new_nbody, const BodySystemHIP<TOld>& old_nbody) -> void {
+    static_assert(!std::is_same_v<TNew, TOld>);
+    hip_check(nb_device_synchronize(), "nb_device_synchronize");
+    fp64_enabled_ = std::is_same_v<TNew, double>;
+
+    const auto old_pos = old_nbody.get_position();
+    auto       new_pos = std::vector<TNew>(old_pos.begin(), old_pos.end());
+    const auto old_vel = old_nbody.get_velocity();
+    auto       new_vel = std::vector<TNew>(old_vel.begin(), old_vel.end());
+
+    new_nbody.set_position(new_pos);
+    new_nbody.set_velocity(new_vel);
+    hip_check(nb_device_synchronize(), "nb_device_synchronize");
+}
+
+auto ComputeHIP::switch_precision() -> void {
+    if (!double_supported_) {
+        std::fprintf(stderr, "WARNING: Attempted to switch precision but double precision is not supported.\n");
+        return;
+    }
+    if (fp64_enabled_) {
+        switch_precision(*nbody_fp32_, *nbody_fp64_);
+        std::printf("> Single precision floating point simulation\n");
+    } else {
+        switch_precision(*nbody_fp64_, *nbody_fp32_);
+        std::printf("> Double precision floating point simulation\n");
+    }
+}
+
+// one untimed step to prime the device, then K steps between two events   (:183-203)
+template <std::floating_point T> auto ComputeHIP::run_benchmark(int nb_iterations, float dt, BodySystemHIP<T>& nbody) -> Milliseconds {
+    nbody.update(dt);
+    start_event_.record();
+    for (int i = 0; i < nb_iterations; ++i) nbody.update(dt);
+    return get_milliseconds_passed();
+}
+
+auto ComputeHIP::run_benchmark(int nb_iterations, float dt) -> Milliseconds { return fp64_enabled_ ? run_benchmark(nb_iterations, dt, *nbody_fp64_) : run_benchmark(nb_iterations, dt, *nbody_fp32_); }
+
+auto ComputeHIP::reset(const NBodyParams& params, NBodyConfig config) -> void {
+    if (fp64_enabled_) {
+        nbody_fp64_->reset(params, config);
+    } else {
+        nbody_fp32_->reset(params, config);
+    }
+}
+
+auto ComputeHIP::set_values(std::span<const float> positions, std::span<const float> velocities) -> void {
+    nbody_fp32_->set_position(positions);
+    nbody_fp32_->set_velocity(velocities);
+}
+auto ComputeHIP::set_values(std::span<const double> positions, std::span<const double> velocities) -> void {
+    nbody_fp64_->set_position(positions);
+    nbody_fp64_->set_velocity(velocities);
+}
+
+auto ComputeHIP::update(float dt) -> void {
+    host_mem_sync_event_.record();
+    if (fp64_enabled_) {
+        nbody_fp64_->update(dt);
+    } else {
+        nbody_fp32_->update(dt);
+    }
+}
+
+auto ComputeHIP::get_position_fp32() const -> std::span<const float> { return nbody_fp32_->get_position(); }
+auto ComputeHIP::get_position_fp64() const -> std::span<const double> { return nbody_fp64_->get_position(); }
+auto ComputeHIP::get_velocity_fp32() const -> std::span<const float> { return nbody_fp32_->get_velocity(); }
+auto ComputeHIP::get_velocity_fp64() const -> std::span<const double> { return nbody_fp64_->get_velocity(); }
+
+auto ComputeHIP::update_params(const NBodyParams& params) -> void {
+    if (fp64_enabled_) {
+        nbody_fp64_->update_params(params);
+    } else {
+        nbody_fp32_->update_params(params);
+    }
+}
+
+// record stop, wait, elapsed, restart   (:263-272)
+auto ComputeHIP::get_milliseconds_passed() -> Milliseconds {
+    stop_event_.record();
+    stop_event_.synchronize();
+    const auto ms = HipEvent::elapsed_ms(start_event_, stop_event_);
+    start_event_.record();
+    return Milliseconds{ms};
+}
+
+// The reference's check (:294-329) steps the GPU, then seeds a CPU system from the GPU's POST-step state and
+// steps that too, i.e. compares t2 against t1.  Here both systems start from the same PRE-step
+// state.  The checker is the STRICT kernel pair, which tests/test_gpu_parity.py hold to 0 ulp against the CPU
+// BodySystem path, so "strict" below reads as "what the reference's CPU path computes".
+template <std::floating_point T> auto ComputeHIP::compare_results(const NBodyParams& params, BodySystemHIP<T>& nbody) const -> bool {
+    auto passed = true;
+
+    const auto pos_span = nbody.get_position();
+    auto       pos0     = std::vector<T>(pos_span.begin(), pos_span.end());
+    const auto vel_span = nbody.get_velocity();
+    auto       vel0     = std::vector<T>(vel_span.begin(), vel_span.end());
+
+    const auto saved_mode = nbody_hip::integration_mode();
+    {
+        nbody_hip::integration_mode() = NB_MODE_STRICT;
+        auto checker = BodySystemHIPDefault<T>(static_cast<unsigned int>(nb_bodies_), static_cast<unsigned int>(block_size_), params, pos0, vel0);
+        checker.update(0.001f);
+        const auto want_span = checker.get_position();
+        const auto want      = std::vector<T>(want_span.begin(), want_span.end());
+
+        nbody_hip::integration_mode() = NB_MODE_FAST;
+        nbody.update(0.001f);
+        const auto got = nbody.get_position();
+
+        constexpr auto tolerance = T{0.0005f};
+        for (auto i = std::size_t{0}; i < nb_bodies_; ++i) {
+            for (auto c = std::size_t{0}; c < 3; ++c) {
+                const auto a = want[4 * i + c], b = got[4 * i + c];
+                if (!(std::abs(a - b) <= tolerance)) {
+                    passed = false;
+                    std::printf("Error: (strict)%s != (fast)%s\n", text::shortest(a).c_str(), text::shortest(b).c_str());
+                }
+            }
+        }
+    }
+    nbody_hip::integration_mode() = saved_mode;
+    if (passed) std::printf("  OK\n");
+    return passed;
+}
+
+auto ComputeHIP::compare_results(const NBodyParams& params) -> bool { return fp64_enabled_ ? compare_results(params, *nbody_fp64_) : compare_results(params, *nbody_fp32_); }
+
+ComputeHIP::~ComputeHIP() noexcept = default;
