@@ -9,6 +9,7 @@
 
 #include <atomic>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 
 namespace {
@@ -19,6 +20,33 @@ std::atomic<float>  g_softening_sq_f32{0.0f};
 std::atomic<double> g_softening_sq_f64{0.0};
 
 std::atomic<int> g_ovr_i{0}, g_ovr_s{0}, g_ovr_tile{0};
+
+// The reference's initial conditions are drawn from the process-global libc rand() stream
+// (randomise_bodies.cpp:37-43), so a drop-in must not disturb that stream.  The HIP runtime does: its first
+// pageable host-to-device copy consumes rand() draws (tools/rand_probe.cpp).  Every entry point that reaches
+// the runtime therefore parks the caller's random()/rand() state and lends the runtime a scratch one.
+class RandStreamGuard {
+ public:
+    RandStreamGuard() {
+        static char scratch[128];
+        static bool seeded = false;
+        if (!seeded) {
+            prev_  = initstate(0x9e3779b9u, scratch, sizeof(scratch));
+            seeded = true;
+        } else {
+            prev_ = setstate(scratch);
+        }
+    }
+    ~RandStreamGuard() {
+        if (prev_ != nullptr) (void)setstate(prev_);
+    }
+    RandStreamGuard(const RandStreamGuard&)            = delete;
+    RandStreamGuard& operator=(const RandStreamGuard&) = delete;
+
+ private:
+    char* prev_ = nullptr;
+};
+#define NB_KEEP_RAND_STREAM RandStreamGuard nb_rand_stream_guard_
 
 int cu_count_cached() {
     static std::atomic<int> cached[64] = {};
@@ -39,6 +67,7 @@ template <typename T> bool aligned_vec4(const void* p) { return (reinterpret_cas
 
 template <typename T>
 int integrate_shard(T* new_pos, const T* old_pos, T* vel, T* acc, unsigned i_begin, unsigned i_count, unsigned j_begin, unsigned j_count, unsigned flags, T dt, T damping, T eps2, int block_size, int mode, nb_stream_t stream) {
+    NB_KEEP_RAND_STREAM;
     const bool acc_in   = (flags & NB_SHARD_ACC_IN) != 0;
     const bool finalize = (flags & NB_SHARD_FINALIZE) != 0;
     if (!old_pos || i_count == 0) return NB_ERR_INVALID_ARGUMENT;
@@ -67,6 +96,7 @@ int integrate_shard(T* new_pos, const T* old_pos, T* vel, T* acc, unsigned i_beg
 
 template <typename T> int plan_query(unsigned i_count, unsigned j_count, nb_launch_plan_t* out) {
     if (!out || i_count == 0) return NB_ERR_INVALID_ARGUMENT;
+    NB_KEEP_RAND_STREAM;
     const nb::Plan p     = nb::plan_fast<T>(i_count, j_count, cu_count_cached(), g_ovr_i.load(), g_ovr_s.load(), g_ovr_tile.load());
     out->bodies_per_lane = p.bodies_per_lane;
     out->lanes_per_body  = p.lanes_per_body;
@@ -93,16 +123,20 @@ const char* nb_error_string(int code) {
 const char* nb_version(void) { return "mi355x-nbody 0.1 (gfx950)"; }
 
 int nb_device_count(int* count) {
+    NB_KEEP_RAND_STREAM;
     if (!count) return NB_ERR_INVALID_ARGUMENT;
     return static_cast<int>(hipGetDeviceCount(count));
 }
-int nb_set_device(int device) { return static_cast<int>(hipSetDevice(device)); }
+int nb_set_device(int device) {
+    NB_KEEP_RAND_STREAM; return static_cast<int>(hipSetDevice(device)); }
 int nb_get_device(int* device) {
+    NB_KEEP_RAND_STREAM;
     if (!device) return NB_ERR_INVALID_ARGUMENT;
     return static_cast<int>(hipGetDevice(device));
 }
 
 int nb_device_info(int device, nb_device_info_t* out) {
+    NB_KEEP_RAND_STREAM;
     if (!out) return NB_ERR_INVALID_ARGUMENT;
     hipDeviceProp_t prop;
     const auto      err = hipGetDeviceProperties(&prop, device);
@@ -120,27 +154,34 @@ int nb_device_info(int device, nb_device_info_t* out) {
 }
 
 int nb_alloc(void** device_ptr, size_t bytes) {
+    NB_KEEP_RAND_STREAM;
     if (!device_ptr) return NB_ERR_INVALID_ARGUMENT;
     return static_cast<int>(hipMalloc(device_ptr, bytes));
 }
-int nb_free(void* device_ptr) { return static_cast<int>(hipFree(device_ptr)); }
-int nb_memset(void* device_ptr, int value, size_t bytes, nb_stream_t stream) { return static_cast<int>(hipMemsetAsync(device_ptr, value, bytes, as_stream(stream))); }
+int nb_free(void* device_ptr) {
+    NB_KEEP_RAND_STREAM; return static_cast<int>(hipFree(device_ptr)); }
+int nb_memset(void* device_ptr, int value, size_t bytes, nb_stream_t stream) {
+    NB_KEEP_RAND_STREAM; return static_cast<int>(hipMemsetAsync(device_ptr, value, bytes, as_stream(stream))); }
 
 int nb_h2d(void* device_dst, const void* host_src, size_t bytes, nb_stream_t stream) {
+    NB_KEEP_RAND_STREAM;
     auto err = hipMemcpyAsync(device_dst, host_src, bytes, hipMemcpyHostToDevice, as_stream(stream));
     if (err != hipSuccess) return static_cast<int>(err);
     return static_cast<int>(hipStreamSynchronize(as_stream(stream)));
 }
 int nb_d2h(void* host_dst, const void* device_src, size_t bytes, nb_stream_t stream) {
+    NB_KEEP_RAND_STREAM;
     auto err = hipMemcpyAsync(host_dst, device_src, bytes, hipMemcpyDeviceToHost, as_stream(stream));
     if (err != hipSuccess) return static_cast<int>(err);
     return static_cast<int>(hipStreamSynchronize(as_stream(stream)));
 }
 int nb_d2d(void* device_dst, const void* device_src, size_t bytes, nb_stream_t stream) {
+    NB_KEEP_RAND_STREAM;
     return static_cast<int>(hipMemcpyAsync(device_dst, device_src, bytes, hipMemcpyDeviceToDevice, as_stream(stream)));
 }
 
 int nb_host_alloc_mapped(void** host_ptr, void** device_ptr, size_t bytes) {
+    NB_KEEP_RAND_STREAM;
     if (!host_ptr || !device_ptr) return NB_ERR_INVALID_ARGUMENT;
     auto err = hipHostMalloc(host_ptr, bytes, hipHostMallocMapped | hipHostMallocPortable);
     if (err != hipSuccess) return static_cast<int>(err);
@@ -151,34 +192,45 @@ int nb_host_alloc_mapped(void** host_ptr, void** device_ptr, size_t bytes) {
     }
     return static_cast<int>(err);
 }
-int nb_host_free(void* host_ptr) { return static_cast<int>(hipHostFree(host_ptr)); }
+int nb_host_free(void* host_ptr) {
+    NB_KEEP_RAND_STREAM; return static_cast<int>(hipHostFree(host_ptr)); }
 
 int nb_stream_create(nb_stream_t* stream) {
+    NB_KEEP_RAND_STREAM;
     if (!stream) return NB_ERR_INVALID_ARGUMENT;
     hipStream_t s   = nullptr;
     const auto  err = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
     *stream         = s;
     return static_cast<int>(err);
 }
-int nb_stream_destroy(nb_stream_t stream) { return static_cast<int>(hipStreamDestroy(as_stream(stream))); }
-int nb_stream_synchronize(nb_stream_t stream) { return static_cast<int>(hipStreamSynchronize(as_stream(stream))); }
-int nb_stream_wait_event(nb_stream_t stream, nb_event_t event) { return static_cast<int>(hipStreamWaitEvent(as_stream(stream), as_event(event), 0)); }
+int nb_stream_destroy(nb_stream_t stream) {
+    NB_KEEP_RAND_STREAM; return static_cast<int>(hipStreamDestroy(as_stream(stream))); }
+int nb_stream_synchronize(nb_stream_t stream) {
+    NB_KEEP_RAND_STREAM; return static_cast<int>(hipStreamSynchronize(as_stream(stream))); }
+int nb_stream_wait_event(nb_stream_t stream, nb_event_t event) {
+    NB_KEEP_RAND_STREAM; return static_cast<int>(hipStreamWaitEvent(as_stream(stream), as_event(event), 0)); }
 
 int nb_event_create(nb_event_t* event) {
+    NB_KEEP_RAND_STREAM;
     if (!event) return NB_ERR_INVALID_ARGUMENT;
     hipEvent_t e   = nullptr;
     const auto err = hipEventCreate(&e);
     *event         = e;
     return static_cast<int>(err);
 }
-int nb_event_destroy(nb_event_t event) { return static_cast<int>(hipEventDestroy(as_event(event))); }
-int nb_event_record(nb_event_t event, nb_stream_t stream) { return static_cast<int>(hipEventRecord(as_event(event), as_stream(stream))); }
-int nb_event_synchronize(nb_event_t event) { return static_cast<int>(hipEventSynchronize(as_event(event))); }
+int nb_event_destroy(nb_event_t event) {
+    NB_KEEP_RAND_STREAM; return static_cast<int>(hipEventDestroy(as_event(event))); }
+int nb_event_record(nb_event_t event, nb_stream_t stream) {
+    NB_KEEP_RAND_STREAM; return static_cast<int>(hipEventRecord(as_event(event), as_stream(stream))); }
+int nb_event_synchronize(nb_event_t event) {
+    NB_KEEP_RAND_STREAM; return static_cast<int>(hipEventSynchronize(as_event(event))); }
 int nb_event_elapsed_ms(float* ms, nb_event_t start, nb_event_t stop) {
+    NB_KEEP_RAND_STREAM;
     if (!ms) return NB_ERR_INVALID_ARGUMENT;
     return static_cast<int>(hipEventElapsedTime(ms, as_event(start), as_event(stop)));
 }
-int nb_device_synchronize(void) { return static_cast<int>(hipDeviceSynchronize()); }
+int nb_device_synchronize(void) {
+    NB_KEEP_RAND_STREAM; return static_cast<int>(hipDeviceSynchronize()); }
 
 int nb_set_softening_sq_f32(float v) {
     g_softening_sq_f32.store(v);

@@ -255,3 +255,21 @@ def test_device_is_gfx950(gpu):
     info = gpu.device_info(0)
     assert info.arch.decode().startswith("gfx950"), info.arch
     assert info.wavefront_size == 64 and info.compute_units == 256
+
+
+def test_library_leaves_the_libc_rand_stream_alone(gpu, oracle):
+    """The reference draws its bodies from the process-global rand() stream; HIP's first pageable H2D copy
+    consumes draws from it (tools/rand_probe.cpp).  The C-ABI must hide that (RandStreamGuard, nbody_capi.hip)."""
+    oracle.srand(1)
+    buf = gpu.DeviceBuffer(1 << 20)
+    host = np.ones(1 << 18, dtype=np.float32)
+    buf.upload(host)
+    buf.download(host)
+    out = gpu.DeviceBuffer(1 << 20)
+    vel = gpu.DeviceBuffer(1 << 20)
+    gpu.set_softening_squared(np.float32(0.01))
+    gpu.integrate_nbody_system(out.ptr, buf.ptr, vel.ptr, 0, 0.016, 1.0, 1024, 256, np.float32, gpu.NB_MODE_FAST)
+    gpu.check(gpu.lib().nb_device_synchronize())
+    assert oracle.lib.oracle_rand() == 1804289383  # first draw of the seed-1 stream: nothing was consumed
+    for b in (buf, out, vel):
+        b.free()
