@@ -32,7 +32,8 @@
 namespace nb {
 namespace {
 
-constexpr int kBlock = 256;
+// workgroup size by j-split factor: S <= 4 -> 256 threads, S = 8 -> 512, S = 16 -> 1024 (a lane group stays >= one wave)
+constexpr int block_threads_for(int S) { return S <= 4 ? 256 : 64 * S; }
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 
@@ -45,7 +46,12 @@ template <> struct Lane<float> {
     static constexpr int W     = 2;
     static __device__ __forceinline__ vec  splat(float a) { return vec{a, a}; }
     static __device__ __forceinline__ vec  fma(vec a, vec b, vec c) { return __builtin_elementwise_fma(a, b, c); }
-    static __device__ __forceinline__ vec  rsqrt(vec a) { return vec{__builtin_amdgcn_rsqf(a.x), __builtin_amdgcn_rsqf(a.y)}; }  // 2 x v_rsq_f32 (1 ulp)
+    // s = m * d2^(-3/2): 2 x v_rsq_f32 (1 ulp, what the reference's rsqrtf is) + 3 v_pk_mul_f32   (bodysystemcuda.cu:110-115)
+    static __device__ __forceinline__ vec coupling(vec m, vec d2) {
+        const vec inv  = vec{__builtin_amdgcn_rsqf(d2.x), __builtin_amdgcn_rsqf(d2.y)};
+        const vec inv2 = inv * inv;
+        return (m * inv) * inv2;
+    }
     static __device__ __forceinline__ float get(vec a, int w) { return w == 0 ? a.x : a.y; }
     static __device__ __forceinline__ void  set(vec& a, int w, float v) {
         if (w == 0) a.x = v; else a.y = v;
@@ -59,16 +65,17 @@ template <> struct Lane<double> {
     static constexpr int W     = 1;
     static __device__ __forceinline__ vec splat(double a) { return a; }
     static __device__ __forceinline__ vec fma(vec a, vec b, vec c) { return __builtin_fma(a, b, c); }
-    // the reference calls CUDA's rsqrt(double) (bodysystemcuda.cu:82-84); here v_rsq_f64 seed + 2 Newton-Raphson
-    // steps  y <- y + y*(0.5 - 0.5*x*y*y)
-    static __device__ __forceinline__ vec rsqrt(vec x) {
-        double       y  = __builtin_amdgcn_rsq(x);
-        const double hx = 0.5 * x;
-        double       e  = __builtin_fma(-hx * y, y, 0.5);
-        y               = __builtin_fma(y, e, y);
-        e               = __builtin_fma(-hx * y, y, 0.5);
-        y               = __builtin_fma(y, e, y);
-        return y;
+    // s = m * d2^(-3/2) in full double precision from the v_rsq_f64 seed y0 (relative error <= 2^-23) WITHOUT
+    // iterating on y: with r = 1 - d2*y0^2 (|r| <= 2^-22),  d2^(-3/2) = y0^3 (1-r)^(-3/2) = y0^3 (1 + 3/2 r + 15/8 r^2 + O(r^3)),
+    // truncation 35/16 r^3 < 2^-64.  7 DP ops + the seed, against 10 for two Newton steps on y followed by the cube
+    // (the reference calls CUDA's <= 1 ulp rsqrt(double) here, bodysystemcuda.cu:82-84,110-115).
+    static __device__ __forceinline__ vec coupling(vec m, vec d2) {
+        const double y0 = __builtin_amdgcn_rsq(d2);
+        const double t0 = y0 * y0;
+        const double r  = __builtin_fma(-d2, t0, 1.0);
+        const double mc = m * (y0 * t0);
+        const double w  = r * __builtin_fma(r, 1.875, 1.5);
+        return __builtin_fma(mc, w, mc);
     }
     static __device__ __forceinline__ double get(vec a, int) { return a; }
     static __device__ __forceinline__ void   set(vec& a, int, double v) { a = v; }
@@ -90,9 +97,7 @@ __device__ __forceinline__ void interact(const typename Lane<T>::vec4 bj, const 
         vec       d2   = L::fma(dx, dx, eps2);
         d2             = L::fma(dy, dy, d2);
         d2             = L::fma(dz, dz, d2);
-        const vec inv  = L::rsqrt(d2);
-        const vec inv2 = inv * inv;
-        const vec s    = (bm * inv) * inv2;
+        const vec s    = L::coupling(bm, d2);
         ax[r]          = L::fma(dx, s, ax[r]);
         ay[r]          = L::fma(dy, s, ay[r]);
         az[r]          = L::fma(dz, s, az[r]);
@@ -100,7 +105,8 @@ __device__ __forceinline__ void interact(const typename Lane<T>::vec4 bj, const 
 }
 
 // T: float|double   R: vectors per lane (I = R*W bodies i)   S: lane groups splitting j   LPT: vec4 loads per thread per tile
-template <typename T, int R, int S, int LPT> __global__ __launch_bounds__(kBlock) void integrate_bodies_fast(Shard<T> s) {
+template <typename T, int R, int S, int LPT> __global__ __launch_bounds__(block_threads_for(S)) void integrate_bodies_fast(Shard<T> s) {
+    constexpr int kBlock = block_threads_for(S);
     using LT            = Lane<T>;
     using vec4          = typename LT::vec4;
     using vec           = typename LT::vec;
@@ -242,11 +248,17 @@ template <typename T, int R, int S, int LPT> __global__ __launch_bounds__(kBlock
 }
 
 template <typename T, int R, int S, int LPT> hipError_t launch_one(const Shard<T>& s, const Plan& p, hipStream_t stream) {
-    hipLaunchKernelGGL((integrate_bodies_fast<T, R, S, LPT>), dim3(p.grid_blocks), dim3(kBlock), p.lds_bytes, stream, s);
+    if (p.lds_bytes > 64u * 1024u) {  // above the default dynamic-LDS ceiling: opt in once per kernel (gfx950 has 160 KiB per CU)
+        static hipError_t opted = hipFuncSetAttribute(reinterpret_cast<const void*>(&integrate_bodies_fast<T, R, S, LPT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (opted != hipSuccess) return opted;
+    }
+    hipLaunchKernelGGL((integrate_bodies_fast<T, R, S, LPT>), dim3(p.grid_blocks), dim3(block_threads_for(S)), p.lds_bytes, stream, s);
     return hipGetLastError();
 }
 
 template <typename T, int R, int S> hipError_t dispatch_lpt(const Shard<T>& s, const Plan& p, hipStream_t stream) {
+    constexpr int kBlock = block_threads_for(S);
+    if (p.tile_bodies % kBlock) return hipErrorInvalidValue;
     switch (p.tile_bodies / kBlock) {
         case 1: return launch_one<T, R, S, 1>(s, p, stream);
         case 2: return launch_one<T, R, S, 2>(s, p, stream);
@@ -260,37 +272,43 @@ template <typename T, int R> hipError_t dispatch_s(const Shard<T>& s, const Plan
         case 1: return dispatch_lpt<T, R, 1>(s, p, stream);
         case 2: return dispatch_lpt<T, R, 2>(s, p, stream);
         case 4: return dispatch_lpt<T, R, 4>(s, p, stream);
+        case 8: return dispatch_lpt<T, R, 8>(s, p, stream);
+        case 16: return dispatch_lpt<T, R, 16>(s, p, stream);
         default: return hipErrorInvalidValue;
     }
 }
 
 }  // namespace
 
-// Geometry.  bodies_per_lane I is a multiple of W (2 for fp32: bodies travel in packed pairs).
-// Fill 256 CUs x 4 SIMDs with >= 4 waves if the shard is big enough; prefer register tiling (I) over
-// j-splitting (S): I amortises the LDS broadcast, S costs an LDS fold at the end.
+// Geometry (measured: profiles/round1_sweep_*.txt, the shard sweeps included).
+//   * S = 16: one 1024-thread workgroup = 16 waves = 4 per SIMD, all working on the SAME 64*I bodies i and each
+//     walking 1/16 of every LDS tile.  One resident workgroup per CU fills the chip for any shard with >= 256
+//     workgroups, which is what keeps a 32 768-body shard (8-GPU strong scaling of 262 144 bodies) at 94 % of the
+//     full-size rate; at full size it is as fast as any smaller split.
+//   * I (bodies i per lane, a multiple of W: fp32 bodies travel in packed pairs) as large as possible while the
+//     shard still yields one workgroup per CU: register tiling amortises the LDS broadcast and the per-tile barrier.
+//   * LDS tile 2048 bodies (fp32, 2 x 32 KiB double-buffered) / 1024 (fp64): 128 bodies j per wave between barriers.
 template <typename T> Plan plan_fast(unsigned i_count, unsigned j_count, int cu_count, int ovr_i, int ovr_s, int ovr_tile) {
-    (void)j_count;
-    constexpr int W            = Lane<T>::W;
-    const long    lanes_wanted = static_cast<long>(cu_count) * 4 * 64 * 4;  // 4 waves per SIMD
-    int           I            = 2 * W;                                      // fp32: 4 bodies (2 pairs); fp64: 2
-    while (I > W && static_cast<long>(i_count) / I * 4 < lanes_wanted) I /= 2;
-    int S = 1;
-    while (S < 4 && static_cast<long>(i_count) / I * S < lanes_wanted) S *= 2;
-    int tile = sizeof(T) == 4 ? 1024 : 512;
+    constexpr int W = Lane<T>::W;
+    int           I = W;
+    while (I * 2 <= 4 * W && static_cast<long>(i_count) / (64L * I * 2) >= cu_count) I *= 2;
+    int S = 16;
     if (ovr_i > 0) I = std::max(ovr_i / W * W, W);
     if (ovr_s > 0) S = ovr_s;
+    const int block = block_threads_for(S);
+    int       tile  = (sizeof(T) == 4 && j_count >= 8192) ? 2048 : 1024;
     if (ovr_tile > 0) tile = ovr_tile;
+    if (tile < block) tile = block;
 
     Plan p;
     p.bodies_per_lane = I;
     p.lanes_per_body  = S;
     p.tile_bodies     = tile;
-    p.block_threads   = kBlock;
-    const unsigned bodies_per_block = static_cast<unsigned>(kBlock / S * I);
+    p.block_threads   = block;
+    const unsigned bodies_per_block = static_cast<unsigned>(block / S * I);
     p.grid_blocks     = (i_count + bodies_per_block - 1) / bodies_per_block;
     const size_t tile_bytes = 2ull * tile * 4 * sizeof(T);
-    const size_t red_bytes  = static_cast<size_t>(S - 1) * 3 * I * (kBlock / S) * sizeof(T);
+    const size_t red_bytes  = static_cast<size_t>(S - 1) * 3 * I * (block / S) * sizeof(T);
     p.lds_bytes             = static_cast<unsigned>(std::max(tile_bytes, red_bytes));
     return p;
 }

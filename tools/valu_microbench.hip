@@ -87,6 +87,42 @@ template <int KIND> __global__ __launch_bounds__(256) void bench(float* out, flo
                  : "v"(pb), "v"(pc));
             REP16(OP)
 #undef OP
+        } else if constexpr (KIND == 10) {  // v_fma_f32, single source register
+#define OP(i) asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(a[i]));
+            REP16(OP)
+#undef OP
+        } else if constexpr (KIND == 11) {  // v_pk_fma_f32, single source register pair
+#define OP(i) asm volatile("v_pk_fma_f32 %0, %0, %0, %0" : "+v"(p[i]));
+            REP16(OP)
+#undef OP
+        } else if constexpr (KIND == 12) {  // v_pk_fma_f32 d, x, x, d  (two distinct sources, like d2 = fma(dx,dx,d2))
+#define OP(i) asm volatile("v_pk_fma_f32 %0, %1, %1, %0" : "+v"(p[i]) : "v"(pb));
+            REP16(OP)
+#undef OP
+        } else if constexpr (KIND == 13) {  // v_pk_mul_f32 d, x, x
+#define OP(i) asm volatile("v_pk_mul_f32 %0, %0, %0" : "+v"(p[i]));
+            REP16(OP)
+#undef OP
+        } else if constexpr (KIND == 14) {  // v_pk_add_f32 with broadcast + neg, as the kernel's dx = bj.x - px
+#define OP(i) asm volatile("v_pk_add_f32 %0, %1, %0 op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]" : "+v"(p[i]) : "v"(pb));
+            REP16(OP)
+#undef OP
+        } else if constexpr (KIND == 15) {  // v_fmac_f32 (VOP2)
+#define OP(i) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+            REP16(OP)
+#undef OP
+        } else if constexpr (KIND == 16) {  // v_pk_fma_f32 acc += dx * s   (three distinct sources)
+#define OP(i) asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(p[i]) : "v"(pb), "v"(pc));
+            REP16(OP)
+#undef OP
+        } else if constexpr (KIND == 17) {  // v_add_f32 a, a, a
+#define OP(i) asm volatile("v_add_f32 %0, %0, %0" : "+v"(a[i]));
+            REP16(OP)
+#undef OP
+        } else if constexpr (KIND == 18) {  // v_mov_b32
+#define OP(i) asm volatile("v_mov_b32 %0, %1" : "=v"(a[i]) : "v"(b));
+            REP16(OP)
+#undef OP
         }
     }
     float s = 0;
@@ -103,7 +139,7 @@ struct Test {
 };
 
 int main(int argc, char** argv) {
-    int waves_per_simd_list[] = {1, 2, 4, 8};
+    int waves_per_simd_list[] = {2, 8};
     float* out;
     CHECK(hipMalloc(&out, 4));
     hipDeviceProp_t prop;
@@ -115,6 +151,9 @@ int main(int argc, char** argv) {
         {"v_pk_add_f32", bench<3>, 16, 2},     {"v_rsq_f32", bench<4>, 16, 1},         {"v_mul_f32", bench<5>, 16, 1},
         {"v_sub_f32(sgpr)", bench<6>, 16, 1},  {"mix 12fma+1rsq", bench<7>, 16 * 13, 0}, {"fma+rsq 1:1", bench<8>, 32, 0},
         {"pkmix 12pk+2rsq", bench<9>, 16 * 14, 0},
+        {"v_fma_f32 1src", bench<10>, 16, 2},  {"v_pk_fma 1src", bench<11>, 16, 4},    {"v_pk_fma d,x,x,d", bench<12>, 16, 4},
+        {"v_pk_mul d,x,x", bench<13>, 16, 2},  {"v_pk_add bcast+neg", bench<14>, 16, 2}, {"v_fmac_f32 vop2", bench<15>, 16, 2},
+        {"v_pk_fma a+=x*s", bench<16>, 16, 4}, {"v_add_f32 1src", bench<17>, 16, 1},    {"v_mov_b32", bench<18>, 16, 0},
     };
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0));
