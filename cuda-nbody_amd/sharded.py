@@ -45,7 +45,9 @@ class ShardedBodySystem:
     """Ping-pong positions + velocities + partial-acceleration scratch, all full-size torch tensors on this
     rank's device (N x 4 T each: 16 MiB at 1 Mi bodies -- nothing next to 288 GB), indexed by global body id."""
 
-    def __init__(self, pos0, vel0, launch, ordered: bool = False, group=None):
+    def __init__(self, pos0, vel0, launch, ordered: bool = False, group=None, gather=None):
+        """`gather(full, own_slice)` -> object with .wait() replaces the in-place RCCL all-gather (tests stage it
+        through host memory with gloo to run two ranks on one GPU)."""
         import torch.distributed as dist
 
         self.dist = dist
@@ -61,6 +63,7 @@ class ShardedBodySystem:
         self.read = 0
         self.pending = None  # the in-flight all-gather of self.pos[self.read]
         self.schedule = chunk_schedule(self.i0, self.ni, self.n, ordered)
+        self._gather = gather or (lambda full, own: self.dist.all_gather_into_tensor(full, own, group=self.group, async_op=True))
 
     def update(self) -> None:
         """One step: pos[1-read][own], vel[own] <- integrate(pos[read]); then start gathering pos[1-read]."""
@@ -77,7 +80,7 @@ class ShardedBodySystem:
             self.pending = None
         if self.world > 1:
             own = nxt[self.i0:self.i0 + self.ni]
-            self.pending = self.dist.all_gather_into_tensor(nxt, own, group=self.group, async_op=True)
+            self.pending = self._gather(nxt, own)
         self.read = 1 - self.read
 
     def finish(self) -> None:
