@@ -117,7 +117,11 @@ template <typename T, int R, int S, int LPT> __global__ __launch_bounds__(block_
     constexpr int SLICE = TILE / S;      // bodies j per group per tile
     constexpr int BODIES_PER_BLOCK = L * I;
     static_assert(L % 64 == 0, "a lane group must be whole waves so the LDS read stays a broadcast");
-    static_assert(SLICE % 8 == 0, "inner loop is unrolled by 8");
+    // j bodies in flight per lane: 8 independent interaction chains (R vectors x U bodies j) hide the VALU latency.
+    // The 512/1024-thread workgroups are capped at 128 VGPRs (4 waves/SIMD), so with R >= 2 they unroll less instead
+    // of spilling (an R = 4 body at U = 8 spilled 1.2 KB/lane to scratch: 1.2 GB of HBM writes per launch).
+    constexpr int U = (kBlock >= 512 && R >= 2) ? 8 / R : 8;
+    static_assert(SLICE % U == 0, "inner loop is unrolled by U");
 
     extern __shared__ __attribute__((aligned(32))) unsigned char smem_raw[];
     vec4* tile = reinterpret_cast<vec4*>(smem_raw);  // [2][TILE]
@@ -187,9 +191,9 @@ template <typename T, int R, int S, int LPT> __global__ __launch_bounds__(block_
 
         const vec4* __restrict__ slice = tile + cur * TILE + group * SLICE;
 #pragma unroll 1
-        for (int jj = 0; jj < SLICE; jj += 8) {
+        for (int jj = 0; jj < SLICE; jj += U) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) interact<T, R>(slice[jj + u], px, py, pz, ax, ay, az, eps2);
+            for (int u = 0; u < U; ++u) interact<T, R>(slice[jj + u], px, py, pz, ax, ay, az, eps2);
         }
 
         if (have_next) store_tile(cur ^ 1, regs);
@@ -209,7 +213,7 @@ template <typename T, int R, int S, int LPT> __global__ __launch_bounds__(block_
         }
         __syncthreads();
         if (group == 0) {
-#pragma unroll
+#pragma unroll 1  // (fully unrolled, the S = 16 fold hoists 45*I LDS loads and spills)
             for (int g = 1; g < S; ++g) {
 #pragma unroll
                 for (int k = 0; k < I; ++k) {
@@ -289,9 +293,10 @@ template <typename T, int R> hipError_t dispatch_s(const Shard<T>& s, const Plan
 //     shard still yields one workgroup per CU: register tiling amortises the LDS broadcast and the per-tile barrier.
 //   * LDS tile 2048 bodies (fp32, 2 x 32 KiB double-buffered) / 1024 (fp64): 128 bodies j per wave between barriers.
 template <typename T> Plan plan_fast(unsigned i_count, unsigned j_count, int cu_count, int ovr_i, int ovr_s, int ovr_tile) {
-    constexpr int W = Lane<T>::W;
-    int           I = W;
-    while (I * 2 <= 4 * W && static_cast<long>(i_count) / (64L * I * 2) >= cu_count) I *= 2;
+    constexpr int W    = Lane<T>::W;
+    constexpr int kMaxI = 4;  // fp32: 2 packed pairs, fp64: 4 bodies -- the most a 1024-thread workgroup holds in 128 VGPRs without spilling
+    int           I    = W;
+    while (I * 2 <= kMaxI && static_cast<long>(i_count) / (64L * I * 2) >= cu_count) I *= 2;
     int S = 16;
     if (ovr_i > 0) I = std::max(ovr_i / W * W, W);
     if (ovr_s > 0) S = ovr_s;

@@ -268,6 +268,72 @@ ORACLE_API double oracle_benchmark_f64(double* pos, double* vel, size_t n, doubl
     return now_ms() - t0;
 }
 
+/* update() restricted to bodies i in [i0, i0+ni): their new position/velocity after ONE step, every body j of
+ * the full system contributing in the order j = 0..n-1 -- the same arithmetic and order as update_f32_scalar /
+ * update_f64 above, so the outputs are bit-identical to the corresponding rows of a full update.  Lets the
+ * full-size tests (262 144 / 1 048 576 bodies) check the STRICT kernels bitwise on a sample in seconds.
+ * out_pos / out_vel are 4*ni (xyz updated, .w copied). */
+ORACLE_API void oracle_update_subset_f32(const float* pos, const float* vel, size_t n, size_t i0, size_t ni, float eps2, float damping, float dt, float* out_pos, float* out_vel) {
+#ifdef _OPENMP
+#pragma omp parallel for
+#endif
+    for (long k = 0; k < (long)ni; ++k) {
+        const size_t i  = i0 + (size_t)k;
+        const float  xi = pos[4 * i], yi = pos[4 * i + 1], zi = pos[4 * i + 2];
+        float        dv[3] = {0.0f, 0.0f, 0.0f};
+        for (size_t j = 0; j < n; ++j) {
+            const float dx = pos[4 * j] - xi, dy = pos[4 * j + 1] - yi, dz = pos[4 * j + 2] - zi;
+            const float dx2 = dx * dx, dy2 = dy * dy, dz2 = dz * dz;
+            float       r2  = eps2 + dx2;
+            r2              = r2 + dy2;
+            r2              = r2 + dz2;
+            const float r    = sqrtf(r2);
+            const float m_r4 = pos[4 * j + 3] / (r2 * r2);
+            const float m_r3 = m_r4 * r;
+            dv[0]            = dv[0] + m_r3 * dx;
+            dv[1]            = dv[1] + m_r3 * dy;
+            dv[2]            = dv[2] + m_r3 * dz;
+        }
+        for (int d = 0; d < 3; ++d) {
+            const float a  = dv[d] * dt;
+            float       v  = vel[4 * i + d] + a;
+            v              = v * damping;
+            const float dp = v * dt;
+            out_vel[4 * k + d] = v;
+            out_pos[4 * k + d] = pos[4 * i + d] + dp;
+        }
+        out_vel[4 * k + 3] = vel[4 * i + 3];
+        out_pos[4 * k + 3] = pos[4 * i + 3];
+    }
+}
+
+ORACLE_API void oracle_update_subset_f64(const double* pos, const double* vel, size_t n, size_t i0, size_t ni, double eps2, double damping, double dt, double* out_pos, double* out_vel) {
+#ifdef _OPENMP
+#pragma omp parallel for
+#endif
+    for (long k = 0; k < (long)ni; ++k) {
+        const size_t i  = i0 + (size_t)k;
+        const double xi = pos[4 * i], yi = pos[4 * i + 1], zi = pos[4 * i + 2];
+        double       acc[3] = {0, 0, 0};
+        for (size_t j = 0; j < n; ++j) {
+            const double dx = pos[4 * j] - xi, dy = pos[4 * j + 1] - yi, dz = pos[4 * j + 2] - zi;
+            const double dx2 = dx * dx, dy2 = dy * dy, dz2 = dz * dz;
+            const double r2  = (dx2 + dy2) + (dz2 + eps2);
+            const double r   = sqrt(r2);
+            const double s   = (pos[4 * j + 3] / (r2 * r2)) * r;
+            acc[0] = acc[0] + dx * s, acc[1] = acc[1] + dy * s, acc[2] = acc[2] + dz * s;
+        }
+        for (int d = 0; d < 3; ++d) {
+            const double dvd = acc[d] * dt;
+            const double v   = (vel[4 * i + d] + dvd) * damping;
+            out_vel[4 * k + d] = v;
+            out_pos[4 * k + d] = pos[4 * i + d] + v * dt;
+        }
+        out_vel[4 * k + 3] = vel[4 * i + 3];
+        out_pos[4 * k + 3] = pos[4 * i + 3];
+    }
+}
+
 /* Bounded sample for bench.py's cpu_baseline leg: the O(N^2) force pass of update() restricted to bodies
  * i in [0, ni) against all n bodies j (same loop nests, same arithmetic as update_f32_avx / update_f64).
  * Returns milliseconds; *checksum keeps the work observable. */

@@ -79,6 +79,10 @@ class Oracle:
         lib.oracle_benchmark_partial_f32.restype = cd
         lib.oracle_benchmark_partial_f64.argtypes = [f64p, sz, sz, cd, f64p]
         lib.oracle_benchmark_partial_f64.restype = cd
+        lib.oracle_update_subset_f32.argtypes = [f32p, f32p, sz, sz, sz, cf, cf, cf, f32p, f32p]
+        lib.oracle_update_subset_f32.restype = None
+        lib.oracle_update_subset_f64.argtypes = [f64p, f64p, sz, sz, sz, cd, cd, cd, f64p, f64p]
+        lib.oracle_update_subset_f64.restype = None
         lib.oracle_accel_f64_from_f32.argtypes = [f32p, sz, sz, sz, cd, f64p]
         lib.oracle_accel_f64_from_f32.restype = None
 
@@ -163,6 +167,18 @@ class Oracle:
         if ms < 0:
             raise RuntimeError("oracle benchmark failed")
         return float(ms)
+
+    def update_subset(self, pos: np.ndarray, vel: np.ndarray, i0: int, ni: int, dt, softening=DEMO0["softening"],
+                      damping=DEMO0["damping"]):
+        """One BodySystemCPU<T>::update step for bodies [i0, i0+ni) only (bit-identical rows of a full update)."""
+        n = pos.size // 4
+        sfx = self._suffix(pos.dtype)
+        T = np.float32 if sfx == "f32" else np.float64
+        eps2 = self.softening_sq(softening, pos.dtype)
+        out_pos, out_vel = np.zeros(4 * ni, dtype=pos.dtype), np.zeros(4 * ni, dtype=pos.dtype)
+        getattr(self.lib, f"oracle_update_subset_{sfx}")(self._ptr(pos), self._ptr(vel), n, i0, ni, T(eps2), T(np.float32(damping)),
+                                                         T(np.float32(dt)), self._ptr(out_pos), self._ptr(out_vel))
+        return out_pos, out_vel
 
     def benchmark_partial(self, pos: np.ndarray, sample_i: int, softening=DEMO0["softening"]) -> float:
         """ms for the force pass of bodies i in [0, sample_i) against all bodies j (bounded cpu_baseline sample)."""

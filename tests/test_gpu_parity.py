@@ -10,6 +10,7 @@ Bars:
                  the north_star's figure.
 """
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -274,3 +275,30 @@ def test_library_leaves_the_libc_rand_stream_alone(gpu, oracle):
     assert oracle.lib.oracle_rand() == 1804289383  # first draw of the seed-1 stream: nothing was consumed
     for b in (buf, out, vel):
         b.free()
+
+
+# ---------------------------------------------------------------------------------------------- full size, bitwise
+@pytest.mark.parametrize("n,dtype", [(65536, np.float32), (262144, np.float32), (1048576, np.float32), (262144, np.float64)])
+def test_full_size_strict_bitwise_on_a_sample(gpu, O, n, dtype):
+    """BASELINE sizes (65 536 / 262 144 / 1 048 576 bodies fp32, 262 144 fp64): one STRICT step on the GPU, then
+    2 048 sampled bodies (first / middle / last blocks) against the CPU path's arithmetic -- 0 ulp -- and the FAST
+    step against the STRICT one on ALL bodies."""
+    omp = O.Oracle(openmp=True)
+    omp.set_num_threads(min(16, os.cpu_count() or 1))
+    pos0, vel0 = omp.startup_state(n, dtype)
+    dt = dtype(DT)
+    strict_pos, strict_vel = run_gpu(gpu, pos0, vel0, 1, gpu.NB_MODE_STRICT)
+    for i0 in (0, n // 2 - 300, n - 1024):
+        ni = 1024 if i0 != n // 2 - 300 else 600  # ragged middle sample
+        want_p, want_v = omp.update_subset(pos0, vel0, i0, ni, DT)
+        assert strict_pos[4 * i0:4 * (i0 + ni)].tobytes() == want_p.tobytes(), (n, i0)
+        assert strict_vel[4 * i0:4 * (i0 + ni)].tobytes() == want_v.tobytes(), (n, i0)
+    if n > 262144:
+        return  # at 1 Mi bodies the sequential fp32 sum of the CPU path is itself off by up to ~6e-3: nothing to learn
+    fast_pos, fast_vel = run_gpu(gpu, pos0, vel0, 1, gpu.NB_MODE_FAST)
+    # fp32: the gap is dominated by the CPU path's own sequential fp32 summation over N terms (error ~ sqrt(N) ulp:
+    # 1.5e-5 measured at 262 144 bodies), not by the FAST kernel, whose 16-way split sums are the more accurate ones
+    # (test_full_size_properties_fp32 holds FAST to an fp64 direct sum).
+    tol = 6e-8 * np.sqrt(n) if dtype == np.float32 else 1e-13
+    assert rel_err(fast_pos, strict_pos).max() < tol
+    del dt

@@ -147,3 +147,17 @@ def test_edge_cases(oracle):
     # AVX form keeps the reference's N % 8 restriction
     with pytest.raises(RuntimeError):
         oracle.update(np.zeros(4 * 12, np.float32), np.zeros(4 * 12, np.float32), DT, avx=True)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_update_subset_rows_equal_full_update(O, oracle, dtype):
+    """oracle.update_subset (used by the full-size GPU tests) == the matching rows of a full update, bitwise."""
+    n = 1000
+    pos, vel = oracle.startup_state(n, dtype)
+    full_p, full_v = pos.copy(), vel.copy()
+    oracle.update(full_p, full_v, DT, steps=1, damping=0.995)
+    for orc in (oracle, O.Oracle(openmp=True)):
+        for i0, ni in ((0, 8), (123, 77), (992, 8)):
+            sp, sv = orc.update_subset(pos, vel, i0, ni, DT, damping=0.995)
+            assert sp.tobytes() == full_p[4 * i0:4 * (i0 + ni)].tobytes()
+            assert sv.tobytes() == full_v[4 * i0:4 * (i0 + ni)].tobytes()

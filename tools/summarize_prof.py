@@ -19,13 +19,19 @@ import sys
 src, prefix = sys.argv[1], sys.argv[2]
 KERNEL = sys.argv[3] if len(sys.argv) > 3 else "integrate_bodies_fast"
 
-stats = glob.glob(f"{src}/trace/*/*_kernel_stats.csv")[0]
+import os
+
+def newest(pattern):
+    """gpurun merges successive runs into the same local directory: take the most recent file"""
+    return max(glob.glob(pattern), key=os.path.getmtime)
+
+stats = newest(f"{src}/trace/*/*_kernel_stats.csv")
 shutil.copy(stats, f"{prefix}_kernel_stats.csv")
 kernel_row = next(r for r in csv.DictReader(open(stats)) if KERNEL in r["Name"])
 
 counters = {}
 meta = {}
-for f in glob.glob(f"{src}/pmc_*/*/*_counter_collection.csv"):
+for f in [newest(os.path.join(d, "*", "*_counter_collection.csv")) for d in sorted(glob.glob(f"{src}/pmc_*")) if os.path.isdir(d)]:
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         if KERNEL in r["Kernel_Name"]:
