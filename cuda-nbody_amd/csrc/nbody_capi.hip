@@ -11,6 +11,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 
 namespace {
 
@@ -25,9 +26,10 @@ std::atomic<int> g_ovr_i{0}, g_ovr_s{0}, g_ovr_tile{0};
 // (randomise_bodies.cpp:37-43), so a drop-in must not disturb that stream.  The HIP runtime does: its first
 // pageable host-to-device copy consumes rand() draws (tools/rand_probe.cpp).  Every entry point that reaches
 // the runtime therefore parks the caller's random()/rand() state and lends the runtime a scratch one.
+// initstate/setstate swap a process-global pointer, so the swap-call-restore sequence is serialised across threads.
 class RandStreamGuard {
  public:
-    RandStreamGuard() {
+    RandStreamGuard() : lock_(mutex()) {
         static char scratch[128];
         static bool seeded = false;
         if (!seeded) {
@@ -44,7 +46,12 @@ class RandStreamGuard {
     RandStreamGuard& operator=(const RandStreamGuard&) = delete;
 
  private:
-    char* prev_ = nullptr;
+    static std::mutex& mutex() {
+        static std::mutex m;
+        return m;
+    }
+    std::lock_guard<std::mutex> lock_;
+    char*                       prev_ = nullptr;
 };
 #define NB_KEEP_RAND_STREAM RandStreamGuard nb_rand_stream_guard_
 
