@@ -103,6 +103,10 @@ SIGNATURES = {
     "nb_integrate_f64": (_ci, [_vp, _vp, _vp, _cd, _cd, _cu, _ci, _ci, _vp]),
     "nb_integrate_shard_f32": (_ci, [_vp, _vp, _vp, _vp, _cu, _cu, _cu, _cu, _cu, _cf, _cf, _ci, _ci, _vp]),
     "nb_integrate_shard_f64": (_ci, [_vp, _vp, _vp, _vp, _cu, _cu, _cu, _cu, _cu, _cd, _cd, _ci, _ci, _vp]),
+    "nb_graph_create_f32": (_ci, [_P(_vp), _vp, _vp, _vp, _cf, _cf, _cu, _ci, _ci, _cu]),
+    "nb_graph_create_f64": (_ci, [_P(_vp), _vp, _vp, _vp, _cd, _cd, _cu, _ci, _ci, _cu]),
+    "nb_graph_launch": (_ci, [_vp, _vp]),
+    "nb_graph_destroy": (_ci, [_vp]),
     "nb_plan_f32": (_ci, [_cu, _cu, _P(LaunchPlan)]),
     "nb_plan_f64": (_ci, [_cu, _cu, _P(LaunchPlan)]),
     "nb_set_plan_override": (_ci, [_ci, _ci, _ci]),
@@ -264,6 +268,29 @@ class BodySystemHIP:
                                self.dtype, self.mode, stream)
         self.current_read, self.current_write = self.current_write, self.current_read
 
+    def update_many(self, delta_time, steps: int, stream=None) -> None:
+        """`steps` (even) updates as ONE hipGraph launch (nb_graph_*): same kernels, same results as `steps` x update()."""
+        key = (float(delta_time), steps, self.current_read, self.mode)
+        if getattr(self, "_graph_key", None) != key:
+            self._free_graph()
+            self._apply_softening()
+            g = _vp()
+            a, b = self._pos[self.current_read].ptr, self._pos[1 - self.current_read].ptr
+            if self.dtype == np.float32:
+                rc = lib().nb_graph_create_f32(ctypes.byref(g), a, b, self._vel.ptr, np.float32(delta_time), self.damping,
+                                               self.nb_bodies, self.block_size, self.mode, steps)
+            else:
+                rc = lib().nb_graph_create_f64(ctypes.byref(g), a, b, self._vel.ptr, float(delta_time), float(self.damping),
+                                               self.nb_bodies, self.block_size, self.mode, steps)
+            check(rc, "nb_graph_create")
+            self._graph, self._graph_key = g, key
+        check(lib().nb_graph_launch(self._graph, stream), "nb_graph_launch")  # even step count: read index unchanged
+
+    def _free_graph(self) -> None:
+        if getattr(self, "_graph", None):
+            lib().nb_graph_destroy(self._graph)
+        self._graph, self._graph_key = None, None
+
     def get_position(self) -> np.ndarray:
         return self._pos[self.current_read].download(self._host_pos)
 
@@ -286,6 +313,7 @@ class BodySystemHIP:
         check(lib().nb_device_synchronize(), "nb_device_synchronize")
 
     def free(self) -> None:
+        self._free_graph()
         for b in self._pos + [self._vel]:
             b.free()
 

@@ -46,11 +46,11 @@ class RandStreamGuard {
     RandStreamGuard& operator=(const RandStreamGuard&) = delete;
 
  private:
-    static std::mutex& mutex() {
-        static std::mutex m;
+    static std::recursive_mutex& mutex() {
+        static std::recursive_mutex m;  // recursive: nb_graph_create_* calls the launch path under its own guard
         return m;
     }
-    std::lock_guard<std::mutex> lock_;
+    std::lock_guard<std::recursive_mutex> lock_;
     char*                       prev_ = nullptr;
 };
 #define NB_KEEP_RAND_STREAM RandStreamGuard nb_rand_stream_guard_
@@ -99,6 +99,53 @@ int integrate_shard(T* new_pos, const T* old_pos, T* vel, T* acc, unsigned i_beg
         return static_cast<int>(nb::launch_fast<T>(s, p, as_stream(stream)));
     }
     return NB_ERR_INVALID_ARGUMENT;
+}
+
+struct StepGraph {
+    hipGraph_t     graph = nullptr;
+    hipGraphExec_t exec  = nullptr;
+};
+
+template <typename T> int graph_create(nb_graph_t* out, T* pos_a, T* pos_b, T* vel, T dt, T damping, T eps2, unsigned n, int block_size, int mode, unsigned steps) {
+    if (!out || !pos_a || !pos_b || !vel || pos_a == pos_b || n == 0 || steps < 2 || (steps & 1u)) return NB_ERR_INVALID_ARGUMENT;
+    NB_KEEP_RAND_STREAM;
+    *out = nullptr;
+    if (mode == NB_MODE_FAST) {  // arm the >64 KiB dynamic-LDS attribute outside the capture
+        nb::Shard<T> probe{};
+        probe.i_count = n, probe.j_count = n;
+        const nb::Plan p   = nb::plan_fast<T>(n, n, cu_count_cached(), g_ovr_i.load(), g_ovr_s.load(), g_ovr_tile.load());
+        const auto     err = nb::launch_fast<T>(probe, p, nullptr, /*prepare_only=*/true);
+        if (err != hipSuccess) return static_cast<int>(err);
+    }
+    hipStream_t capture = nullptr;
+    auto        err     = hipStreamCreateWithFlags(&capture, hipStreamNonBlocking);
+    if (err != hipSuccess) return static_cast<int>(err);
+    StepGraph* g  = new StepGraph;
+    int        rc = 0;
+    err           = hipStreamBeginCapture(capture, hipStreamCaptureModeThreadLocal);
+    if (err != hipSuccess) rc = static_cast<int>(err);
+    for (unsigned k = 0; rc == 0 && k < steps; ++k) {
+        T* from = (k & 1u) ? pos_b : pos_a;
+        T* to   = (k & 1u) ? pos_a : pos_b;
+        rc      = integrate_shard<T>(to, from, vel, nullptr, 0, n, 0, n, NB_SHARD_FINALIZE, dt, damping, eps2, block_size, mode, capture);
+    }
+    if (err == hipSuccess) {  // always close an opened capture
+        const auto end = hipStreamEndCapture(capture, &g->graph);
+        if (rc == 0 && end != hipSuccess) rc = static_cast<int>(end);
+    }
+    if (rc == 0) {
+        err = hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0);
+        if (err != hipSuccess) rc = static_cast<int>(err);
+    }
+    (void)hipStreamDestroy(capture);
+    if (rc != 0) {
+        if (g->exec) (void)hipGraphExecDestroy(g->exec);
+        if (g->graph) (void)hipGraphDestroy(g->graph);
+        delete g;
+        return rc;
+    }
+    *out = g;
+    return 0;
 }
 
 template <typename T> int plan_query(unsigned i_count, unsigned j_count, nb_launch_plan_t* out) {
@@ -274,6 +321,27 @@ int nb_integrate_f64(double* new_positions, const double* old_positions, double*
     return integrate_shard<double>(new_positions, old_positions, velocities, nullptr, 0, num_bodies, 0, num_bodies, NB_SHARD_FINALIZE, dt, damping, g_softening_sq_f64.load(), block_size, mode, stream);
 }
 
+int nb_graph_create_f32(nb_graph_t* graph, float* position_a, float* position_b, float* velocities, float dt, float damping, unsigned num_bodies, int block_size, int mode, unsigned steps) {
+    return graph_create<float>(graph, position_a, position_b, velocities, dt, damping, g_softening_sq_f32.load(), num_bodies, block_size, mode, steps);
+}
+int nb_graph_create_f64(nb_graph_t* graph, double* position_a, double* position_b, double* velocities, double dt, double damping, unsigned num_bodies, int block_size, int mode, unsigned steps) {
+    return graph_create<double>(graph, position_a, position_b, velocities, dt, damping, g_softening_sq_f64.load(), num_bodies, block_size, mode, steps);
+}
+int nb_graph_launch(nb_graph_t graph, nb_stream_t stream) {
+    if (!graph) return NB_ERR_INVALID_ARGUMENT;
+    NB_KEEP_RAND_STREAM;
+    return static_cast<int>(hipGraphLaunch(static_cast<StepGraph*>(graph)->exec, as_stream(stream)));
+}
+int nb_graph_destroy(nb_graph_t graph) {
+    if (!graph) return NB_ERR_INVALID_ARGUMENT;
+    NB_KEEP_RAND_STREAM;
+    auto* g = static_cast<StepGraph*>(graph);
+    (void)hipGraphExecDestroy(g->exec);
+    (void)hipGraphDestroy(g->graph);
+    delete g;
+    return 0;
+}
+
 int nb_plan_f32(unsigned i_count, unsigned j_count, nb_launch_plan_t* plan) { return plan_query<float>(i_count, j_count, plan); }
 int nb_plan_f64(unsigned i_count, unsigned j_count, nb_launch_plan_t* plan) { return plan_query<double>(i_count, j_count, plan); }
 
@@ -283,7 +351,7 @@ int nb_set_plan_override(int bodies_per_lane, int lanes_per_body, int tile_bodie
             if (v == a) return true;
         return false;
     };
-    if (!ok(bodies_per_lane, {0, 1, 2, 4, 8}) || !ok(lanes_per_body, {0, 1, 2, 4, 8, 16}) || !ok(tile_bodies, {0, 256, 512, 1024, 2048, 4096})) return NB_ERR_INVALID_ARGUMENT;
+    if (!ok(bodies_per_lane, {0, 1, 2, 4, 8}) || !ok(lanes_per_body, {0, 1, 2, 4, 8, 16, 64}) || !ok(tile_bodies, {0, 256, 512, 1024, 2048, 4096})) return NB_ERR_INVALID_ARGUMENT;
     g_ovr_i.store(bodies_per_lane);
     g_ovr_s.store(lanes_per_body);
     g_ovr_tile.store(tile_bodies);

@@ -34,6 +34,8 @@ namespace {
 
 // workgroup size by j-split factor: S <= 4 -> 256 threads, S = 8 -> 512, S = 16 -> 1024 (a lane group stays >= one wave)
 constexpr int block_threads_for(int S) { return S <= 4 ? 256 : 64 * S; }
+// lanes_per_body value that selects the wave-split layout (all 64 lanes of a wave split j for the wave's bodies i)
+constexpr int kWaveSplit = 64;
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 
@@ -251,33 +253,169 @@ template <typename T, int R, int S, int LPT> __global__ __launch_bounds__(block_
     }
 }
 
-template <typename T, int R, int S, int LPT> hipError_t launch_one(const Shard<T>& s, const Plan& p, hipStream_t stream) {
-    if (p.lds_bytes > 64u * 1024u) {  // above the default dynamic-LDS ceiling: opt in once per kernel (gfx950 has 160 KiB per CU)
-        static hipError_t opted = hipFuncSetAttribute(reinterpret_cast<const void*>(&integrate_bodies_fast<T, R, S, LPT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (opted != hipSuccess) return opted;
+// ---- wave-split layout for small shards ------------------------------------------------------------------
+// When there are fewer bodies i than the chip has lanes (i_count < 64*W*#CUs: 32 768 fp32 bodies on 256 CUs) the
+// layout above leaves CUs idle.  Here the roles turn: a WAVE owns R vectors of bodies i (wave-uniform registers)
+// and its 64 lanes split the bodies j -- lane l takes tile entries l, l+64, ... (one conflict-free ds_read_b128 per
+// lane, stride 16 B) -- and the 64 partial sums are folded with a wavefront-64 butterfly (ds_swizzle/bpermute
+// shuffles, fixed order => deterministic).  Same interaction code, same LDS staging; 4 waves (4 x I bodies) per
+// 256-thread workgroup, so 1 024 bodies already make 128-256 workgroups.
+template <typename F> __device__ __forceinline__ F wave64_sum(F v) {
+#pragma unroll
+    for (int offset = 32; offset > 0; offset >>= 1) v += __shfl_xor(v, offset, 64);
+    return v;
+}
+
+template <typename T, int R, int LPT> __global__ __launch_bounds__(256) void integrate_bodies_wavesplit(Shard<T> s) {
+    using LT            = Lane<T>;
+    using vec4          = typename LT::vec4;
+    using vec           = typename LT::vec;
+    constexpr int kBlock = 256;
+    constexpr int WAVES = kBlock / 64;
+    constexpr int W     = LT::W;
+    constexpr int I     = R * W;          // bodies i per WAVE
+    constexpr int TILE  = kBlock * LPT;   // bodies j per LDS tile
+    constexpr int U     = 8 / R;          // j bodies in flight per lane (8 independent interaction chains)
+    static_assert(TILE % (64 * U) == 0, "a tile is consumed in rounds of 64*U bodies");
+
+    extern __shared__ __attribute__((aligned(32))) unsigned char smem_raw[];
+    vec4* tile = reinterpret_cast<vec4*>(smem_raw);  // [2][TILE]
+
+    const vec4* __restrict__ old_pos = reinterpret_cast<const vec4*>(s.old_pos);
+    const int tid  = threadIdx.x;
+    const int wave = tid >> 6;
+    const int lane = tid & 63;
+
+    // bodies i of this wave (every lane holds the same values)
+    const unsigned wave_base = (blockIdx.x * WAVES + wave) * I;
+    vec      px[R], py[R], pz[R], ax[R], ay[R], az[R];
+    unsigned idx[I];
+    bool     active[I];
+#pragma unroll
+    for (int k = 0; k < I; ++k) {
+        const unsigned local = wave_base + k;
+        active[k]            = local < s.i_count;
+        idx[k]               = s.i_begin + (active[k] ? local : s.i_count - 1);
+        const vec4 p         = old_pos[idx[k]];
+        LT::set(px[k / W], k % W, p.x);
+        LT::set(py[k / W], k % W, p.y);
+        LT::set(pz[k / W], k % W, p.z);
     }
-    hipLaunchKernelGGL((integrate_bodies_fast<T, R, S, LPT>), dim3(p.grid_blocks), dim3(block_threads_for(S)), p.lds_bytes, stream, s);
+#pragma unroll
+    for (int r = 0; r < R; ++r) ax[r] = ay[r] = az[r] = LT::splat(0);
+    vec eps2 = LT::splat(s.eps2);
+    LT::keep_in_vgpr(eps2);
+
+    const unsigned j_end   = s.j_begin + s.j_count;
+    const unsigned n_tiles = (s.j_count + TILE - 1) / TILE;
+
+    auto load_tile = [&](unsigned t, vec4 (&regs)[LPT]) {
+#pragma unroll
+        for (int r = 0; r < LPT; ++r) {
+            const unsigned j = s.j_begin + t * TILE + r * kBlock + tid;
+            vec4           v;
+            v.x = v.y = v.z = v.w = 0;  // out-of-range slots: zero-mass bodies, contribute exactly 0
+            if (j < j_end) v = old_pos[j];
+            regs[r] = v;
+        }
+    };
+    auto store_tile = [&](int buf, const vec4 (&regs)[LPT]) {
+#pragma unroll
+        for (int r = 0; r < LPT; ++r) tile[buf * TILE + r * kBlock + tid] = regs[r];
+    };
+
+    vec4 regs[LPT];
+    load_tile(0, regs);
+    store_tile(0, regs);
+    __syncthreads();
+
+    for (unsigned t = 0; t < n_tiles; ++t) {
+        const int  cur       = t & 1;
+        const bool have_next = (t + 1) < n_tiles;
+        if (have_next) load_tile(t + 1, regs);
+        const vec4* __restrict__ mine = tile + cur * TILE + lane;  // this lane's column of the tile
+#pragma unroll 1
+        for (int jj = 0; jj < TILE; jj += 64 * U) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) interact<T, R>(mine[jj + 64 * u], px, py, pz, ax, ay, az, eps2);
+        }
+        if (have_next) store_tile(cur ^ 1, regs);
+        __syncthreads();
+    }
+
+    // wavefront-64 fold; lane k then finishes body k of the wave
+#pragma unroll
+    for (int k = 0; k < I; ++k) {
+        T fx = wave64_sum(LT::get(ax[k / W], k % W));
+        T fy = wave64_sum(LT::get(ay[k / W], k % W));
+        T fz = wave64_sum(LT::get(az[k / W], k % W));
+        if (lane != k || !active[k]) continue;
+        const unsigned i = idx[k];
+        if (s.acc_in) {
+            const vec4 a = reinterpret_cast<const vec4*>(s.acc)[i];
+            fx += a.x, fy += a.y, fz += a.z;
+        }
+        if (s.finalize) {
+            vec4 v  = reinterpret_cast<const vec4*>(s.vel)[i];
+            vec4 pn = old_pos[i];
+            v.x     = __builtin_fma(fx, s.dt, v.x) * s.damping;
+            v.y     = __builtin_fma(fy, s.dt, v.y) * s.damping;
+            v.z     = __builtin_fma(fz, s.dt, v.z) * s.damping;
+            pn.x    = __builtin_fma(v.x, s.dt, pn.x);
+            pn.y    = __builtin_fma(v.y, s.dt, pn.y);
+            pn.z    = __builtin_fma(v.z, s.dt, pn.z);
+            reinterpret_cast<vec4*>(s.new_pos)[i] = pn;
+            reinterpret_cast<vec4*>(s.vel)[i]     = v;
+        } else {
+            vec4 a;
+            a.x = fx, a.y = fy, a.z = fz, a.w = 0;
+            reinterpret_cast<vec4*>(s.acc)[i] = a;
+        }
+    }
+}
+
+template <typename T, int R, int LPT> hipError_t launch_wavesplit(const Shard<T>& s, const Plan& p, hipStream_t stream, bool prepare_only) {
+    if (prepare_only) return hipSuccess;
+    hipLaunchKernelGGL((integrate_bodies_wavesplit<T, R, LPT>), dim3(p.grid_blocks), dim3(256), p.lds_bytes, stream, s);
     return hipGetLastError();
 }
 
-template <typename T, int R, int S> hipError_t dispatch_lpt(const Shard<T>& s, const Plan& p, hipStream_t stream) {
-    constexpr int kBlock = block_threads_for(S);
-    if (p.tile_bodies % kBlock) return hipErrorInvalidValue;
-    switch (p.tile_bodies / kBlock) {
-        case 1: return launch_one<T, R, S, 1>(s, p, stream);
-        case 2: return launch_one<T, R, S, 2>(s, p, stream);
-        case 4: return launch_one<T, R, S, 4>(s, p, stream);
+template <typename T, int R> hipError_t dispatch_wavesplit(const Shard<T>& s, const Plan& p, hipStream_t stream, bool prepare_only) {
+    switch (p.tile_bodies / 256) {
+        case 2: return launch_wavesplit<T, R, 2>(s, p, stream, prepare_only);
+        case 4: return launch_wavesplit<T, R, 4>(s, p, stream, prepare_only);
         default: return hipErrorInvalidValue;
     }
 }
 
-template <typename T, int R> hipError_t dispatch_s(const Shard<T>& s, const Plan& p, hipStream_t stream) {
+template <typename T, int R, int S, int LPT> hipError_t launch_one(const Shard<T>& s, const Plan& p, hipStream_t stream, bool prepare_only) {
+    if (p.lds_bytes > 64u * 1024u) {  // above the default dynamic-LDS ceiling: opt in once per kernel (gfx950 has 160 KiB per CU)
+        static hipError_t opted = hipFuncSetAttribute(reinterpret_cast<const void*>(&integrate_bodies_fast<T, R, S, LPT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (opted != hipSuccess) return opted;
+    }
+    if (prepare_only) return hipSuccess;  // graph capture arms the attribute before hipStreamBeginCapture
+    hipLaunchKernelGGL((integrate_bodies_fast<T, R, S, LPT>), dim3(p.grid_blocks), dim3(block_threads_for(S)), p.lds_bytes, stream, s);
+    return hipGetLastError();
+}
+
+template <typename T, int R, int S> hipError_t dispatch_lpt(const Shard<T>& s, const Plan& p, hipStream_t stream, bool prepare_only) {
+    constexpr int kBlock = block_threads_for(S);
+    if (p.tile_bodies % kBlock) return hipErrorInvalidValue;
+    switch (p.tile_bodies / kBlock) {
+        case 1: return launch_one<T, R, S, 1>(s, p, stream, prepare_only);
+        case 2: return launch_one<T, R, S, 2>(s, p, stream, prepare_only);
+        case 4: return launch_one<T, R, S, 4>(s, p, stream, prepare_only);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+template <typename T, int R> hipError_t dispatch_s(const Shard<T>& s, const Plan& p, hipStream_t stream, bool prepare_only) {
     switch (p.lanes_per_body) {
-        case 1: return dispatch_lpt<T, R, 1>(s, p, stream);
-        case 2: return dispatch_lpt<T, R, 2>(s, p, stream);
-        case 4: return dispatch_lpt<T, R, 4>(s, p, stream);
-        case 8: return dispatch_lpt<T, R, 8>(s, p, stream);
-        case 16: return dispatch_lpt<T, R, 16>(s, p, stream);
+        case 1: return dispatch_lpt<T, R, 1>(s, p, stream, prepare_only);
+        case 2: return dispatch_lpt<T, R, 2>(s, p, stream, prepare_only);
+        case 4: return dispatch_lpt<T, R, 4>(s, p, stream, prepare_only);
+        case 8: return dispatch_lpt<T, R, 8>(s, p, stream, prepare_only);
+        case 16: return dispatch_lpt<T, R, 16>(s, p, stream, prepare_only);
         default: return hipErrorInvalidValue;
     }
 }
@@ -298,8 +436,25 @@ template <typename T> Plan plan_fast(unsigned i_count, unsigned j_count, int cu_
     int           I    = W;
     while (I * 2 <= kMaxI && static_cast<long>(i_count) / (64L * I * 2) >= cu_count) I *= 2;
     int S = 16;
+    // fewer bodies i than one wave per SIMD pair of the tile layout can use: turn to the wave-split layout (S = 64)
+    if (static_cast<long>(i_count) < 64L * W * cu_count) {
+        S = kWaveSplit;
+        I = (static_cast<long>(i_count) / (4 * 2 * W) >= 4L * cu_count) ? 2 * W : W;  // 2 vectors per wave while that leaves >= 4 workgroups per CU
+    }
     if (ovr_i > 0) I = std::max(ovr_i / W * W, W);
     if (ovr_s > 0) S = ovr_s;
+    if (S == kWaveSplit) {
+        if (I > 2 * W) I = 2 * W;
+        Plan p;
+        p.bodies_per_lane = I;  // per WAVE in this layout
+        p.lanes_per_body  = kWaveSplit;
+        p.tile_bodies     = (ovr_tile == 512 || ovr_tile == 1024) ? ovr_tile : (j_count > 512 ? 1024 : 512);
+        p.block_threads   = 256;
+        const unsigned bodies_per_block = 4u * static_cast<unsigned>(I);
+        p.grid_blocks     = (i_count + bodies_per_block - 1) / bodies_per_block;
+        p.lds_bytes       = static_cast<unsigned>(2ull * p.tile_bodies * 4 * sizeof(T));
+        return p;
+    }
     const int block = block_threads_for(S);
     int       tile  = (sizeof(T) == 4 && j_count >= 8192) ? 2048 : 1024;
     if (ovr_tile > 0) tile = ovr_tile;
@@ -318,19 +473,26 @@ template <typename T> Plan plan_fast(unsigned i_count, unsigned j_count, int cu_
     return p;
 }
 
-template <typename T> hipError_t launch_fast(const Shard<T>& s, const Plan& p, hipStream_t stream) {
+template <typename T> hipError_t launch_fast(const Shard<T>& s, const Plan& p, hipStream_t stream, bool prepare_only) {
     constexpr int W = Lane<T>::W;
+    if (p.lanes_per_body == kWaveSplit) {
+        switch (p.bodies_per_lane / W) {
+            case 1: return dispatch_wavesplit<T, 1>(s, p, stream, prepare_only);
+            case 2: return dispatch_wavesplit<T, 2>(s, p, stream, prepare_only);
+            default: return hipErrorInvalidValue;
+        }
+    }
     switch (p.bodies_per_lane / W) {
-        case 1: return dispatch_s<T, 1>(s, p, stream);
-        case 2: return dispatch_s<T, 2>(s, p, stream);
-        case 4: return dispatch_s<T, 4>(s, p, stream);
+        case 1: return dispatch_s<T, 1>(s, p, stream, prepare_only);
+        case 2: return dispatch_s<T, 2>(s, p, stream, prepare_only);
+        case 4: return dispatch_s<T, 4>(s, p, stream, prepare_only);
         default: return hipErrorInvalidValue;
     }
 }
 
 template Plan       plan_fast<float>(unsigned, unsigned, int, int, int, int);
 template Plan       plan_fast<double>(unsigned, unsigned, int, int, int, int);
-template hipError_t launch_fast<float>(const Shard<float>&, const Plan&, hipStream_t);
-template hipError_t launch_fast<double>(const Shard<double>&, const Plan&, hipStream_t);
+template hipError_t launch_fast<float>(const Shard<float>&, const Plan&, hipStream_t, bool);
+template hipError_t launch_fast<double>(const Shard<double>&, const Plan&, hipStream_t, bool);
 
 }  // namespace nb

@@ -25,6 +25,13 @@ template <std::floating_point T> class BodySystemHIP {
 
     auto virtual update(T deltaTime) -> void = 0;
 
+    // Extension: `steps` updates issued as one unit.  The default is a loop of update(); the device-memory
+    // variant replays a captured hipGraph (steps even), built by prepare_many() outside any timed region.
+    auto virtual prepare_many([[maybe_unused]] T deltaTime, [[maybe_unused]] unsigned steps) -> void {}
+    auto virtual update_many(T deltaTime, unsigned steps) -> void {
+        for (unsigned s = 0; s < steps; ++s) update(deltaTime);
+    }
+
     auto update_params(const NBodyParams& active_params) -> void;
 
     auto virtual set_position(std::span<const T> data) -> void = 0;

@@ -24,6 +24,40 @@ template <std::floating_point T> auto BodySystemHIPDefault<T>::update(T deltaTim
     std::swap(this->current_read_, this->current_write_);
 }
 
+template <std::floating_point T> BodySystemHIPDefault<T>::~BodySystemHIPDefault() { drop_graph(); }
+
+template <std::floating_point T> auto BodySystemHIPDefault<T>::drop_graph() noexcept -> void {
+    if (graph_ != nullptr) (void)nb_graph_destroy(graph_);
+    graph_ = nullptr;
+}
+
+// Launch-bound small systems: capture `steps` ping-pong launches once, replay them with one host call.
+template <std::floating_point T> auto BodySystemHIPDefault<T>::prepare_many(T deltaTime, unsigned steps) -> void {
+    if (steps < 2 || (steps & 1u)) return;  // odd counts fall back to the loop in update_many
+    if (graph_ != nullptr && graph_dt_ == deltaTime && graph_steps_ == steps && graph_read_ == this->current_read_) return;
+    drop_graph();
+    this->apply_softening();
+    T* a = device_pos_[this->current_read_].data();
+    T* b = device_pos_[1 - this->current_read_].data();
+    int status;
+    if constexpr (std::same_as<T, float>) {
+        status = nb_graph_create_f32(&graph_, a, b, device_vel_.data(), deltaTime, this->damping_, this->nb_bodies_, static_cast<int>(this->block_size_), nbody_hip::integration_mode(), steps);
+    } else {
+        status = nb_graph_create_f64(&graph_, a, b, device_vel_.data(), deltaTime, this->damping_, this->nb_bodies_, static_cast<int>(this->block_size_), nbody_hip::integration_mode(), steps);
+    }
+    hip_check(status, "nb_graph_create");
+    graph_dt_ = deltaTime, graph_steps_ = steps, graph_read_ = this->current_read_;
+}
+
+template <std::floating_point T> auto BodySystemHIPDefault<T>::update_many(T deltaTime, unsigned steps) -> void {
+    if (steps < 2 || (steps & 1u)) {
+        BodySystemHIP<T>::update_many(deltaTime, steps);
+        return;
+    }
+    prepare_many(deltaTime, steps);
+    hip_check(nb_graph_launch(graph_, nullptr), "nb_graph_launch");  // even step count: the read index is unchanged
+}
+
 // blocking D2H into the host mirror   (:26-37)
 template <std::floating_point T> auto BodySystemHIPDefault<T>::get_position() const -> std::span<const T> {
     device_pos_[this->current_read_].download(host_pos_);

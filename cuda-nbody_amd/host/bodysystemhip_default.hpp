@@ -15,6 +15,9 @@ template <std::floating_point T> class BodySystemHIPDefault : public BodySystemH
     auto get_position() const -> std::span<const T> override;
     auto get_velocity() const -> std::span<const T> override;
     auto update(T deltaTime) -> void override;
+    auto prepare_many(T deltaTime, unsigned steps) -> void override;
+    auto update_many(T deltaTime, unsigned steps) -> void override;
+    ~BodySystemHIPDefault() override;
     auto set_position(std::span<const T> data) -> void override;
     auto set_velocity(std::span<const T> data) -> void override;
 
@@ -25,6 +28,13 @@ template <std::floating_point T> class BodySystemHIPDefault : public BodySystemH
 
     std::array<DeviceArray<T>, 2> device_pos_{DeviceArray<T>(this->nb_bodies_ * 4), DeviceArray<T>(this->nb_bodies_ * 4)};
     DeviceArray<T>                device_vel_{this->nb_bodies_ * 4};
+
+    // captured step loop (nb_graph_*): valid for one (dt, steps, read index) combination
+    auto drop_graph() noexcept -> void;
+    nb_graph_t   graph_       = nullptr;
+    T            graph_dt_    = 0;
+    unsigned     graph_steps_ = 0;
+    unsigned int graph_read_  = 0;
 };
 
 extern template class BodySystemHIPDefault<float>;

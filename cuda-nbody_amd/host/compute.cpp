@@ -110,6 +110,8 @@ auto Compute::run_benchmark(int nb_iterations) -> void {
     print_benchmark_results(nb_iterations, milliseconds.count());
 }
 
+auto Compute::use_graph(bool enable) -> void { compute_hip_->use_graph(enable); }
+
 auto Compute::compare_results() -> bool { return compute_hip_->compare_results(active_params_); }
 
 auto Compute::positions_fp32() const -> std::span<const float> { return compute_hip_->get_position_fp32(); }

@@ -31,6 +31,7 @@ class Compute {
     auto fp64_enabled() const noexcept { return fp64_enabled_; }
 
     auto run_benchmark(int nb_iterations) -> void;
+    auto use_graph(bool enable) -> void;
     auto compare_results() -> bool;
     auto switch_precision() -> void;
     auto select_demo(std::size_t index) -> void;

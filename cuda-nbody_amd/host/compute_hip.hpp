@@ -44,6 +44,8 @@ class ComputeHIP {
     using Milliseconds = std::chrono::duration<float, std::milli>;
     auto get_milliseconds_passed() -> Milliseconds;
     auto run_benchmark(int nb_iterations, float dt) -> Milliseconds;
+    // extension (--graph): issue the timed iterations as one captured hipGraph instead of K launches
+    auto use_graph(bool enable) noexcept -> void { use_graph_ = enable; }
 
     ~ComputeHIP() noexcept;
 
@@ -57,6 +59,7 @@ class ComputeHIP {
     bool        fp64_enabled_;
     bool        use_host_mem_;
     bool        double_supported_ = true;
+    bool        use_graph_        = false;
 
     std::unique_ptr<BodySystemHIP<float>>  nbody_fp32_;
     std::unique_ptr<BodySystemHIP<double>> nbody_fp64_;

@@ -4,7 +4,7 @@
 //
 //   reference flags : --fullscreen --fp64 --hostmem --benchmark --numbodies=<n> --compare --qatest --cpu
 //                     --tipsy=<file> -i,--iterations=<n> --blockSize=<n>      (single-dash spellings accepted too)
-//   extensions      : --mode=fast|strict  --config=shell|random|expand  --steps=<n>  --dump=<file>  --seed=<n>
+//   extensions      : --mode=fast|strict  --config=shell|random|expand  --steps=<n>  --dump=<file>  --seed=<n>  --graph
 #include "compute.hpp"
 #include "integrate_nbody_hip.hpp"
 
@@ -44,6 +44,7 @@ struct Options {
     std::size_t           steps  = 0;
     std::filesystem::path dump;
     std::optional<unsigned> seed;
+    bool                  graph = false;
 };
 
 constexpr auto help_text = R"(The MI355X NBody hot path (drop-in for cuda-nbody's compute path).
@@ -67,6 +68,7 @@ Options:
   --steps UINT                Advance this many steps (untimed) before --dump
   --dump TEXT                 Write final positions then velocities (raw little-endian T[4N] each) to this file
   --seed UINT                 srand() this value first (the reference never seeds: default stream = seed 1)
+  --graph                     --benchmark issues its (even number of) iterations as one captured hipGraph
 )";
 
 template <typename I> auto parse_number(std::string_view text, I& out) -> bool {
@@ -123,6 +125,7 @@ auto parse_args(int argc, char** argv) -> std::pair<Status, Options> {
         else if (name == "compare") ok = flag(options.compare);
         else if (name == "qatest") ok = flag(options.qatest);
         else if (name == "cpu") ok = flag(options.cpu);
+        else if (name == "graph") ok = flag(options.graph);
         else if (name == "numbodies") {
             const auto v = take_value();
             ok           = v && parse_number(*v, options.numbodies) && options.numbodies >= 1;
@@ -201,6 +204,7 @@ auto main(int argc, char** argv) -> int {
 
         auto compute = Compute(cmd_options.fp64, cmd_options.cpu, compare_to_cpu, cmd_options.benchmark, cmd_options.hostmem, cmd_options.block_size, cmd_options.numbodies, cmd_options.tipsy, cmd_options.config);
 
+        compute.use_graph(cmd_options.graph);
         if (cmd_options.benchmark) {
             const auto nb_iterations = cmd_options.iterations == 0 ? 10 : static_cast<int>(cmd_options.iterations);
             compute.run_benchmark(nb_iterations);

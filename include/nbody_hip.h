@@ -135,10 +135,23 @@ NB_API int nb_integrate_shard_f64(double* new_positions, const double* old_posit
                                   unsigned flags, double delta_time, double damping, int block_size, int mode,
                                   nb_stream_t stream);
 
+/* ---- hipGraph form of the step loop (new).  Small systems are launch-bound (a 1 024-body step is ~2 us of GPU work):
+ *  `steps` consecutive nb_integrate_* launches, ping-ponging between position_a (read first) and position_b, are
+ *  captured once and replayed with one host call.  `steps` must be even so every replay starts from position_a again.
+ *  The softening^2 current at creation time is baked in.  The arrays must outlive the graph. ------------------------ */
+typedef void* nb_graph_t;
+NB_API int nb_graph_create_f32(nb_graph_t* graph, float* position_a, float* position_b, float* velocities,
+                               float delta_time, float damping, unsigned num_bodies, int block_size, int mode, unsigned steps);
+NB_API int nb_graph_create_f64(nb_graph_t* graph, double* position_a, double* position_b, double* velocities,
+                               double delta_time, double damping, unsigned num_bodies, int block_size, int mode, unsigned steps);
+NB_API int nb_graph_launch(nb_graph_t graph, nb_stream_t stream);
+NB_API int nb_graph_destroy(nb_graph_t graph);
+
 /* ---- introspection: the launch geometry the FAST path would use for a shard (tests / DESIGN.md) ---- */
 typedef struct nb_launch_plan {
     int bodies_per_lane;   /* I  : i-bodies register-tiled per lane                  */
-    int lanes_per_body;    /* S  : lanes of one workgroup that split the j range     */
+    int lanes_per_body;    /* S  : wave groups of one workgroup that split the j range; 64 = wave-split layout
+                              (small shards): the 64 lanes of a wave split j and bodies_per_lane counts per WAVE */
     int tile_bodies;       /* LDS tile, bodies                                       */
     int block_threads;
     unsigned grid_blocks;

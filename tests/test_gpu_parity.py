@@ -134,7 +134,8 @@ def gpu_accel(gpu, pos, dtype, i_begin, i_count, j_begin, j_count, mode, acc_in=
 
 
 @pytest.mark.parametrize("plan", [(2, 1, 256), (2, 1, 1024), (4, 1, 1024), (8, 1, 512), (2, 2, 1024), (4, 4, 256), (8, 4, 1024), (2, 4, 512), (4, 2, 512), (8, 2, 256),
-                                  (2, 8, 512), (4, 8, 1024), (2, 16, 1024), (4, 16, 1024), (8, 16, 1024), (8, 8, 512)])
+                                  (2, 8, 512), (4, 8, 1024), (2, 16, 1024), (4, 16, 1024), (8, 16, 1024), (8, 8, 512),
+                                  (2, 64, 512), (2, 64, 1024), (4, 64, 512), (4, 64, 1024)])  # S = 64: wave-split layout
 def test_fast_force_error_every_geometry(gpu, oracle, plan):
     """Every (bodies/lane, lane-groups, tile) instantiation against an fp64 direct sum, ragged N and ranges."""
     n = 3000
@@ -179,6 +180,28 @@ def test_shard_chunks_compose(gpu, oracle, dtype, mode_name):
         assert err.max() < tol, err.max()
     # untouched rows stay zero (only the i-slice is written)
     assert not acc.reshape(n, 4)[:i0].any() and not acc.reshape(n, 4)[i0 + ni:].any()
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_fast_fp64_and_fp32_wavesplit_vs_tile_layout(gpu, oracle, dtype):
+    """Small shards run the wave-split layout by default; forcing the tile layout must give the same forces to rounding."""
+    n = 4000
+    eps = dtype(np.float32(0.1))
+    gpu.set_softening_squared(eps * eps)
+    oracle.srand(21)
+    pos, _ = oracle.randomise(1, n, 1.54, 8.0, dtype)
+    assert gpu.plan(n, n, dtype).lanes_per_body == 64
+    a = gpu_accel(gpu, pos, dtype, 0, n, 0, n, gpu.NB_MODE_FAST)
+    gpu.set_plan_override(0, 16, 0)
+    try:
+        assert gpu.plan(n, n, dtype).lanes_per_body == 16
+        b = gpu_accel(gpu, pos, dtype, 0, n, 0, n, gpu.NB_MODE_FAST)
+    finally:
+        gpu.set_plan_override(0, 0, 0)
+    err = np.linalg.norm(xyz(a) - xyz(b), axis=1) / np.linalg.norm(xyz(b), axis=1)
+    assert err.max() < (1e-5 if dtype == np.float32 else 1e-13), err.max()  # two summation orders of ~4000 terms
+    # large shards keep the tile layout
+    assert gpu.plan(262144, 262144, dtype).lanes_per_body == 16
 
 
 def test_fast_handles_tiny_and_ragged_n(gpu, oracle):
@@ -302,3 +325,29 @@ def test_full_size_strict_bitwise_on_a_sample(gpu, O, n, dtype):
     tol = 6e-8 * np.sqrt(n) if dtype == np.float32 else 1e-13
     assert rel_err(fast_pos, strict_pos).max() < tol
     del dt
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("mode_name", ["strict", "fast"])
+def test_graph_replay_equals_eager_steps(gpu, oracle, dtype, mode_name):
+    """nb_graph_*: 6 captured steps replayed twice == 12 eager steps, bitwise (same kernels, same launch geometry)."""
+    mode = gpu.NB_MODE_STRICT if mode_name == "strict" else gpu.NB_MODE_FAST
+    n = 1536
+    pos0, vel0 = oracle.startup_state(n, dtype)
+    eager = gpu.BodySystemHIP(n, 256, gpu.NBodyParams(), dtype, pos0, vel0, mode=mode)
+    for _ in range(12):
+        eager.update(dtype(DT))
+    graph = gpu.BodySystemHIP(n, 256, gpu.NBodyParams(), dtype, pos0, vel0, mode=mode)
+    graph.update_many(dtype(DT), 6)
+    graph.update_many(dtype(DT), 6)
+    assert graph.get_position().tobytes() == eager.get_position().tobytes()
+    assert graph.get_velocity().tobytes() == eager.get_velocity().tobytes()
+    if mode == gpu.NB_MODE_STRICT:
+        ref_p, ref_v = pos0.copy(), vel0.copy()
+        oracle.update(ref_p, ref_v, DT, steps=12)
+        assert graph.get_position().tobytes() == ref_p.tobytes()
+    lib = gpu.lib()
+    g = ctypes.c_void_p()
+    assert lib.nb_graph_create_f32(ctypes.byref(g), graph._pos[0].ptr, graph._pos[1].ptr, graph._vel.ptr, 0.016, 1.0, n, 256, mode, 3) == 10001  # odd
+    assert lib.nb_graph_create_f32(ctypes.byref(g), graph._pos[0].ptr, graph._pos[0].ptr, graph._vel.ptr, 0.016, 1.0, n, 256, mode, 2) == 10001  # aliasing
+    eager.free(), graph.free()
