@@ -63,7 +63,29 @@ class ShardedBodySystem:
         self.read = 0
         self.pending = None  # the in-flight all-gather of self.pos[self.read]
         self.schedule = chunk_schedule(self.i0, self.ni, self.n, ordered)
-        self._gather = gather or (lambda full, own: self.dist.all_gather_into_tensor(full, own, group=self.group, async_op=True))
+        self._gather = gather or self._rccl_gather
+        self._in_place = True
+
+    def _rccl_gather(self, full, own):
+        """In-place all-gather (own slice already sits at its offset in `full`; RCCL then moves only remote slices).
+        If the backend rejects the aliasing form, fall back once and for all to gathering into a staging buffer."""
+        if self._in_place:
+            try:
+                return self.dist.all_gather_into_tensor(full, own, group=self.group, async_op=True)
+            except (RuntimeError, ValueError):
+                self._in_place = False
+                self._staging = full.new_empty(full.shape)
+        work = self.dist.all_gather_into_tensor(self._staging, own.contiguous(), group=self.group, async_op=True)
+
+        class _CopyBack:
+            def __init__(self, work, dst, src):
+                self.work, self.dst, self.src = work, dst, src
+
+            def wait(self):
+                self.work.wait()
+                self.dst.copy_(self.src)
+
+        return _CopyBack(work, full, self._staging)
 
     def update(self) -> None:
         """One step: pos[1-read][own], vel[own] <- integrate(pos[read]); then start gathering pos[1-read]."""
