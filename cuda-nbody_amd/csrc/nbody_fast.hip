@@ -10,15 +10,16 @@
 //     carries its bodies i in PAIRS, one pair per 64-bit VGPR pair: an interaction pair is
 //     3 v_pk_add + 6 v_pk_fma + 3 v_pk_mul + 2 v_rsq_f32 (14 issue slots for 2 interactions instead of 26),
 //     the j body's x/y/z/m being broadcast into both halves with op_sel, not moved.
-//     fp64 has no packed form: one body per "vector", v_rsq_f64 seed + 2 Newton steps.
-//   * 256-thread workgroups = 4 wave64.  Each lane register-tiles R vectors (I = R*W bodies i, W = 2 fp32 /
-//     1 fp64), so one broadcast ds_read_b128 of a body j feeds I interactions.
-//   * j bodies stream HBM/L2 -> registers -> LDS in tiles of TILE = 256*LPT bodies (coalesced 16 B/lane
-//     global_load_dwordx4), double-buffered: tile t+1 is in flight in registers while tile t is consumed
-//     from LDS; ONE barrier per tile.
-//   * j-split: the S lane groups of a workgroup (whole waves, L = 256/S lanes) walk disjoint 1/S slices of
-//     every tile for the SAME bodies i and are folded through LDS in a fixed order at the end
-//     (deterministic).  This is what puts >= 2-4 waves on every SIMD of 256 CUs when N/I < 131072 lanes.
+//     fp64 has no packed form: one body per "vector"; m*d2^(-3/2) from the v_rsq_f64 seed by a 2-term series (Lane<double>::coupling).
+//   * Tile layout (large shards): each lane register-tiles R vectors (I = R*W bodies i, W = 2 fp32 / 1 fp64), so
+//     one broadcast ds_read_b128 of a body j feeds I interactions.  j bodies stream HBM/L2 -> registers -> LDS in
+//     tiles of TILE = block*LPT bodies (coalesced 16 B/lane global_load_dwordx4), double-buffered: tile t+1 is in
+//     flight in registers while tile t is consumed from LDS; ONE barrier per tile.
+//   * j-split: the S wave groups of a workgroup (L = block/S lanes each, whole waves) walk disjoint 1/S slices of
+//     every tile for the SAME bodies i and are folded through LDS in a fixed order at the end (deterministic).
+//     Production geometry is S = 16: a 1024-thread workgroup = 4 waves on every SIMD of its CU (plan_fast below).
+//   * Wave-split layout (small shards, fewer bodies i than lanes on the chip): a wave owns the bodies i, its 64
+//     lanes split j, wavefront-64 butterfly fold at the end (integrate_bodies_wavesplit below).
 //   * softening^2 lives in VGPRs: a VALU op with an SGPR source issues ~35 % slower on this chip.
 //   * The shard form (i-range x j-range, optional partial sums in/out) is the same kernel; the single-GPU
 //     step is the shard i = j = [0,N) with finalize.
