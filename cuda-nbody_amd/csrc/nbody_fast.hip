@@ -428,17 +428,29 @@ template <typename T, int R> hipError_t dispatch_s(const Shard<T>& s, const Plan
 //     walking 1/16 of every LDS tile.  One resident workgroup per CU fills the chip for any shard with >= 256
 //     workgroups, which is what keeps a 32 768-body shard (8-GPU strong scaling of 262 144 bodies) at 94 % of the
 //     full-size rate; at full size it is as fast as any smaller split.
-//   * I (bodies i per lane, a multiple of W: fp32 bodies travel in packed pairs) as large as possible while the
-//     shard still yields one workgroup per CU: register tiling amortises the LDS broadcast and the per-tile barrier.
+//   * I (bodies i per lane, a multiple of W: fp32 bodies travel in packed pairs; at most 4, what fits 128 VGPRs):
+//     register tiling amortises the LDS broadcast and the per-tile barrier, but what matters more is how the
+//     resulting workgroup count fills whole rounds of 256 CUs.
 //   * LDS tile 2048 bodies (fp32, 2 x 32 KiB double-buffered) / 1024 (fp64): 128 bodies j per wave between barriers.
 template <typename T> Plan plan_fast(unsigned i_count, unsigned j_count, int cu_count, int ovr_i, int ovr_s, int ovr_tile) {
-    constexpr int W    = Lane<T>::W;
+    constexpr int W     = Lane<T>::W;
     constexpr int kMaxI = 4;  // fp32: 2 packed pairs, fp64: 4 bodies -- the most a 1024-thread workgroup holds in 128 VGPRs without spilling
-    int           I    = W;
-    while (I * 2 <= kMaxI && static_cast<long>(i_count) / (64L * I * 2) >= cu_count) I *= 2;
+    // Tile layout, S = 16: one workgroup per CU at a time, so its efficiency is the fill of the last round of
+    // workgroups.  Pick the I whose workgroup count quantises best (larger I is ~3 % faster per interaction).
+    int    I        = W;
+    double best_eff = 0.0;
+    for (int cand = W; cand <= kMaxI; cand *= 2) {
+        const long   blocks = (static_cast<long>(i_count) + 64L * cand - 1) / (64L * cand);
+        const long   rounds = (blocks + cu_count - 1) / cu_count;
+        const double eff    = static_cast<double>(blocks) / static_cast<double>(rounds * cu_count) * (cand == kMaxI ? 1.0 : 0.97);
+        if (eff >= best_eff) best_eff = eff, I = cand;
+    }
     int S = 16;
-    // fewer bodies i than one wave per SIMD pair of the tile layout can use: turn to the wave-split layout (S = 64)
-    if (static_cast<long>(i_count) < 64L * W * cu_count) {
+    // The wave-split layout has no such quantisation (its workgroups are 64-256x smaller) but runs at ~0.78 (fp32) /
+    // ~0.62 (fp64) of the tile layout's full rate (tools/layout_crossover.py): take it when the tile layout would
+    // fill the chip worse than that.
+    const double wave_split_eff = sizeof(T) == 4 ? 0.78 : 0.62;
+    if (best_eff < wave_split_eff) {
         S = kWaveSplit;
         I = (static_cast<long>(i_count) / (4 * 2 * W) >= 4L * cu_count) ? 2 * W : W;  // 2 vectors per wave while that leaves >= 4 workgroups per CU
     }
