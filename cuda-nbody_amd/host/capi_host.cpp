@@ -4,6 +4,7 @@
 #include "randomise_bodies.hpp"
 #include "tipsy.hpp"
 
+#include <algorithm>
 #include <cstddef>
 #include <cstdlib>
 #include <cstring>
@@ -32,6 +33,31 @@ NBH_API int nbh_demo_params(std::size_t index, float* out5) {
     const auto& p = Compute::demo_params[index];
     out5[0] = p.time_step, out5[1] = p.cluster_scale, out5[2] = p.velocity_scale, out5[3] = p.softening, out5[4] = p.damping;
     return 0;
+}
+
+// Drives the reference-shaped stack (Compute -> ComputeHIP -> BodySystemHIP*) for the GPU tests: N bodies, `steps32`
+// fp32 steps, switch_precision() to fp64 (compute_cuda.cpp:152-181), `steps64` fp64 steps, switch back.
+// out32_a: fp32 state after the fp32 steps; out64: fp64 state after the fp64 steps; out32_b: fp32 state after switching
+// back (positions then velocities, 4N each).  Returns 0, or -1 on any exception.
+NBH_API int nbh_precision_switch_roundtrip(std::size_t nb_bodies, int hostmem, int steps32, int steps64, float* out32_a, double* out64, float* out32_b) {
+    try {
+        auto compute = Compute(false, false, false, true, hostmem != 0, 256, nb_bodies, {});
+        const auto n4 = 4 * compute.nb_bodies();
+        for (int s = 0; s < steps32; ++s) compute.update_simulation();
+        auto copy = [n4](auto span, auto* dst) { std::copy(span.begin(), span.begin() + static_cast<std::ptrdiff_t>(n4), dst); };
+        copy(compute.positions_fp32(), out32_a);
+        copy(compute.velocities_fp32(), out32_a + n4);
+        compute.switch_precision();
+        if (!compute.fp64_enabled()) return -2;
+        for (int s = 0; s < steps64; ++s) compute.update_simulation();
+        copy(compute.positions_fp64(), out64);
+        copy(compute.velocities_fp64(), out64 + n4);
+        compute.switch_precision();
+        if (compute.fp64_enabled()) return -3;
+        copy(compute.positions_fp32(), out32_b);
+        copy(compute.velocities_fp32(), out32_b + n4);
+        return 0;
+    } catch (...) { return -1; }
 }
 
 // tipsy round trip: returns the padded body count, or -1 on error; fills up to `capacity` bodies

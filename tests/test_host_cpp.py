@@ -32,6 +32,7 @@ def host():
     lib.nbh_read_tipsy.argtypes = [ctypes.c_char_p, f64p, f64p, ctypes.c_size_t]
     lib.nbh_read_tipsy.restype = ctypes.c_long
     lib.nbh_write_tipsy.argtypes = [ctypes.c_char_p, f64p, f64p, ctypes.c_size_t, ctypes.c_int]
+    lib.nbh_precision_switch_roundtrip.argtypes = [ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_int, f32p, f64p, f32p]
     return lib
 
 
@@ -196,3 +197,30 @@ def test_cli_tipsy_and_other_configs(host, tmp_path, oracle):
     # RANDOM / EXPAND start-up configurations run
     for cfg in ("random", "expand"):
         assert run_cli("--numbodies=512", f"--config={cfg}", "--steps=2", f"--dump={tmp_path / cfg}").returncode == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hostmem", [0, 1])
+def test_precision_switch_through_compute(host, oracle, hostmem):
+    """Compute::switch_precision (compute.cpp:123-131, compute_cuda.cpp:152-181): the state crosses fp32 -> fp64 -> fp32
+    through the host exactly (widening is exact; narrowing rounds once), for both storage variants."""
+    n, s32, s64 = 1024, 3, 2
+    a = np.zeros(8 * n, np.float32)
+    d = np.zeros(8 * n, np.float64)
+    b = np.zeros(8 * n, np.float32)
+    f32p, f64p = ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_double)
+    host.nbh_srand(1)
+    rc = host.nbh_precision_switch_roundtrip(n, hostmem, s32, s64, a.ctypes.data_as(f32p), d.ctypes.data_as(f64p), b.ctypes.data_as(f32p))
+    assert rc == 0
+    # fp32 leg == the FAST kernel from the reference's start-up state (tolerance as in test_gpu_parity)
+    ref_p, ref_v = oracle.startup_state(n, np.float32)
+    oracle.update(ref_p, ref_v, np.float32(0.016), steps=s32)
+    np.testing.assert_allclose(a[:4 * n], ref_p, rtol=1e-5, atol=1e-5)
+    # fp64 leg started from exactly the widened fp32 state: re-run it on the oracle
+    p64, v64 = a[:4 * n].astype(np.float64), a[4 * n:].astype(np.float64)
+    oracle.update(p64, v64, np.float32(0.016), steps=s64)
+    np.testing.assert_allclose(d[:4 * n], p64, rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(d[4 * n:], v64, rtol=1e-11, atol=1e-11)
+    # switching back narrows the fp64 state once
+    assert b[:4 * n].tobytes() == d[:4 * n].astype(np.float32).tobytes()
+    assert b[4 * n:].tobytes() == d[4 * n:].astype(np.float32).tobytes()
