@@ -1,7 +1,6 @@
 #include "bodysystemhip.hpp"
 
 #include "integrate_nbody_hip.hpp"
-#include "params.hpp"
 #include "randomise_bodies.hpp"
 
 // ctor chain and softening^2 = T(softening) * T(softening): /root/reference/src/nbody/bodysystemcuda.cpp:42-58

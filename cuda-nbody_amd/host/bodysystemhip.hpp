@@ -2,13 +2,13 @@
 // (/root/reference/src/nbody/bodysystemcuda.hpp:38-72) on HIP: same members, same virtuals, same ping-pong state.
 #pragma once
 
-#include "nbody_config.hpp"
+#include "nbody_types.hpp"
 
 #include <concepts>
 #include <span>
 #include <vector>
 
-struct NBodyParams;
+
 
 template <std::floating_point T> class BodySystemHIP {
  public:

@@ -1,10 +1,8 @@
 #include "compute_hip.hpp"
 
 #include "bodysystemhip.hpp"
-#include "bodysystemhip_default.hpp"
-#include "bodysystemhip_host_memory.hpp"
+#include "bodysystemhip_storage.hpp"
 #include "integrate_nbody_hip.hpp"
-#include "params.hpp"
 #include "text.hpp"
 
 #include <cassert>
@@ -42,10 +40,7 @@ ComputeHIP::ComputeHIP(bool enable_host_mem, int block_size, bool fp64_enabled, 
     if (use_host_mem_ && !device.can_map_host_memory) {
         throw std::invalid_argument(std::string("Device ") + device.name + " cannot map host memory!");
     }
-    // every gfx9 part has native fp64; kept for interface parity with the reference's CC <= 1.2 check (:89-96)
-    if (fp64_enabled_ && !double_supported_) {
-        throw std::invalid_argument("One or more of the requested devices does not support double precision floating-point");
-    }
+    // (the reference refuses --fp64 on CC <= 1.2 parts here, :89-96; every gfx9 GPU has native fp64)
     if (block_size_ <= 0 || block_size_ % 64 != 0 || block_size_ > 1024) {
         throw std::invalid_argument("--blockSize must be a multiple of the 64-lane wavefront, at most 1024");
     }
@@ -75,10 +70,10 @@ ComputeHIP::ComputeHIP(bool enable_host_mem, int block_size, bool fp64_enabled, 
         const auto b = static_cast<unsigned int>(block_size_);
         if (!positions_fp32.empty()) {
             nbody_fp32_ = std::make_unique<System32>(n, b, params, std::move(positions_fp32), std::move(velocities_fp32));
-            if (double_supported_) nbody_fp64_ = std::make_unique<System64>(n, b, params, std::move(positions_fp64), std::move(velocities_fp64));
+            nbody_fp64_ = std::make_unique<System64>(n, b, params, std::move(positions_fp64), std::move(velocities_fp64));
         } else {
             nbody_fp32_ = std::make_unique<System32>(n, b, params);
-            if (double_supported_) nbody_fp64_ = std::make_unique<System64>(n, b, params);
+            nbody_fp64_ = std::make_unique<System64>(n, b, params);
         }
     };
     if (use_host_mem_) {
@@ -90,58 +85,52 @@ ComputeHIP::ComputeHIP(bool enable_host_mem, int block_size, bool fp64_enabled, 
     start_event_.record();
 }
 
-// fp32 <-> fp64 through the host   (:152-181)
-template <std::floating_point TNew, std::floating_point TOld> auto ComputeHIP::switch_precision(BodySystemHIP<TNew>& new_nbody, const BodySystemHIP<TOld>& old_nbody) -> void {
-    static_assert(!std::is_same_v<TNew, TOld>);
+template <typename F> auto ComputeHIP::with_active(F&& f) -> decltype(auto) {
+    if (fp64_enabled_) return f(*nbody_fp64_);
+    return f(*nbody_fp32_);
+}
+
+// The state crosses precisions through the host (compute_cuda.cpp:152-181): widening is exact, narrowing rounds once.
+template <std::floating_point To, std::floating_point From> auto ComputeHIP::convert_state(BodySystemHIP<To>& to, const BodySystemHIP<From>& from) -> void {
+    static_assert(!std::is_same_v<To, From>);
     hip_check(nb_device_synchronize(), "nb_device_synchronize");
-    fp64_enabled_ = std::is_same_v<TNew, double>;
-
-    const auto old_pos = old_nbody.get_position();
-    auto       new_pos = std::vector<TNew>(old_pos.begin(), old_pos.end());
-    const auto old_vel = old_nbody.get_velocity();
-    auto       new_vel = std::vector<TNew>(old_vel.begin(), old_vel.end());
-
-    new_nbody.set_position(new_pos);
-    new_nbody.set_velocity(new_vel);
+    const auto pos = from.get_position();
+    const auto converted_pos = std::vector<To>(pos.begin(), pos.end());
+    const auto vel = from.get_velocity();
+    const auto converted_vel = std::vector<To>(vel.begin(), vel.end());
+    to.set_position(converted_pos);
+    to.set_velocity(converted_vel);
     hip_check(nb_device_synchronize(), "nb_device_synchronize");
 }
 
 auto ComputeHIP::switch_precision() -> void {
-    if (!double_supported_) {
-        std::fprintf(stderr, "WARNING: Attempted to switch precision but double precision is not supported.\n");
-        return;
-    }
     if (fp64_enabled_) {
-        switch_precision(*nbody_fp32_, *nbody_fp64_);
-        std::printf("> Single precision floating point simulation\n");
+        convert_state(*nbody_fp32_, *nbody_fp64_);
     } else {
-        switch_precision(*nbody_fp64_, *nbody_fp32_);
-        std::printf("> Double precision floating point simulation\n");
+        convert_state(*nbody_fp64_, *nbody_fp32_);
     }
+    fp64_enabled_ = !fp64_enabled_;
+    std::printf("> %s precision floating point simulation\n", fp64_enabled_ ? "Double" : "Single");
 }
 
 // one untimed step to prime the device, then K steps between two events   (:183-203)
-template <std::floating_point T> auto ComputeHIP::run_benchmark(int nb_iterations, float dt, BodySystemHIP<T>& nbody) -> Milliseconds {
-    nbody.update(dt);
-    if (use_graph_ && nb_iterations >= 2 && nb_iterations % 2 == 0) {
-        nbody.prepare_many(dt, static_cast<unsigned>(nb_iterations));  // capture + instantiate outside the timed region
+auto ComputeHIP::run_benchmark(int nb_iterations, float dt) -> Milliseconds {
+    return with_active([&](auto& nbody) {
+        nbody.update(dt);
+        if (use_graph_ && nb_iterations >= 2 && nb_iterations % 2 == 0) {
+            nbody.prepare_many(dt, static_cast<unsigned>(nb_iterations));  // capture + instantiate outside the timed region
+            start_event_.record();
+            nbody.update_many(dt, static_cast<unsigned>(nb_iterations));
+            return get_milliseconds_passed();
+        }
         start_event_.record();
-        nbody.update_many(dt, static_cast<unsigned>(nb_iterations));
+        for (int i = 0; i < nb_iterations; ++i) nbody.update(dt);
         return get_milliseconds_passed();
-    }
-    start_event_.record();
-    for (int i = 0; i < nb_iterations; ++i) nbody.update(dt);
-    return get_milliseconds_passed();
+    });
 }
 
-auto ComputeHIP::run_benchmark(int nb_iterations, float dt) -> Milliseconds { return fp64_enabled_ ? run_benchmark(nb_iterations, dt, *nbody_fp64_) : run_benchmark(nb_iterations, dt, *nbody_fp32_); }
-
 auto ComputeHIP::reset(const NBodyParams& params, NBodyConfig config) -> void {
-    if (fp64_enabled_) {
-        nbody_fp64_->reset(params, config);
-    } else {
-        nbody_fp32_->reset(params, config);
-    }
+    with_active([&](auto& nbody) { nbody.reset(params, config); });
 }
 
 auto ComputeHIP::set_values(std::span<const float> positions, std::span<const float> velocities) -> void {
@@ -154,12 +143,8 @@ auto ComputeHIP::set_values(std::span<const double> positions, std::span<const d
 }
 
 auto ComputeHIP::update(float dt) -> void {
-    host_mem_sync_event_.record();
-    if (fp64_enabled_) {
-        nbody_fp64_->update(dt);
-    } else {
-        nbody_fp32_->update(dt);
-    }
+    host_mem_sync_event_.record();  // what a renderer of mapped host memory would wait on (compute_cuda.cpp:237-246,284)
+    with_active([&](auto& nbody) { nbody.update(dt); });
 }
 
 auto ComputeHIP::get_position_fp32() const -> std::span<const float> { return nbody_fp32_->get_position(); }
@@ -168,11 +153,7 @@ auto ComputeHIP::get_velocity_fp32() const -> std::span<const float> { return nb
 auto ComputeHIP::get_velocity_fp64() const -> std::span<const double> { return nbody_fp64_->get_velocity(); }
 
 auto ComputeHIP::update_params(const NBodyParams& params) -> void {
-    if (fp64_enabled_) {
-        nbody_fp64_->update_params(params);
-    } else {
-        nbody_fp32_->update_params(params);
-    }
+    with_active([&](auto& nbody) { nbody.update_params(params); });
 }
 
 // record stop, wait, elapsed, restart   (:263-272)
@@ -224,6 +205,8 @@ template <std::floating_point T> auto ComputeHIP::compare_results(const NBodyPar
     return passed;
 }
 
-auto ComputeHIP::compare_results(const NBodyParams& params) -> bool { return fp64_enabled_ ? compare_results(params, *nbody_fp64_) : compare_results(params, *nbody_fp32_); }
+auto ComputeHIP::compare_results(const NBodyParams& params) -> bool {
+    return with_active([&](auto& nbody) { return compare_results(params, nbody); });
+}
 
 ComputeHIP::~ComputeHIP() noexcept = default;

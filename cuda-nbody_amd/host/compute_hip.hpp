@@ -1,10 +1,13 @@
-// compute_hip.hpp -- GPU facade: device checks, N rounding, storage-variant selection, benchmark timing,
-// precision switch and the self-check.  Mirrors ComputeCUDA (/root/reference/src/nbody/compute_cuda.{hpp,cpp})
-// minus the OpenGL interop variant (display only; an MI355X is a headless accelerator).
+// compute_hip.hpp -- the GPU facade between Compute and the body systems.
+//
+// Same public surface as the reference's ComputeCUDA (/root/reference/src/nbody/compute_cuda.hpp:22-91) -- Compute and
+// anything else written against it keeps compiling -- minus the OpenGL interop variant (display only; an MI355X is
+// a headless accelerator).  It owns one fp32 and one fp64 body system side by side, as the reference does, and
+// routes every call to the one that is active.
 #pragma once
 
 #include "device_array.hpp"
-#include "nbody_config.hpp"
+#include "nbody_types.hpp"
 
 #include <chrono>
 #include <concepts>
@@ -12,54 +15,55 @@
 #include <span>
 #include <vector>
 
-struct NBodyParams;
 template <std::floating_point T> class BodySystemHIP;
 
 class ComputeHIP {
  public:
-    ComputeHIP(bool enable_host_mem, int block_size, bool fp64_enabled, std::size_t num_bodies, const NBodyParams& params);
-    ComputeHIP(bool enable_host_mem, int block_size, bool fp64_enabled, std::size_t num_bodies, const NBodyParams& params, std::vector<float> positions_fp32, std::vector<float> velocities_fp32, std::vector<double> positions_fp64,
-               std::vector<double> velocities_fp64);
+    using Milliseconds = std::chrono::duration<float, std::milli>;
 
+    // ---- construction: device checks, N rounding (or #CUs * 4 * blockSize when N == 0), storage variant ------------
+    ComputeHIP(bool enable_host_mem, int block_size, bool fp64_enabled, std::size_t num_bodies, const NBodyParams& params);
+    ComputeHIP(bool enable_host_mem, int block_size, bool fp64_enabled, std::size_t num_bodies, const NBodyParams& params, std::vector<float> positions_fp32, std::vector<float> velocities_fp32,
+               std::vector<double> positions_fp64, std::vector<double> velocities_fp64);
+    ~ComputeHIP() noexcept;
+
+    // ---- state ---------------------------------------------------------------------------------------------------
     auto nb_bodies() const noexcept { return nb_bodies_; }
     auto use_host_mem() const noexcept { return use_host_mem_; }
     auto fp64_enabled() const noexcept { return fp64_enabled_; }
-
     auto get_position_fp32() const -> std::span<const float>;
     auto get_position_fp64() const -> std::span<const double>;
-    auto get_velocity_fp32() const -> std::span<const float>;
-    auto get_velocity_fp64() const -> std::span<const double>;
+    auto get_velocity_fp32() const -> std::span<const float>;   // extension (the reference exposes positions only)
+    auto get_velocity_fp64() const -> std::span<const double>;  // extension
 
-    auto switch_precision() -> void;
+    // ---- simulation ----------------------------------------------------------------------------------------------
+    auto update(float dt) -> void;
     auto reset(const NBodyParams& params, NBodyConfig config) -> void;
+    auto update_params(const NBodyParams& params) -> void;
     auto set_values(std::span<const float> positions, std::span<const float> velocities) -> void;
     auto set_values(std::span<const double> positions, std::span<const double> velocities) -> void;
-    auto update(float dt) -> void;
-    auto update_params(const NBodyParams& params) -> void;
+    auto switch_precision() -> void;  // fp32 <-> fp64 through the host, compute_cuda.cpp:152-181,205-218
+
+    // ---- measurement ---------------------------------------------------------------------------------------------
+    auto get_milliseconds_passed() -> Milliseconds;                    // since the last call (event pair)
+    auto run_benchmark(int nb_iterations, float dt) -> Milliseconds;   // 1 untimed step, then K between two events
+    auto use_graph(bool enable) noexcept -> void { use_graph_ = enable; }  // extension (--graph): the K steps as one hipGraph
 
     // One dt = 0.001 step of the FAST kernels against the bit-reproducing STRICT kernels started from the SAME
     // pre-step state, |dp| <= 5e-4 per component (the reference's tolerance, compute_cuda.cpp:297-323).
     auto compare_results(const NBodyParams& params) -> bool;
 
-    using Milliseconds = std::chrono::duration<float, std::milli>;
-    auto get_milliseconds_passed() -> Milliseconds;
-    auto run_benchmark(int nb_iterations, float dt) -> Milliseconds;
-    // extension (--graph): issue the timed iterations as one captured hipGraph instead of K launches
-    auto use_graph(bool enable) noexcept -> void { use_graph_ = enable; }
-
-    ~ComputeHIP() noexcept;
-
  private:
-    template <std::floating_point TNew, std::floating_point TOld> auto switch_precision(BodySystemHIP<TNew>& new_nbody, const BodySystemHIP<TOld>& old_nbody) -> void;
-    template <std::floating_point T> auto run_benchmark(int nb_iterations, float dt, BodySystemHIP<T>& nbody) -> Milliseconds;
+    // calls f(system) with the active precision's body system
+    template <typename F> auto with_active(F&& f) -> decltype(auto);
+    template <std::floating_point To, std::floating_point From> auto convert_state(BodySystemHIP<To>& to, const BodySystemHIP<From>& from) -> void;
     template <std::floating_point T> auto compare_results(const NBodyParams& params, BodySystemHIP<T>& nbody) const -> bool;
 
     std::size_t nb_bodies_ = 0;
     int         block_size_;
     bool        fp64_enabled_;
     bool        use_host_mem_;
-    bool        double_supported_ = true;
-    bool        use_graph_        = false;
+    bool        use_graph_ = false;
 
     std::unique_ptr<BodySystemHIP<float>>  nbody_fp32_;
     std::unique_ptr<BodySystemHIP<double>> nbody_fp64_;

@@ -4,7 +4,7 @@
 // same libc rand() state.
 #pragma once
 
-#include "nbody_config.hpp"
+#include "nbody_types.hpp"
 
 #include <concepts>
 #include <span>
