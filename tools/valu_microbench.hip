@@ -30,6 +30,10 @@ template <int KIND> __global__ __launch_bounds__(256) void bench(float* out, flo
         a[i] = seed + threadIdx.x * 1e-3f + i;
         p[i] = make_float2(a[i], a[i] + 0.5f);
     }
+    double dd[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) dd[i] = seed + i + threadIdx.x * 1e-3;
+    double db = seed * 0.999, dc = seed * 1e-3;
     float  b = seed * 0.999f, c = seed * 1e-3f;
     float2 pb = make_float2(b, b), pc = make_float2(c, c);
     for (int it = 0; it < ITERS; ++it) {
@@ -123,11 +127,27 @@ template <int KIND> __global__ __launch_bounds__(256) void bench(float* out, flo
 #define OP(i) asm volatile("v_mov_b32 %0, %1" : "=v"(a[i]) : "v"(b));
             REP16(OP)
 #undef OP
+        } else if constexpr (KIND == 19) {  // v_fma_f64
+#define OP(i) asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(dd[i]) : "v"(db), "v"(dc));
+            REP16(OP)
+#undef OP
+        } else if constexpr (KIND == 20) {  // v_mul_f64
+#define OP(i) asm volatile("v_mul_f64 %0, %0, %1" : "+v"(dd[i]) : "v"(db));
+            REP16(OP)
+#undef OP
+        } else if constexpr (KIND == 21) {  // v_add_f64
+#define OP(i) asm volatile("v_add_f64 %0, %0, %1" : "+v"(dd[i]) : "v"(dc));
+            REP16(OP)
+#undef OP
+        } else if constexpr (KIND == 22) {  // v_rsq_f64
+#define OP(i) asm volatile("v_rsq_f64 %0, %0" : "+v"(dd[i]));
+            REP16(OP)
+#undef OP
         }
     }
     float s = 0;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) s += a[i] + p[i].x + p[i].y;
+    for (int i = 0; i < 16; ++i) s += a[i] + p[i].x + p[i].y + (float)dd[i];
     if (s == 123.456f) out[0] = s;
 }
 
@@ -154,6 +174,8 @@ int main(int argc, char** argv) {
         {"v_fma_f32 1src", bench<10>, 16, 2},  {"v_pk_fma 1src", bench<11>, 16, 4},    {"v_pk_fma d,x,x,d", bench<12>, 16, 4},
         {"v_pk_mul d,x,x", bench<13>, 16, 2},  {"v_pk_add bcast+neg", bench<14>, 16, 2}, {"v_fmac_f32 vop2", bench<15>, 16, 2},
         {"v_pk_fma a+=x*s", bench<16>, 16, 4}, {"v_add_f32 1src", bench<17>, 16, 1},    {"v_mov_b32", bench<18>, 16, 0},
+        {"v_fma_f64", bench<19>, 16, 2},       {"v_mul_f64", bench<20>, 16, 1},         {"v_add_f64", bench<21>, 16, 1},
+        {"v_rsq_f64", bench<22>, 16, 1},
     };
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0));
