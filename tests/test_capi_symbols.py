@@ -50,3 +50,35 @@ def test_strict_translation_unit_has_no_fused_multiply_add():
     assert "-ffp-contract=off" in rule
     fast_rule = re.search(r"nbody_fast\.o:.*?\n\t(.*)\n", mk).group(1)
     assert "-ffp-contract=off" not in fast_rule
+
+
+def test_launch_plan_heuristics_without_gpu(pkg):
+    """nb_plan_* is pure host logic (256 CUs assumed when no device is visible): the geometry each BASELINE size and
+    each multi-GPU shard of 262 144 bodies gets."""
+    import numpy as np
+
+    def plan(i, j, dtype=np.float32):
+        p = pkg.plan(i, j, dtype)
+        return p.bodies_per_lane, p.lanes_per_body, p.tile_bodies, p.block_threads, p.grid_blocks
+
+    # full-size fp32 systems: 16 wave-groups per 1024-thread workgroup, 4 bodies (2 packed pairs) per lane
+    assert plan(262144, 262144) == (4, 16, 2048, 1024, 1024)
+    assert plan(65536, 65536) == (4, 16, 2048, 1024, 256)
+    assert plan(1048576, 1048576) == (4, 16, 2048, 1024, 4096)
+    # strong-scaling shards of 262 144 bodies on 2 / 4 / 8 GPUs keep whole rounds of 256 workgroups
+    assert plan(131072, 262144)[:2] + plan(131072, 262144)[4:] == (4, 16, 512)
+    assert plan(65536, 262144)[:2] + plan(65536, 262144)[4:] == (4, 16, 256)
+    assert plan(32768, 262144)[:2] + plan(32768, 262144)[4:] == (2, 16, 256)
+    # small or awkward sizes: wave-split layout (lanes_per_body == 64), 256-thread workgroups
+    for n in (1, 1024, 4096, 16384, 40960):
+        assert plan(n, n)[1] == 64 and plan(n, n)[3] == 256, n
+    # fp64: one body per vector, up to 4 per lane
+    assert plan(262144, 262144, np.float64) == (4, 16, 1024, 1024, 1024)
+    assert plan(1024, 1024, np.float64)[1] == 64
+    # overrides are validated and reversible
+    pkg.set_plan_override(2, 4, 512)
+    try:
+        assert plan(262144, 262144)[:4] == (2, 4, 512, 256)
+    finally:
+        pkg.set_plan_override(0, 0, 0)
+    assert plan(262144, 262144)[1] == 16
