@@ -351,3 +351,28 @@ def test_graph_replay_equals_eager_steps(gpu, oracle, dtype, mode_name):
     assert lib.nb_graph_create_f32(ctypes.byref(g), graph._pos[0].ptr, graph._pos[1].ptr, graph._vel.ptr, 0.016, 1.0, n, 256, mode, 3) == 10001  # odd
     assert lib.nb_graph_create_f32(ctypes.byref(g), graph._pos[0].ptr, graph._pos[0].ptr, graph._vel.ptr, 0.016, 1.0, n, 256, mode, 2) == 10001  # aliasing
     eager.free(), graph.free()
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_strict_bitwise_on_extreme_values(gpu, oracle, dtype):
+    """Masses and coordinates over many decades, tiny softening, denormal-range products: the IEEE divide / sqrt
+    expansions and the denormal mode of the STRICT kernels must still match the CPU's arithmetic bit for bit
+    (NaN/inf patterns included)."""
+    rng = np.random.default_rng(2024)
+    n = 777
+    decades = 12 if dtype == np.float32 else 60
+    pos = np.zeros((n, 4), dtype=dtype)
+    pos[:, :3] = (rng.choice([-1.0, 1.0], (n, 3)) * 10.0 ** rng.uniform(-decades, 3, (n, 3))).astype(dtype)
+    pos[:, 3] = (10.0 ** rng.uniform(-decades - 8, decades, n)).astype(dtype)
+    pos[::50, 3] = 0              # zero-mass bodies
+    pos[1::97, :3] = pos[0, :3]   # coincident bodies (distance exactly 0, only the softening separates them)
+    vel = np.zeros((n, 4), dtype=dtype)
+    vel[:, :3] = (rng.standard_normal((n, 3)) * 10.0 ** rng.uniform(-6, 2, (n, 1))).astype(dtype)
+    pos0, vel0 = pos.reshape(-1).copy(), vel.reshape(-1).copy()
+    params = gpu.NBodyParams(softening=1e-3, damping=0.999)
+    ref_pos, ref_vel = pos0.copy(), vel0.copy()
+    with np.errstate(all="ignore"):
+        oracle.update(ref_pos, ref_vel, np.float32(0.016), steps=2, softening=1e-3, damping=0.999)
+    got_pos, got_vel = run_gpu(gpu, pos0, vel0, 2, gpu.NB_MODE_STRICT, params=params)
+    assert got_pos.tobytes() == ref_pos.tobytes()
+    assert got_vel.tobytes() == ref_vel.tobytes()
