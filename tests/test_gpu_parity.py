@@ -376,3 +376,61 @@ def test_strict_bitwise_on_extreme_values(gpu, oracle, dtype):
     got_pos, got_vel = run_gpu(gpu, pos0, vel0, 2, gpu.NB_MODE_STRICT, params=params)
     assert got_pos.tobytes() == ref_pos.tobytes()
     assert got_vel.tobytes() == ref_vel.tobytes()
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("config", [0, 2])
+def test_strict_other_start_configurations(gpu, oracle, dtype, config):
+    """RANDOM and EXPAND start-up configurations (keys 2/3 of the reference's viewer), demo parameter set 5
+    (dt 0.0016, softening 0.145): STRICT stays bit-identical."""
+    n = 1280
+    oracle.srand(5)
+    pos0, vel0 = oracle.randomise(config, n, 0.32, 272.0, dtype)
+    params = gpu.NBodyParams(time_step=0.0016, softening=0.145, damping=1.0)
+    ref_pos, ref_vel = pos0.copy(), vel0.copy()
+    oracle.update(ref_pos, ref_vel, np.float32(0.0016), steps=5, softening=0.145)
+    pos, vel = run_gpu(gpu, pos0, vel0, 5, gpu.NB_MODE_STRICT, dt=np.float32(0.0016), params=params)
+    assert pos.tobytes() == ref_pos.tobytes() and vel.tobytes() == ref_vel.tobytes()
+
+
+def test_strict_long_horizon_bitwise(gpu, oracle):
+    """1 000 steps at N = 256: chaos amplifies any 1-ulp slip to O(1), so equality here is a strong statement."""
+    n = 256
+    pos0, vel0 = oracle.startup_state(n, np.float32)
+    ref_pos, ref_vel = pos0.copy(), vel0.copy()
+    oracle.update(ref_pos, ref_vel, DT, steps=1000, avx=True)
+    system = gpu.BodySystemHIP(n, 256, gpu.NBodyParams(), np.float32, pos0, vel0, mode=gpu.NB_MODE_STRICT)
+    system.update_many(DT, 1000)  # one hipGraph of 1 000 launches
+    assert system.get_position().tobytes() == ref_pos.tobytes()
+    assert system.get_velocity().tobytes() == ref_vel.tobytes()
+    system.free()
+
+
+def test_fast_conserves_what_the_cpu_path_conserves(gpu, oracle):
+    """100 steps at N = 1024 (BASELINE configs[0]): total momentum and energy drift of the FAST trajectory are no worse
+    than the CPU path's own (the trajectories themselves diverge chaotically, SURVEY 7 hard part 1)."""
+    n, steps = 1024, 100
+    g = load_golden(n, "f32")
+    pos0, vel0 = g["pos_0"], g["vel_0"]
+    fast_pos, fast_vel = run_gpu(gpu, pos0, vel0, steps, gpu.NB_MODE_FAST)
+    cpu_pos, cpu_vel = g["pos_100"], g["vel_100"]
+
+    def momentum(pos, vel):
+        return (pos.reshape(n, 4)[:, 3:4].astype(np.float64) * xyz(vel).astype(np.float64)).sum(axis=0)
+
+    def energy(pos, vel):
+        p, m = xyz(pos).astype(np.float64), pos.reshape(n, 4)[:, 3].astype(np.float64)
+        kin = 0.5 * (m * (xyz(vel).astype(np.float64) ** 2).sum(axis=1)).sum()
+        d = p[:, None, :] - p[None, :, :]
+        r = np.sqrt((d * d).sum(axis=2) + 0.1 ** 2)
+        pot = -0.5 * ((m[:, None] * m[None, :]) / r).sum()
+        return kin + pot
+
+    p0, e0 = momentum(pos0, vel0), energy(pos0, vel0)
+    scale_p = (np.abs(xyz(vel0)).astype(np.float64) * pos0.reshape(n, 4)[:, 3:4]).sum()
+    drift_fast = np.abs(momentum(fast_pos, fast_vel) - p0).max() / scale_p
+    drift_cpu = np.abs(momentum(cpu_pos, cpu_vel) - p0).max() / scale_p
+    assert drift_fast <= max(2 * drift_cpu, 1e-6), (drift_fast, drift_cpu)
+    de_fast = abs(energy(fast_pos, fast_vel) - e0) / abs(e0)
+    de_cpu = abs(energy(cpu_pos, cpu_vel) - e0) / abs(e0)
+    assert de_fast <= max(1.5 * de_cpu, 1e-4), (de_fast, de_cpu)
