@@ -270,7 +270,8 @@ class BodySystemHIP:
 
     def update_many(self, delta_time, steps: int, stream=None) -> None:
         """`steps` (even) updates as ONE hipGraph launch (nb_graph_*): same kernels, same results as `steps` x update()."""
-        key = (float(delta_time), steps, self.current_read, self.mode)
+        # everything nb_graph_create_* bakes into the capture (damping and softening^2 are kernel arguments too)
+        key = (float(delta_time), steps, self.current_read, self.mode, float(self.damping), float(self._softening_sq))
         if getattr(self, "_graph_key", None) != key:
             self._free_graph()
             self._apply_softening()

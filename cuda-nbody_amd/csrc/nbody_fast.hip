@@ -2,22 +2,26 @@
 //
 // What it computes is the reference kernel's bodyBodyInteraction / computeBodyAccel / integrateBodies
 // (/root/reference/src/nbody/bodysystemcuda.cu:98-184); how it is laid out is MI355X-first and follows
-// what tools/valu_microbench.hip measured on the chip (profiles/round1_valu_microbench.txt):
+// what the microbenchmarks measured on the chip (profiles/round1_valu_microbench.txt, profiles/round2_loop_microbench.txt):
 //
 //   * The loop is VALU-issue bound: no MFMA (a 3-vector accumulate is not a contraction), HBM traffic is
-//     64 B per body per step.  On gfx950 the PACKED fp32 ops (v_pk_add/mul/fma_f32) deliver 1.2-1.4x the
-//     lane-throughput of their scalar forms, and v_rsq_f32 costs ~2.6 FMA slots.  So for fp32 each lane
-//     carries its bodies i in PAIRS, one pair per 64-bit VGPR pair: an interaction pair is
-//     3 v_pk_add + 6 v_pk_fma + 3 v_pk_mul + 2 v_rsq_f32 (14 issue slots for 2 interactions instead of 26),
+//     64 B per body per step.  A packed fp32 op (v_pk_add/mul/fma_f32) issues in 4.1 cycles per wave64 on a SIMD with 4
+//     resident waves and does two lanes' worth of work; v_rsq_f32 costs 8.4.  So for fp32 each lane carries its bodies i
+//     in PAIRS, one pair per 64-bit VGPR pair: an interaction pair is 3 v_pk_add + 6 v_pk_fma + 2-3 v_pk_mul + 2 v_rsq_f32,
 //     the j body's x/y/z/m being broadcast into both halves with op_sel, not moved.
 //     fp64 has no packed form: one body per "vector"; m*d2^(-3/2) from the v_rsq_f64 seed by a 2-term series (Lane<double>::coupling).
-//   * Tile layout (large shards): each lane register-tiles R vectors (I = R*W bodies i, W = 2 fp32 / 1 fp64), so
-//     one broadcast ds_read_b128 of a body j feeds I interactions.  j bodies stream HBM/L2 -> registers -> LDS in
-//     tiles of TILE = block*LPT bodies (coalesced 16 B/lane global_load_dwordx4), double-buffered: tile t+1 is in
-//     flight in registers while tile t is consumed from LDS; ONE barrier per tile.
-//   * j-split: the S wave groups of a workgroup (L = block/S lanes each, whole waves) walk disjoint 1/S slices of
-//     every tile for the SAME bodies i and are folded through LDS in a fixed order at the end (deterministic).
-//     Production geometry is S = 16: a 1024-thread workgroup = 4 waves on every SIMD of its CU (plan_fast below).
+//   * Wave-stream layout (large shards): each lane register-tiles R vectors (I = R*W bodies i, W = 2 fp32 / 1 fp64), so
+//     one broadcast ds_read_b128 of a body j feeds I interactions.  The S waves of a workgroup own the SAME 64*I bodies i
+//     and split the bodies j: wave w streams chunks w, w+S, w+2S, ... of CH = 64*LPT consecutive bodies, each through its
+//     OWN double-buffered LDS ring (coalesced 16 B/lane global_load_dwordx4 -> registers -> ds_write_b128 -> broadcast
+//     ds_read_b128).  Because a wave reads only what it wrote itself there is NO workgroup barrier in the main loop: the
+//     waves of a SIMD drift apart freely and keep its VALU issuing (a per-tile s_barrier cost 3-4 % at 4 waves/SIMD,
+//     where one wave alone can only issue every 8th cycle).  The S partial sums are folded through LDS in a fixed
+//     order at the end (deterministic).
+//   * Mass factorisation: sums are accumulated in units of m_ref (the mass of the first body j of the range): the ring
+//     holds m_j/m_ref, and a chunk whose 64*LPT bodies ALL have mass m_ref -- every chunk of an equal-mass system such
+//     as the reference's start-up configurations -- takes a loop without the mass multiply (one v_pk_mul fewer of 12,
+//     and no mass moves: -8 % loop time).  With m_ref = 1 both forms are bit-identical to the plain one.
 //   * Wave-split layout (small shards, fewer bodies i than lanes on the chip): a wave owns the bodies i, its 64
 //     lanes split j, wavefront-64 butterfly fold at the end (integrate_bodies_wavesplit below).
 //   * softening^2 lives in VGPRs: a VALU op with an SGPR source issues ~35 % slower on this chip.
@@ -29,12 +33,13 @@
 #include "nbody_kernels.h"
 
 #include <algorithm>
+#include <atomic>
 
 namespace nb {
 namespace {
 
-// workgroup size by j-split factor: S <= 4 -> 256 threads, S = 8 -> 512, S = 16 -> 1024 (a lane group stays >= one wave)
-constexpr int block_threads_for(int S) { return S <= 4 ? 256 : 64 * S; }
+// workgroup size by j-split factor: S waves (S = 4, 8, 16 -> 256, 512, 1024 threads)
+constexpr int block_threads_for(int S) { return 64 * S; }
 // lanes_per_body value that selects the wave-split layout (all 64 lanes of a wave split j for the wave's bodies i)
 constexpr int kWaveSplit = 64;
 
@@ -49,10 +54,12 @@ template <> struct Lane<float> {
     static constexpr int W     = 2;
     static __device__ __forceinline__ vec  splat(float a) { return vec{a, a}; }
     static __device__ __forceinline__ vec  fma(vec a, vec b, vec c) { return __builtin_elementwise_fma(a, b, c); }
-    // s = m * d2^(-3/2): 2 x v_rsq_f32 (1 ulp, what the reference's rsqrtf is) + 3 v_pk_mul_f32   (bodysystemcuda.cu:110-115)
-    static __device__ __forceinline__ vec coupling(vec m, vec d2) {
+    // s = m * d2^(-3/2): 2 x v_rsq_f32 (1 ulp, what the reference's rsqrtf is) + 3 v_pk_mul_f32   (bodysystemcuda.cu:110-115);
+    // UNIT: the body's relative mass is 1 -> 2 v_pk_mul_f32
+    template <bool UNIT> static __device__ __forceinline__ vec coupling(vec m, vec d2) {
         const vec inv  = vec{__builtin_amdgcn_rsqf(d2.x), __builtin_amdgcn_rsqf(d2.y)};
         const vec inv2 = inv * inv;
+        if constexpr (UNIT) return inv * inv2;
         return (m * inv) * inv2;
     }
     static __device__ __forceinline__ float get(vec a, int w) { return w == 0 ? a.x : a.y; }
@@ -71,12 +78,13 @@ template <> struct Lane<double> {
     // s = m * d2^(-3/2) in full double precision from the v_rsq_f64 seed y0 (relative error <= 2^-23) WITHOUT
     // iterating on y: with r = 1 - d2*y0^2 (|r| <= 2^-22),  d2^(-3/2) = y0^3 (1-r)^(-3/2) = y0^3 (1 + 3/2 r + 15/8 r^2 + O(r^3)),
     // truncation 35/16 r^3 < 2^-64.  7 DP ops + the seed, against 10 for two Newton steps on y followed by the cube
-    // (the reference calls CUDA's <= 1 ulp rsqrt(double) here, bodysystemcuda.cu:82-84,110-115).
-    static __device__ __forceinline__ vec coupling(vec m, vec d2) {
+    // (the reference calls CUDA's <= 1 ulp rsqrt(double) here, bodysystemcuda.cu:82-84,110-115).  UNIT: 6 DP ops.
+    template <bool UNIT> static __device__ __forceinline__ vec coupling(vec m, vec d2) {
         const double y0 = __builtin_amdgcn_rsq(d2);
         const double t0 = y0 * y0;
         const double r  = __builtin_fma(-d2, t0, 1.0);
-        const double mc = m * (y0 * t0);
+        double       mc = y0 * t0;
+        if constexpr (!UNIT) mc = m * mc;
         const double w  = r * __builtin_fma(r, 1.875, 1.5);
         return __builtin_fma(mc, w, mc);
     }
@@ -86,7 +94,8 @@ template <> struct Lane<double> {
 };
 
 // bodyBodyInteraction, bodysystemcuda.cu:98-123, for one body j against the R vectors of bodies i of this lane.
-template <typename T, int R>
+// bj.w is the body's mass relative to the range's reference mass; UNIT: it is exactly 1 and never read.
+template <typename T, int R, bool UNIT>
 __device__ __forceinline__ void interact(const typename Lane<T>::vec4 bj, const typename Lane<T>::vec (&px)[R], const typename Lane<T>::vec (&py)[R], const typename Lane<T>::vec (&pz)[R], typename Lane<T>::vec (&ax)[R],
                                          typename Lane<T>::vec (&ay)[R], typename Lane<T>::vec (&az)[R], const typename Lane<T>::vec eps2) {
     using L   = Lane<T>;
@@ -100,48 +109,60 @@ __device__ __forceinline__ void interact(const typename Lane<T>::vec4 bj, const 
         vec       d2   = L::fma(dx, dx, eps2);
         d2             = L::fma(dy, dy, d2);
         d2             = L::fma(dz, dz, d2);
-        const vec s    = L::coupling(bm, d2);
+        const vec s    = L::template coupling<UNIT>(bm, d2);
         ax[r]          = L::fma(dx, s, ax[r]);
         ay[r]          = L::fma(dy, s, ay[r]);
         az[r]          = L::fma(dz, s, az[r]);
     }
 }
 
-// T: float|double   R: vectors per lane (I = R*W bodies i)   S: lane groups splitting j   LPT: vec4 loads per thread per tile
-template <typename T, int R, int S, int LPT> __global__ __launch_bounds__(block_threads_for(S)) void integrate_bodies_fast(Shard<T> s) {
-    constexpr int kBlock = block_threads_for(S);
+// The mass every sum of a j range is expressed in units of: the first body's, when 1/m is a well-behaved number
+// (then an equal-mass range never multiplies by a mass inside the loop), otherwise 1.
+template <typename T> __device__ __forceinline__ T reference_mass(const Shard<T>& s) {
+    if (s.j_count == 0) return T(1);
+    const T m = s.old_pos[4 * static_cast<size_t>(s.j_begin) + 3];
+    const T a = m < 0 ? -m : m;
+    return (a >= T(0x1p-60) && a <= T(0x1p60)) ? m : T(1);  // false for NaN too
+}
+
+// A wave's LDS traffic is ordered (one queue per CU, in issue order), so data a wave writes for ITSELF needs no
+// s_barrier: wait for the writes to land and keep the compiler from moving LDS accesses across this point.
+__device__ __forceinline__ void wave_lds_sync() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// T: float|double   R: vectors per lane (I = R*W bodies i)   S: waves splitting j   LPT: vec4 loads per lane per chunk
+template <typename T, int R, int S, int LPT> __global__ __launch_bounds__(block_threads_for(S), 4) void integrate_bodies_fast(Shard<T> s) {
     using LT            = Lane<T>;
     using vec4          = typename LT::vec4;
     using vec           = typename LT::vec;
     constexpr int W     = LT::W;
-    constexpr int I     = R * W;         // bodies i per lane
-    constexpr int TILE  = kBlock * LPT;  // bodies j per LDS tile
-    constexpr int L     = kBlock / S;    // lanes per group
-    constexpr int SLICE = TILE / S;      // bodies j per group per tile
-    constexpr int BODIES_PER_BLOCK = L * I;
-    static_assert(L % 64 == 0, "a lane group must be whole waves so the LDS read stays a broadcast");
+    constexpr int I     = R * W;     // bodies i per lane
+    constexpr int CH    = 64 * LPT;  // bodies j per wave per chunk
+    constexpr int BODIES_PER_BLOCK = 64 * I;
     // j bodies in flight per lane: 8 independent interaction chains (R vectors x U bodies j) hide the VALU latency.
-    // The 512/1024-thread workgroups are capped at 128 VGPRs (4 waves/SIMD), so with R >= 2 they unroll less instead
-    // of spilling (an R = 4 body at U = 8 spilled 1.2 KB/lane to scratch: 1.2 GB of HBM writes per launch).
-    constexpr int U = (kBlock >= 512 && R >= 2) ? 8 / R : 8;
-    static_assert(SLICE % U == 0, "inner loop is unrolled by U");
+    // Every geometry is capped at 128 VGPRs (4 waves/SIMD: 16 waves per CU in 1, 2 or 4 workgroups), so with R >= 2 the
+    // loop unrolls less instead of spilling (an R = 4 body at U = 8 spilled 1.2 KB/lane to scratch: 1.2 GB of HBM writes per launch).
+    constexpr int U = R >= 2 ? 8 / R : 8;
+    static_assert(CH % U == 0, "inner loop is unrolled by U");
 
     extern __shared__ __attribute__((aligned(32))) unsigned char smem_raw[];
-    vec4* tile = reinterpret_cast<vec4*>(smem_raw);  // [2][TILE]
 
     const vec4* __restrict__ old_pos = reinterpret_cast<const vec4*>(s.old_pos);
-    const int tid   = threadIdx.x;
-    const int group = tid / L;
-    const int lane  = tid - group * L;
+    const int tid  = threadIdx.x;
+    const int wave = tid >> 6;
+    const int lane = tid & 63;
+    vec4* ring = reinterpret_cast<vec4*>(smem_raw) + wave * (2 * CH);  // this wave's [2][CH]
 
-    // bodies i of this lane: block_base + k*L + lane, k = r*W + w  (coalesced across the lanes of a group)
+    // bodies i of this lane: block_base + k*64 + lane, k = r*W + w  (coalesced across the lanes of a wave)
     const unsigned block_base = blockIdx.x * BODIES_PER_BLOCK;
     vec      px[R], py[R], pz[R], ax[R], ay[R], az[R];
     unsigned idx[I];
     bool     active[I];
 #pragma unroll
     for (int k = 0; k < I; ++k) {
-        const unsigned local = block_base + k * L + lane;
+        const unsigned local = block_base + k * 64 + lane;
         active[k]            = local < s.i_count;
         idx[k]               = s.i_begin + (active[k] ? local : s.i_count - 1);
         const vec4 p         = old_pos[idx[k]];
@@ -149,91 +170,125 @@ template <typename T, int R, int S, int LPT> __global__ __launch_bounds__(block_
         LT::set(py[k / W], k % W, p.y);
         LT::set(pz[k / W], k % W, p.z);
     }
+    const T m_ref    = reference_mass(s);
+    const T inv_mref = T(1) / m_ref;
 #pragma unroll
     for (int r = 0; r < R; ++r) ax[r] = ay[r] = az[r] = LT::splat(0);
-    if (s.acc_in && group == 0) {
+    if (s.acc_in && wave == 0) {
 #pragma unroll
         for (int k = 0; k < I; ++k) {
             const vec4 a = reinterpret_cast<const vec4*>(s.acc)[idx[k]];
-            LT::set(ax[k / W], k % W, a.x);
-            LT::set(ay[k / W], k % W, a.y);
-            LT::set(az[k / W], k % W, a.z);
+            LT::set(ax[k / W], k % W, a.x * inv_mref);
+            LT::set(ay[k / W], k % W, a.y * inv_mref);
+            LT::set(az[k / W], k % W, a.z * inv_mref);
         }
     }
     vec eps2 = LT::splat(s.eps2);
     LT::keep_in_vgpr(eps2);
 
-    const unsigned j_end   = s.j_begin + s.j_count;
-    const unsigned n_tiles = (s.j_count + TILE - 1) / TILE;
+    const unsigned j_end    = s.j_begin + s.j_count;
+    const unsigned n_chunks = (s.j_count + CH - 1) / CH;
 
-    // out-of-range j slots become zero-mass bodies at the origin: they add exactly 0 (eps2 > 0)
-    auto load_tile = [&](unsigned t, vec4 (&regs)[LPT]) {
+    // Out-of-range slots become zero-mass bodies at the origin: they add exactly 0 (eps2 > 0).
+    auto load_chunk = [&](unsigned c, vec4 (&regs)[LPT]) {
 #pragma unroll
         for (int r = 0; r < LPT; ++r) {
-            const unsigned j = s.j_begin + t * TILE + r * kBlock + tid;
+            const unsigned j = s.j_begin + c * CH + r * 64 + lane;
             vec4           v;
             v.x = v.y = v.z = v.w = 0;
             if (j < j_end) v = old_pos[j];
             regs[r] = v;
         }
     };
-    auto store_tile = [&](int buf, const vec4 (&regs)[LPT]) {
+    // Stores the chunk with masses relative to m_ref; returns whether EVERY body of it has the reference mass
+    // (wave-uniform; a chunk with out-of-range slots is a mixed one).
+    auto store_chunk = [&](int buf, const vec4 (&regs)[LPT]) -> bool {
+        bool same = true;
 #pragma unroll
-        for (int r = 0; r < LPT; ++r) tile[buf * TILE + r * kBlock + tid] = regs[r];
+        for (int r = 0; r < LPT; ++r) {
+            vec4 v = regs[r];
+            same   = same && (v.w == m_ref);
+            v.w    = v.w * inv_mref;
+            ring[buf * CH + r * 64 + lane] = v;
+        }
+        return __builtin_amdgcn_ballot_w64(!same) == 0;
     };
 
-    vec4 regs[LPT];
-    load_tile(0, regs);
-    store_tile(0, regs);
-    __syncthreads();
+    vec4     regs[LPT];
+    unsigned c    = wave;  // wave w streams chunks w, w+S, w+2S, ...
+    bool     unit = false;
+    if (c < n_chunks) {
+        load_chunk(c, regs);
+        unit = store_chunk(0, regs);
+    }
+    wave_lds_sync();
 
-    for (unsigned t = 0; t < n_tiles; ++t) {
-        const int  cur       = t & 1;
-        const bool have_next = (t + 1) < n_tiles;
-        if (have_next) load_tile(t + 1, regs);  // global loads in flight across the compute below
+    // The SIMD arbiter favours its oldest wave heavily (in isolation the four waves of a SIMD ran this loop at rates
+    // 3.5 : ... : 1), so equal shares of work finish at very different times and the SIMD runs under-filled (one wave
+    // alone issues only every 8th cycle) until the workgroup's last wave is done.  Rotating a static priority with the
+    // chunk counter gives each of the four SIMD mates (waves w, w+4, w+8, w+12) the top slot a quarter of the time.
+    unsigned turn = static_cast<unsigned>(wave >> 2) + (S < 16 ? blockIdx.x * (S / 4) : 0u);
 
-        const vec4* __restrict__ slice = tile + cur * TILE + group * SLICE;
+    int cur = 0;
+    for (; c < n_chunks; c += S) {
+        const bool have_next = (c + S) < n_chunks;
+        if (have_next) load_chunk(c + S, regs);  // global loads in flight across the compute below
+        switch (turn++ & 3u) {
+            case 0: __builtin_amdgcn_s_setprio(0); break;
+            case 1: __builtin_amdgcn_s_setprio(1); break;
+            case 2: __builtin_amdgcn_s_setprio(2); break;
+            default: __builtin_amdgcn_s_setprio(3); break;
+        }
+
+        const vec4* __restrict__ chunk = ring + cur * CH;
+        if (unit) {
 #pragma unroll 1
-        for (int jj = 0; jj < SLICE; jj += U) {
+            for (int jj = 0; jj < CH; jj += U) {
 #pragma unroll
-            for (int u = 0; u < U; ++u) interact<T, R>(slice[jj + u], px, py, pz, ax, ay, az, eps2);
-        }
-
-        if (have_next) store_tile(cur ^ 1, regs);
-        __syncthreads();
-    }
-
-    // fold the S partial sums (groups 1..S-1 -> group 0) through LDS, fixed order
-    if constexpr (S > 1) {
-        T* red = reinterpret_cast<T*>(smem_raw);  // [(S-1)][3][I][L]; the tiles are dead after the last barrier
-        if (group > 0) {
+                for (int u = 0; u < U; ++u) interact<T, R, true>(chunk[jj + u], px, py, pz, ax, ay, az, eps2);
+            }
+        } else {
+#pragma unroll 1
+            for (int jj = 0; jj < CH; jj += U) {
 #pragma unroll
-            for (int k = 0; k < I; ++k) {
-                red[(((group - 1) * 3 + 0) * I + k) * L + lane] = LT::get(ax[k / W], k % W);
-                red[(((group - 1) * 3 + 1) * I + k) * L + lane] = LT::get(ay[k / W], k % W);
-                red[(((group - 1) * 3 + 2) * I + k) * L + lane] = LT::get(az[k / W], k % W);
+                for (int u = 0; u < U; ++u) interact<T, R, false>(chunk[jj + u], px, py, pz, ax, ay, az, eps2);
             }
         }
-        __syncthreads();
-        if (group == 0) {
+
+        if (have_next) unit = store_chunk(cur ^ 1, regs);
+        wave_lds_sync();
+        cur ^= 1;
+    }
+    __builtin_amdgcn_s_setprio(0);
+
+    // fold the S partial sums (waves 1..S-1 -> wave 0) through LDS, fixed order
+    T* red = reinterpret_cast<T*>(smem_raw);  // [(S-1)][3][I][64]; overlays the rings, hence the barrier: every wave is done streaming
+    __syncthreads();
+    if (wave > 0) {
+#pragma unroll
+        for (int k = 0; k < I; ++k) {
+            red[(((wave - 1) * 3 + 0) * I + k) * 64 + lane] = LT::get(ax[k / W], k % W);
+            red[(((wave - 1) * 3 + 1) * I + k) * 64 + lane] = LT::get(ay[k / W], k % W);
+            red[(((wave - 1) * 3 + 2) * I + k) * 64 + lane] = LT::get(az[k / W], k % W);
+        }
+    }
+    __syncthreads();
+    if (wave != 0) return;
 #pragma unroll 1  // (fully unrolled, the S = 16 fold hoists 45*I LDS loads and spills)
-            for (int g = 1; g < S; ++g) {
+    for (int g = 1; g < S; ++g) {
 #pragma unroll
-                for (int k = 0; k < I; ++k) {
-                    LT::set(ax[k / W], k % W, LT::get(ax[k / W], k % W) + red[(((g - 1) * 3 + 0) * I + k) * L + lane]);
-                    LT::set(ay[k / W], k % W, LT::get(ay[k / W], k % W) + red[(((g - 1) * 3 + 1) * I + k) * L + lane]);
-                    LT::set(az[k / W], k % W, LT::get(az[k / W], k % W) + red[(((g - 1) * 3 + 2) * I + k) * L + lane]);
-                }
-            }
+        for (int k = 0; k < I; ++k) {
+            LT::set(ax[k / W], k % W, LT::get(ax[k / W], k % W) + red[(((g - 1) * 3 + 0) * I + k) * 64 + lane]);
+            LT::set(ay[k / W], k % W, LT::get(ay[k / W], k % W) + red[(((g - 1) * 3 + 1) * I + k) * 64 + lane]);
+            LT::set(az[k / W], k % W, LT::get(az[k / W], k % W) + red[(((g - 1) * 3 + 2) * I + k) * 64 + lane]);
         }
     }
-    if (group != 0) return;
 
 #pragma unroll
     for (int k = 0; k < I; ++k) {
         if (!active[k]) continue;
         const unsigned i  = idx[k];
-        const T        fx = LT::get(ax[k / W], k % W), fy = LT::get(ay[k / W], k % W), fz = LT::get(az[k / W], k % W);
+        const T        fx = LT::get(ax[k / W], k % W) * m_ref, fy = LT::get(ay[k / W], k % W) * m_ref, fz = LT::get(az[k / W], k % W) * m_ref;
         if (s.finalize) {
             // integrateBodies, bodysystemcuda.cu:166-183
             vec4 v  = reinterpret_cast<const vec4*>(s.vel)[i];
@@ -338,7 +393,7 @@ template <typename T, int R, int LPT> __global__ __launch_bounds__(256) void int
 #pragma unroll 1
         for (int jj = 0; jj < TILE; jj += 64 * U) {
 #pragma unroll
-            for (int u = 0; u < U; ++u) interact<T, R>(mine[jj + 64 * u], px, py, pz, ax, ay, az, eps2);
+            for (int u = 0; u < U; ++u) interact<T, R, false>(mine[jj + 64 * u], px, py, pz, ax, ay, az, eps2);
         }
         if (have_next) store_tile(cur ^ 1, regs);
         __syncthreads();
@@ -389,10 +444,21 @@ template <typename T, int R> hipError_t dispatch_wavesplit(const Shard<T>& s, co
     }
 }
 
+// Dynamic LDS above 64 KiB needs an opt-in per kernel AND per device (gfx950 has 160 KiB per CU); one bit per device.
+template <typename Kernel> hipError_t allow_large_lds(Kernel kernel) {
+    static std::atomic<unsigned long long> armed{0};
+    int device = 0;
+    if (const auto err = hipGetDevice(&device); err != hipSuccess) return err;
+    const unsigned long long bit = 1ull << (device & 63);
+    if (armed.load(std::memory_order_acquire) & bit) return hipSuccess;
+    const auto err = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (err == hipSuccess) armed.fetch_or(bit, std::memory_order_release);
+    return err;
+}
+
 template <typename T, int R, int S, int LPT> hipError_t launch_one(const Shard<T>& s, const Plan& p, hipStream_t stream, bool prepare_only) {
-    if (p.lds_bytes > 64u * 1024u) {  // above the default dynamic-LDS ceiling: opt in once per kernel (gfx950 has 160 KiB per CU)
-        static hipError_t opted = hipFuncSetAttribute(reinterpret_cast<const void*>(&integrate_bodies_fast<T, R, S, LPT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (opted != hipSuccess) return opted;
+    if (p.lds_bytes > 64u * 1024u) {
+        if (const auto err = allow_large_lds(&integrate_bodies_fast<T, R, S, LPT>); err != hipSuccess) return err;
     }
     if (prepare_only) return hipSuccess;  // graph capture arms the attribute before hipStreamBeginCapture
     hipLaunchKernelGGL((integrate_bodies_fast<T, R, S, LPT>), dim3(p.grid_blocks), dim3(block_threads_for(S)), p.lds_bytes, stream, s);
@@ -402,7 +468,7 @@ template <typename T, int R, int S, int LPT> hipError_t launch_one(const Shard<T
 template <typename T, int R, int S> hipError_t dispatch_lpt(const Shard<T>& s, const Plan& p, hipStream_t stream, bool prepare_only) {
     constexpr int kBlock = block_threads_for(S);
     if (p.tile_bodies % kBlock) return hipErrorInvalidValue;
-    switch (p.tile_bodies / kBlock) {
+    switch (p.tile_bodies / kBlock) {  // = bodies j per wave per chunk / 64
         case 1: return launch_one<T, R, S, 1>(s, p, stream, prepare_only);
         case 2: return launch_one<T, R, S, 2>(s, p, stream, prepare_only);
         case 4: return launch_one<T, R, S, 4>(s, p, stream, prepare_only);
@@ -412,8 +478,6 @@ template <typename T, int R, int S> hipError_t dispatch_lpt(const Shard<T>& s, c
 
 template <typename T, int R> hipError_t dispatch_s(const Shard<T>& s, const Plan& p, hipStream_t stream, bool prepare_only) {
     switch (p.lanes_per_body) {
-        case 1: return dispatch_lpt<T, R, 1>(s, p, stream, prepare_only);
-        case 2: return dispatch_lpt<T, R, 2>(s, p, stream, prepare_only);
         case 4: return dispatch_lpt<T, R, 4>(s, p, stream, prepare_only);
         case 8: return dispatch_lpt<T, R, 8>(s, p, stream, prepare_only);
         case 16: return dispatch_lpt<T, R, 16>(s, p, stream, prepare_only);
@@ -454,7 +518,7 @@ template <typename T> Plan plan_fast(unsigned i_count, unsigned j_count, int cu_
         S = kWaveSplit;
         I = (static_cast<long>(i_count) / (4 * 2 * W) >= 4L * cu_count) ? 2 * W : W;  // 2 vectors per wave while that leaves >= 4 workgroups per CU
     }
-    if (ovr_i > 0) I = std::max(ovr_i / W * W, W);
+    if (ovr_i > 0) I = std::min(std::max(ovr_i / W * W, W), kMaxI);
     if (ovr_s > 0) S = ovr_s;
     if (S == kWaveSplit) {
         if (I > 2 * W) I = 2 * W;
@@ -495,10 +559,10 @@ template <typename T> hipError_t launch_fast(const Shard<T>& s, const Plan& p, h
             default: return hipErrorInvalidValue;
         }
     }
-    switch (p.bodies_per_lane / W) {
-        case 1: return dispatch_s<T, 1>(s, p, stream, prepare_only);
-        case 2: return dispatch_s<T, 2>(s, p, stream, prepare_only);
-        case 4: return dispatch_s<T, 4>(s, p, stream, prepare_only);
+    switch (p.bodies_per_lane) {  // at most 4 bodies i per lane: fp32 R = 1, 2 packed pairs; fp64 R = 1, 2, 4
+        case 1: if constexpr (W == 1) return dispatch_s<T, 1>(s, p, stream, prepare_only); else return hipErrorInvalidValue;
+        case 2: return dispatch_s<T, 2 / W>(s, p, stream, prepare_only);
+        case 4: return dispatch_s<T, 4 / W>(s, p, stream, prepare_only);
         default: return hipErrorInvalidValue;
     }
 }

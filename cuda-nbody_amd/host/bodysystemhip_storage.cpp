@@ -54,7 +54,12 @@ template <std::floating_point T, template <std::floating_point> class Storage> a
 template <std::floating_point T, template <std::floating_point> class Storage> auto BodySystemHIPStored<T, Storage>::prepare_many(T deltaTime, unsigned steps) -> void {
     if (steps < 2 || (steps & 1u)) return;  // odd counts fall back to the loop in update_many
     const auto mode = nbody_hip::integration_mode();
-    if (graph_ != nullptr && graph_dt_ == deltaTime && graph_steps_ == steps && graph_read_ == this->current_read_ && graph_mode_ == mode) return;
+    // everything nb_graph_create_* bakes into the captured launches is part of the key: dt, step count, which buffer is
+    // read first, mode, and -- kernel arguments too -- this system's damping and softening^2 (update_params changes them)
+    if (graph_ != nullptr && graph_dt_ == deltaTime && graph_steps_ == steps && graph_read_ == this->current_read_ && graph_mode_ == mode && graph_damping_ == this->damping_ &&
+        graph_softening_squared_ == this->softening_squared_) {
+        return;
+    }
     drop_graph();
     this->apply_softening();
     T*  from = storage_.position_ptr(this->current_read_);
@@ -67,6 +72,7 @@ template <std::floating_point T, template <std::floating_point> class Storage> a
     }
     hip_check(status, "nb_graph_create");
     graph_dt_ = deltaTime, graph_steps_ = steps, graph_read_ = this->current_read_, graph_mode_ = mode;
+    graph_damping_ = this->damping_, graph_softening_squared_ = this->softening_squared_;
 }
 
 template <std::floating_point T, template <std::floating_point> class Storage> auto BodySystemHIPStored<T, Storage>::update_many(T deltaTime, unsigned steps) -> void {

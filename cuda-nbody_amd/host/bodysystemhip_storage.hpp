@@ -102,12 +102,14 @@ template <std::floating_point T, template <std::floating_point> class Storage> c
 
     Storage<T> storage_{static_cast<std::size_t>(this->nb_bodies_) * 4};
 
-    // captured step loop (nb_graph_*): valid for one (dt, steps, read index, mode) combination
+    // captured step loop (nb_graph_*): valid for one (dt, steps, read index, mode, damping, softening^2) combination
     nb_graph_t   graph_       = nullptr;
     T            graph_dt_    = 0;
     unsigned     graph_steps_ = 0;
     unsigned int graph_read_  = 0;
     int          graph_mode_  = 0;
+    T            graph_damping_           = 0;
+    T            graph_softening_squared_ = 0;
 };
 
 template <std::floating_point T> using BodySystemHIPDefault    = BodySystemHIPStored<T, DeviceStorage>;

@@ -1,6 +1,7 @@
 // capi_host.cpp -- extern "C" doorway onto the C++ host mirror so pytest can drive it with ctypes
 // (tests/test_host_cpp.py).  Not part of the drop-in boundary (that is include/nbody_hip.h).
 #include "compute.hpp"
+#include "integrate_nbody_hip.hpp"
 #include "randomise_bodies.hpp"
 #include "tipsy.hpp"
 
@@ -56,6 +57,33 @@ NBH_API int nbh_precision_switch_roundtrip(std::size_t nb_bodies, int hostmem, i
         if (compute.fp64_enabled()) return -3;
         copy(compute.positions_fp32(), out32_b);
         copy(compute.velocities_fp32(), out32_b + n4);
+        return 0;
+    } catch (...) { return -1; }
+}
+
+// Compute::compare_results through the reference-shaped stack: 1 = check passed, 0 = check failed, -1 = exception.
+// `injected_error` perturbs the FAST result (body 0, x) before the check -- a check that cannot fail checks nothing.
+NBH_API int nbh_compare_results(std::size_t nb_bodies, int fp64, int hostmem, double injected_error) {
+    try {
+        auto compute = Compute(fp64 != 0, false, true, false, hostmem != 0, 256, nb_bodies, {});
+        return compute.compare_results(injected_error) ? 1 : 0;
+    } catch (...) { return -1; }
+}
+
+// Compute::select_demo + `steps` x update_simulation in the given mode; out = positions then velocities (4N each).
+NBH_API int nbh_run_demo(std::size_t nb_bodies, std::size_t demo, int mode, int steps, float* out) {
+    try {
+        const auto saved              = nbody_hip::integration_mode();
+        nbody_hip::integration_mode() = mode;
+        auto compute                  = Compute(false, false, false, false, false, 256, nb_bodies, {});
+        compute.select_demo(demo);
+        for (int s = 0; s < steps; ++s) compute.update_simulation();
+        const auto n4  = 4 * compute.nb_bodies();
+        const auto pos = compute.positions_fp32();
+        std::copy(pos.begin(), pos.begin() + static_cast<std::ptrdiff_t>(n4), out);
+        const auto vel = compute.velocities_fp32();
+        std::copy(vel.begin(), vel.begin() + static_cast<std::ptrdiff_t>(n4), out + n4);
+        nbody_hip::integration_mode() = saved;
         return 0;
     } catch (...) { return -1; }
 }

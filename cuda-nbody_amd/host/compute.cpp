@@ -82,7 +82,9 @@ auto Compute::switch_precision() -> void {
     fp64_enabled_ = !fp64_enabled_;
 }
 
-// compute.cpp:156-187 without the camera
+// compute.cpp:156-187 without the camera.  One deliberate difference: the reference's select_demo leaves the body
+// system's softening and damping at the PREVIOUS demo's values until a slider moves (only controls.cpp:51,64 call
+// update_params); here the selected row's softening/damping take effect with the row, which is what its table means.
 auto Compute::select_demo(std::size_t index) -> void {
     if (index >= demo_params.size()) throw std::invalid_argument("demo index out of range");
     active_demo_   = index;
@@ -112,7 +114,7 @@ auto Compute::run_benchmark(int nb_iterations) -> void {
 
 auto Compute::use_graph(bool enable) -> void { compute_hip_->use_graph(enable); }
 
-auto Compute::compare_results() -> bool { return compute_hip_->compare_results(active_params_); }
+auto Compute::compare_results(double injected_error) -> bool { return compute_hip_->compare_results(active_params_, injected_error); }
 
 auto Compute::positions_fp32() const -> std::span<const float> { return compute_hip_->get_position_fp32(); }
 auto Compute::positions_fp64() const -> std::span<const double> { return compute_hip_->get_position_fp64(); }

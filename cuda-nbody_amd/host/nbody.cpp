@@ -4,7 +4,8 @@
 //
 //   reference flags : --fullscreen --fp64 --hostmem --benchmark --numbodies=<n> --compare --qatest --cpu
 //                     --tipsy=<file> -i,--iterations=<n> --blockSize=<n>      (single-dash spellings accepted too)
-//   extensions      : --mode=fast|strict  --config=shell|random|expand  --steps=<n>  --dump=<file>  --seed=<n>  --graph
+//   extensions      : --mode=fast|strict  --config=shell|random|expand  --demo=<0..6>  --steps=<n>  --dump=<file>
+//                     --seed=<n>  --graph  --inject-error=<x> (test hook for --compare)
 #include "compute.hpp"
 #include "integrate_nbody_hip.hpp"
 
@@ -45,6 +46,8 @@ struct Options {
     std::filesystem::path dump;
     std::optional<unsigned> seed;
     bool                  graph = false;
+    std::optional<std::size_t> demo;   // row of Compute::demo_params (the reference reaches them from the viewer's keys only)
+    double                inject_error = 0.0;
 };
 
 constexpr auto help_text = R"(The MI355X NBody hot path (drop-in for cuda-nbody's compute path).
@@ -65,10 +68,12 @@ Options:
   --blockSize INT [256]       Workgroup / LDS tile size of the strict kernels (multiple of 64); a hint for the fast ones
   --mode TEXT [fast]          fast | strict (strict bit-reproduces the reference's CPU BodySystem path)
   --config TEXT [shell]       shell | random | expand initial configuration
+  --demo UINT                 Select row 0..6 of the demo parameter table (dt, scales, softening, damping) and reset
   --steps UINT                Advance this many steps (untimed) before --dump
   --dump TEXT                 Write final positions then velocities (raw little-endian T[4N] each) to this file
   --seed UINT                 srand() this value first (the reference never seeds: default stream = seed 1)
   --graph                     --benchmark issues its (even number of) iterations as one captured hipGraph
+  --inject-error FLOAT        Test hook: added to body 0's x of the fast result before --compare checks it
 )";
 
 template <typename I> auto parse_number(std::string_view text, I& out) -> bool {
@@ -155,6 +160,21 @@ auto parse_args(int argc, char** argv) -> std::pair<Status, Options> {
             const auto v = take_value();
             ok           = v.has_value();
             if (ok) options.dump = std::filesystem::path(std::string(*v));
+        } else if (name == "demo") {
+            const auto  v = take_value();
+            std::size_t d = 0;
+            ok            = v && parse_number(*v, d) && d < Compute::demo_params.size();
+            if (!ok) return error("--demo: Value not in range 0 to " + std::to_string(Compute::demo_params.size() - 1));
+            options.demo = d;
+        } else if (name == "inject-error") {
+            const auto v = take_value();
+            ok           = v.has_value();
+            if (ok) {
+                char* end            = nullptr;
+                const auto text      = std::string(*v);
+                options.inject_error = std::strtod(text.c_str(), &end);
+                ok                   = end != nullptr && *end == '\0' && end != text.c_str();
+            }
         } else if (name == "mode") {
             const auto v = take_value();
             ok           = v && (*v == "fast" || *v == "strict");
@@ -205,13 +225,14 @@ auto main(int argc, char** argv) -> int {
         auto compute = Compute(cmd_options.fp64, cmd_options.cpu, compare_to_cpu, cmd_options.benchmark, cmd_options.hostmem, cmd_options.block_size, cmd_options.numbodies, cmd_options.tipsy, cmd_options.config);
 
         compute.use_graph(cmd_options.graph);
+        if (cmd_options.demo) compute.select_demo(*cmd_options.demo);
         if (cmd_options.benchmark) {
             const auto nb_iterations = cmd_options.iterations == 0 ? 10 : static_cast<int>(cmd_options.iterations);
             compute.run_benchmark(nb_iterations);
             return 0;
         }
         if (compare_to_cpu) {
-            const auto result = compute.compare_results();
+            const auto result = compute.compare_results(cmd_options.inject_error);
             return static_cast<int>(!result);
         }
         for (auto s = std::size_t{0}; s < cmd_options.steps; ++s) compute.update_simulation();

@@ -133,8 +133,9 @@ def gpu_accel(gpu, pos, dtype, i_begin, i_count, j_begin, j_count, mode, acc_in=
     return out
 
 
-@pytest.mark.parametrize("plan", [(2, 1, 256), (2, 1, 1024), (4, 1, 1024), (8, 1, 512), (2, 2, 1024), (4, 4, 256), (8, 4, 1024), (2, 4, 512), (4, 2, 512), (8, 2, 256),
-                                  (2, 8, 512), (4, 8, 1024), (2, 16, 1024), (4, 16, 1024), (8, 16, 1024), (8, 8, 512),
+@pytest.mark.parametrize("plan", [(2, 4, 256), (2, 4, 512), (2, 4, 1024), (4, 4, 256), (4, 4, 512), (4, 4, 1024),
+                                  (2, 8, 512), (2, 8, 1024), (2, 8, 2048), (4, 8, 512), (4, 8, 1024), (4, 8, 2048),
+                                  (2, 16, 1024), (2, 16, 2048), (2, 16, 4096), (4, 16, 1024), (4, 16, 2048), (4, 16, 4096),
                                   (2, 64, 512), (2, 64, 1024), (4, 64, 512), (4, 64, 1024)])  # S = 64: wave-split layout
 def test_fast_force_error_every_geometry(gpu, oracle, plan):
     """Every (bodies/lane, lane-groups, tile) instantiation against an fp64 direct sum, ragged N and ranges."""
