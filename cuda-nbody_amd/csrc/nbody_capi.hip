@@ -92,7 +92,7 @@ int integrate_shard(T* new_pos, const T* old_pos, T* vel, T* acc, unsigned i_beg
     if (mode == NB_MODE_STRICT) {
         if (block_size <= 0) block_size = 256;  // the reference's default --blockSize (nbody.cpp:285)
         if (block_size % 64 != 0 || block_size > 1024) return NB_ERR_INVALID_ARGUMENT;
-        return static_cast<int>(nb::launch_strict<T>(s, block_size, as_stream(stream)));
+        return static_cast<int>(nb::launch_strict<T>(s, block_size, cu_count_cached(), as_stream(stream)));
     }
     if (mode == NB_MODE_FAST) {
         const nb::Plan p = nb::plan_fast<T>(i_count, j_count, cu_count_cached(), g_ovr_i.load(), g_ovr_s.load(), g_ovr_tile.load());

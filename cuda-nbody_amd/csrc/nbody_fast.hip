@@ -214,6 +214,9 @@ template <typename T, int R, int S, int LPT> __global__ __launch_bounds__(block_
         return __builtin_amdgcn_ballot_w64(!same) == 0;
     };
 
+#ifdef NB_STAMPS  // diagnostic build only (tools/stamp_probe.py): when does each wave start / finish streaming?
+    const unsigned long long stamp_t0 = __builtin_amdgcn_s_memtime();
+#endif
     vec4     regs[LPT];
     unsigned c    = wave;  // wave w streams chunks w, w+S, w+2S, ...
     bool     unit = false;
@@ -223,22 +226,49 @@ template <typename T, int R, int S, int LPT> __global__ __launch_bounds__(block_
     }
     wave_lds_sync();
 
-    // The SIMD arbiter favours its oldest wave heavily (in isolation the four waves of a SIMD ran this loop at rates
-    // 3.5 : ... : 1), so equal shares of work finish at very different times and the SIMD runs under-filled (one wave
-    // alone issues only every 8th cycle) until the workgroup's last wave is done.  Rotating a static priority with the
-    // chunk counter gives each of the four SIMD mates (waves w, w+4, w+8, w+12) the top slot a quarter of the time.
-    unsigned turn = static_cast<unsigned>(wave >> 2) + (S < 16 ? blockIdx.x * (S / 4) : 0u);
+    // The SIMD arbiter is strictly oldest-first: left alone, the four waves that share a SIMD finish equal shares of work
+    // at 30 % / 53 % / 76 % / 100 % of the workgroup's time (profiles/round2_wave_finish_times.txt), and for the last
+    // quarter each SIMD is down to ONE wave, which only reaches 76 % of the issue rate four waves sustain (80.6 against 61.5
+    // cycles per interaction pair).  s_setprio outranks age, so progress is equalised instead: each wave publishes how many
+    // chunks it has done; a wave that is level with the slowest wave of ITS SIMD (HW_ID.SIMD_ID) runs at priority 3, one that is ahead
+    // at 0.  With two waves per SIMD and workgroup (S = 8, the production geometry: two 512-thread workgroups per CU) they
+    // finish within 0.5 % of each other; with four (S = 16) the two youngest still trail (a starved wave cannot re-evaluate
+    // itself; graded levels made it worse), which is why S = 8 is the default.  The chunk -> wave assignment stays static, so the summation order (and every result bit) is the same
+    // from run to run.  (Putting the leaders to sleep instead equalises too, but costs 15 %: a SIMD needs 3-4 runnable waves.)
+    constexpr size_t kRingBytes = static_cast<size_t>(S) * 2 * CH * sizeof(vec4);
+    constexpr size_t kFoldBytes = static_cast<size_t>(S - 1) * 3 * I * 64 * sizeof(T);
+    unsigned* const   balance    = reinterpret_cast<unsigned*>(smem_raw + (kRingBytes > kFoldBytes ? kRingBytes : kFoldBytes));
+    unsigned* const   simd_count = balance;                                     // [4] waves of this workgroup per SIMD
+    volatile unsigned* progress  = reinterpret_cast<volatile unsigned*>(balance + 4);  // [4][8] chunks done, by SIMD and slot
+    if (tid < 36) balance[tid] = tid < 4 ? 0u : 0xffffffffu;
+    __syncthreads();
+    const unsigned simd = static_cast<unsigned>(__builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4));  // HW_REG_HW_ID[5:4] = SIMD_ID
+    unsigned       slot = 0;
+    if (lane == 0) slot = atomicAdd(&simd_count[simd], 1u);
+    slot                = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(slot))) & 7u;
+    volatile unsigned* const mine = progress + simd * 8;
+    unsigned done = 0;
+    if (lane == 0) mine[slot] = 0;
 
     int cur = 0;
     for (; c < n_chunks; c += S) {
         const bool have_next = (c + S) < n_chunks;
         if (have_next) load_chunk(c + S, regs);  // global loads in flight across the compute below
-        switch (turn++ & 3u) {
-            case 0: __builtin_amdgcn_s_setprio(0); break;
-            case 1: __builtin_amdgcn_s_setprio(1); break;
-            case 2: __builtin_amdgcn_s_setprio(2); break;
-            default: __builtin_amdgcn_s_setprio(3); break;
+#ifndef NB_EXP_BALANCE
+#define NB_EXP_BALANCE 1
+#endif
+#if NB_EXP_BALANCE == 1  // a wave that is not ahead of any wave of its SIMD (same workgroup) runs at priority 3, the others at 0
+        {
+            unsigned least = done;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) least = min(least, mine[q]);  // unsynchronised reads: a stale value only delays a priority change
+            if (static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(least))) >= done) {
+                __builtin_amdgcn_s_setprio(3);
+            } else {
+                __builtin_amdgcn_s_setprio(0);
+            }
         }
+#endif
 
         const vec4* __restrict__ chunk = ring + cur * CH;
         if (unit) {
@@ -256,10 +286,19 @@ template <typename T, int R, int S, int LPT> __global__ __launch_bounds__(block_
         }
 
         if (have_next) unit = store_chunk(cur ^ 1, regs);
+        ++done;
+        if (lane == 0) mine[slot] = done;
         wave_lds_sync();
         cur ^= 1;
     }
+    if (lane == 0) mine[slot] = 0xffffffffu;  // finished: never the one the others defer to
     __builtin_amdgcn_s_setprio(0);
+#ifdef NB_STAMPS
+    if (lane == 0 && s.acc != nullptr && s.finalize && !s.acc_in) {
+        unsigned long long* stamps = reinterpret_cast<unsigned long long*>(s.acc) + (static_cast<size_t>(blockIdx.x) * S + wave) * 2;
+        stamps[0] = stamp_t0, stamps[1] = __builtin_amdgcn_s_memtime();
+    }
+#endif
 
     // fold the S partial sums (waves 1..S-1 -> wave 0) through LDS, fixed order
     T* red = reinterpret_cast<T*>(smem_raw);  // [(S-1)][3][I][64]; overlays the rings, hence the barrier: every wave is done streaming
@@ -487,20 +526,22 @@ template <typename T, int R> hipError_t dispatch_s(const Shard<T>& s, const Plan
 
 }  // namespace
 
-// Geometry (measured: profiles/round1_sweep_*.txt, the shard sweeps included).
-//   * S = 16: one 1024-thread workgroup = 16 waves = 4 per SIMD, all working on the SAME 64*I bodies i and each
-//     walking 1/16 of every LDS tile.  One resident workgroup per CU fills the chip for any shard with >= 256
-//     workgroups, which is what keeps a 32 768-body shard (8-GPU strong scaling of 262 144 bodies) at 94 % of the
-//     full-size rate; at full size it is as fast as any smaller split.
+// Geometry (measured: profiles/round2_plan_sweep_*.txt; round 1's sweeps for the wave-split crossover).
+//   * S = 8: a 512-thread workgroup = 8 waves = 2 per SIMD, all working on the SAME 64*I bodies i and each streaming every
+//     8th chunk of the bodies j.  Two workgroups share a CU (128 VGPRs -> 4 waves per SIMD); a SIMD sustains its full issue
+//     rate with 3-4 runnable waves and 96.5 % of it with 2 (61.5 / 63.7 cycles per interaction pair), so a shard that only
+//     has one workgroup per CU (65 536 bodies at I = 4) still runs near full rate.  S = 16 (one 1024-thread workgroup per
+//     CU) is 1-2 % slower: its four waves per SIMD cannot be kept level (see the kernel), S = 4 is 8 % slower.
 //   * I (bodies i per lane, a multiple of W: fp32 bodies travel in packed pairs; at most 4, what fits 128 VGPRs):
-//     register tiling amortises the LDS broadcast and the per-tile barrier, but what matters more is how the
-//     resulting workgroup count fills whole rounds of 256 CUs.
-//   * LDS tile 2048 bodies (fp32, 2 x 32 KiB double-buffered) / 1024 (fp64): 128 bodies j per wave between barriers.
+//     register tiling amortises the LDS broadcast, but what matters more is how the resulting workgroup count divides
+//     over the 256 CUs.
+//   * 128 bodies j per wave and chunk (tile = S * 128 = 1024 bodies staged per workgroup and round, 2 x 16 KiB fp32 /
+//     2 x 32 KiB fp64 of LDS rings).
 template <typename T> Plan plan_fast(unsigned i_count, unsigned j_count, int cu_count, int ovr_i, int ovr_s, int ovr_tile) {
     constexpr int W     = Lane<T>::W;
     constexpr int kMaxI = 4;  // fp32: 2 packed pairs, fp64: 4 bodies -- the most a 1024-thread workgroup holds in 128 VGPRs without spilling
-    // Tile layout, S = 16: one workgroup per CU at a time, so its efficiency is the fill of the last round of
-    // workgroups.  Pick the I whose workgroup count quantises best (larger I is ~3 % faster per interaction).
+    // Wave-stream layout: a CU works through ceil(blocks / CUs) workgroups (two at a time), so its efficiency is the fill
+    // of the last round.  Pick the I whose workgroup count quantises best (larger I is ~3 % faster per interaction).
     int    I        = W;
     double best_eff = 0.0;
     for (int cand = W; cand <= kMaxI; cand *= 2) {
@@ -509,7 +550,7 @@ template <typename T> Plan plan_fast(unsigned i_count, unsigned j_count, int cu_
         const double eff    = static_cast<double>(blocks) / static_cast<double>(rounds * cu_count) * (cand == kMaxI ? 1.0 : 0.97);
         if (eff >= best_eff) best_eff = eff, I = cand;
     }
-    int S = 16;
+    int S = 8;
     // The wave-split layout has no such quantisation (its workgroups are 64-256x smaller) but runs at ~0.78 (fp32) /
     // ~0.62 (fp64) of the tile layout's full rate (tools/layout_crossover.py): take it when the tile layout would
     // fill the chip worse than that.
@@ -533,7 +574,7 @@ template <typename T> Plan plan_fast(unsigned i_count, unsigned j_count, int cu_
         return p;
     }
     const int block = block_threads_for(S);
-    int       tile  = (sizeof(T) == 4 && j_count >= 8192) ? 2048 : 1024;
+    int       tile  = 128 * S;
     if (ovr_tile > 0) tile = ovr_tile;
     if (tile < block) tile = block;
 
@@ -546,7 +587,7 @@ template <typename T> Plan plan_fast(unsigned i_count, unsigned j_count, int cu_
     p.grid_blocks     = (i_count + bodies_per_block - 1) / bodies_per_block;
     const size_t tile_bytes = 2ull * tile * 4 * sizeof(T);
     const size_t red_bytes  = static_cast<size_t>(S - 1) * 3 * I * (block / S) * sizeof(T);
-    p.lds_bytes             = static_cast<unsigned>(std::max(tile_bytes, red_bytes));
+    p.lds_bytes             = static_cast<unsigned>(std::max(tile_bytes, red_bytes)) + 256u;  // + the waves' progress words
     return p;
 }
 

@@ -30,6 +30,6 @@ struct Plan {
 
 template <typename T> Plan       plan_fast(unsigned i_count, unsigned j_count, int cu_count, int ovr_i, int ovr_s, int ovr_tile);
 template <typename T> hipError_t launch_fast(const Shard<T>& s, const Plan& p, hipStream_t stream, bool prepare_only = false);
-template <typename T> hipError_t launch_strict(const Shard<T>& s, int block_size, hipStream_t stream);
+template <typename T> hipError_t launch_strict(const Shard<T>& s, int block_size, int cu_count, hipStream_t stream);
 
 }  // namespace nb

@@ -61,19 +61,20 @@ def test_launch_plan_heuristics_without_gpu(pkg):
         p = pkg.plan(i, j, dtype)
         return p.bodies_per_lane, p.lanes_per_body, p.tile_bodies, p.block_threads, p.grid_blocks
 
-    # full-size fp32 systems: 16 wave-groups per 1024-thread workgroup, 4 bodies (2 packed pairs) per lane
-    assert plan(262144, 262144) == (4, 16, 2048, 1024, 1024)
-    assert plan(65536, 65536) == (4, 16, 2048, 1024, 256)
-    assert plan(1048576, 1048576) == (4, 16, 2048, 1024, 4096)
+    # full-size fp32 systems: 8 waves per 512-thread workgroup (two workgroups per CU), 4 bodies (2 packed pairs) per lane,
+    # 128 bodies j per wave and chunk
+    assert plan(262144, 262144) == (4, 8, 1024, 512, 1024)
+    assert plan(65536, 65536) == (4, 8, 1024, 512, 256)
+    assert plan(1048576, 1048576) == (4, 8, 1024, 512, 4096)
     # strong-scaling shards of 262 144 bodies on 2 / 4 / 8 GPUs keep whole rounds of 256 workgroups
-    assert plan(131072, 262144)[:2] + plan(131072, 262144)[4:] == (4, 16, 512)
-    assert plan(65536, 262144)[:2] + plan(65536, 262144)[4:] == (4, 16, 256)
-    assert plan(32768, 262144)[:2] + plan(32768, 262144)[4:] == (2, 16, 256)
+    assert plan(131072, 262144)[:2] + plan(131072, 262144)[4:] == (4, 8, 512)
+    assert plan(65536, 262144)[:2] + plan(65536, 262144)[4:] == (4, 8, 256)
+    assert plan(32768, 262144)[:2] + plan(32768, 262144)[4:] == (2, 8, 256)
     # small or awkward sizes: wave-split layout (lanes_per_body == 64), 256-thread workgroups
     for n in (1, 1024, 4096, 16384, 40960):
         assert plan(n, n)[1] == 64 and plan(n, n)[3] == 256, n
     # fp64: one body per vector, up to 4 per lane
-    assert plan(262144, 262144, np.float64) == (4, 16, 1024, 1024, 1024)
+    assert plan(262144, 262144, np.float64) == (4, 8, 1024, 512, 1024)
     assert plan(1024, 1024, np.float64)[1] == 64
     # overrides are validated and reversible
     pkg.set_plan_override(2, 4, 512)
@@ -81,4 +82,4 @@ def test_launch_plan_heuristics_without_gpu(pkg):
         assert plan(262144, 262144)[:4] == (2, 4, 512, 256)
     finally:
         pkg.set_plan_override(0, 0, 0)
-    assert plan(262144, 262144)[1] == 16
+    assert plan(262144, 262144)[1] == 8

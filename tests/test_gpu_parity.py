@@ -201,8 +201,8 @@ def test_fast_fp64_and_fp32_wavesplit_vs_tile_layout(gpu, oracle, dtype):
         gpu.set_plan_override(0, 0, 0)
     err = np.linalg.norm(xyz(a) - xyz(b), axis=1) / np.linalg.norm(xyz(b), axis=1)
     assert err.max() < (1e-5 if dtype == np.float32 else 1e-13), err.max()  # two summation orders of ~4000 terms
-    # large shards keep the tile layout
-    assert gpu.plan(262144, 262144, dtype).lanes_per_body == 16
+    # large shards keep the wave-stream layout
+    assert gpu.plan(262144, 262144, dtype).lanes_per_body == 8
 
 
 def test_fast_handles_tiny_and_ragged_n(gpu, oracle):
@@ -377,6 +377,57 @@ def test_strict_bitwise_on_extreme_values(gpu, oracle, dtype):
     got_pos, got_vel = run_gpu(gpu, pos0, vel0, 2, gpu.NB_MODE_STRICT, params=params)
     assert got_pos.tobytes() == ref_pos.tobytes()
     assert got_vel.tobytes() == ref_vel.tobytes()
+
+
+def test_strict_fast_form_window_edges_bitwise(gpu, oracle):
+    """The fp32 STRICT kernel runs divide and sqrt without scaling/fix-up steps while every operand sits inside a
+    checked window (|coordinate| <= 2^18, 2^-40 <= |mass| <= 2^40 or +0, softening^2 in [2^-39, 2^38]) and falls back to
+    the generic IEEE expansions per 64-body chunk otherwise.  Systems that sit ON the window's edges, mix in-window and
+    out-of-window chunks, produce denormal products (tiny separations) and carry -0 / zero masses must all stay 0 ulp."""
+    rng = np.random.default_rng(7)
+    n = 64 * 9 + 17  # ragged last chunk
+
+    def system(coord_scale, mass_lo, mass_hi):
+        pos = np.zeros((n, 4), np.float32)
+        pos[:, :3] = (rng.uniform(-1, 1, (n, 3)) * coord_scale).astype(np.float32)
+        pos[:, 3] = (2.0 ** rng.uniform(mass_lo, mass_hi, n)).astype(np.float32)
+        vel = (rng.standard_normal((n, 4)) * 0.1).astype(np.float32)
+        vel[:, 3] = 0
+        return pos, vel
+
+    cases = []
+    # (a) exactly on the coordinate edge, masses on both mass edges
+    pos, vel = system(2.0 ** 18, -40, 40)
+    pos[0, :3] = 2.0 ** 18
+    pos[1, :3] = -(2.0 ** 18)
+    pos[2, 3], pos[3, 3] = 2.0 ** -40, 2.0 ** 40
+    cases.append(("edges", pos, vel, 0.1))
+    # (b) one chunk just outside (coordinate 2^18 * (1 + 2^-23), mass 2^41, mass -0.0, inf, NaN-free), the others inside
+    pos, vel = system(100.0, -3, 3)
+    pos[64 * 2 + 5, 0] = np.float32(2.0 ** 18) * np.float32(1 + 2.0 ** -23)
+    pos[64 * 4 + 1, 3] = 2.0 ** 41
+    pos[64 * 6 + 9, 3] = -0.0
+    pos[64 * 7 + 2, 3] = 0.0
+    pos[64 * 8 + 3, 3] = -1.5  # negative masses are in the window too
+    cases.append(("mixed chunks", pos, vel, 0.1))
+    # (c) tiny separations: dx^2 underflows / goes denormal, softening at the window's lower edge
+    pos, vel = system(1.0, -2, 2)
+    pos[1::2, :3] = pos[0::2, :3][: pos[1::2].shape[0]] + np.float32(2.0 ** -70)
+    pos[5, :3] = pos[4, :3] * np.float32(1 + 2.0 ** -23)
+    cases.append(("tiny separations", pos, vel, float(np.sqrt(np.float32(2.0 ** -39)))))
+    # (d) softening outside the window (too small / too large): whole run on the generic form
+    pos, vel = system(10.0, -2, 2)
+    cases.append(("softening below window", pos, vel, 2.0 ** -21))
+    cases.append(("softening above window", pos, vel, 2.0 ** 19.5))
+    for name, pos, vel, softening in cases:
+        pos0, vel0 = pos.reshape(-1).copy(), vel.reshape(-1).copy()
+        params = gpu.NBodyParams(softening=softening, damping=0.999)
+        ref_pos, ref_vel = pos0.copy(), vel0.copy()
+        with np.errstate(all="ignore"):
+            oracle.update(ref_pos, ref_vel, np.float32(0.016), steps=2, softening=softening, damping=0.999)
+        got_pos, got_vel = run_gpu(gpu, pos0, vel0, 2, gpu.NB_MODE_STRICT, params=params)
+        assert got_pos.tobytes() == ref_pos.tobytes(), name
+        assert got_vel.tobytes() == ref_vel.tobytes(), name
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])

@@ -35,8 +35,8 @@ OUTER = 512
 variants = []
 
 
-def variant(name, lines, pairs_per_iter=8):
-    variants.append((name, lines, pairs_per_iter))
+def variant(name, lines, pairs_per_iter=8, prologue=()):
+    variants.append((name, lines, pairs_per_iter, tuple(prologue)))
 
 
 for label, lines in loops:
@@ -63,10 +63,40 @@ if len(loops) > 1:
     variant("unit loop without s_nop", [l for l in unit if not l.startswith("s_nop")])
     variant("unit loop, VALU only", [l for l in unit if not l.startswith("ds_read") and not l.startswith("s_waitcnt")])
 
+if len(loops) > 1:
+    unit = loops[1][1]
+    get = ["v_lshrrev_b32 v1, 8, %4", "v_readfirstlane_b32 s41, v1"]  # s41 = wave >> 2 (0..3): position among the 4 mates of a SIMD
+    def by_slot(p0, p1, p2, p3):
+        return get + ["s_cmp_eq_u32 s41, 0", "s_cbranch_scc0 11f", f"s_setprio {p0}", "11:", "s_cmp_eq_u32 s41, 1", "s_cbranch_scc0 12f", f"s_setprio {p1}", "12:",
+                      "s_cmp_eq_u32 s41, 2", "s_cbranch_scc0 13f", f"s_setprio {p2}", "13:", "s_cmp_eq_u32 s41, 3", "s_cbranch_scc0 14f", f"s_setprio {p3}", "14:"]
+    variant("unit loop, static prio 0,1,2,3 by wave>>2", unit, prologue=by_slot(0, 1, 2, 3))
+    variant("unit loop, static prio 3,2,1,0 by wave>>2", unit, prologue=by_slot(3, 2, 1, 0))
+    variant("unit loop, all prio 3", unit, prologue=["s_setprio 3"])
+
+
+# ---- pipe-overlap probes: do packed fp32, plain fp32 and transcendental ops share one issue pipe? (32 instr per iteration) ----
+def acc(k):
+    return 2 + 2 * (k % 24)          # accumulator pairs v[2..49]
+PK  = lambda k: f"v_pk_fma_f32 v[{acc(k)}:{acc(k)+1}], v[100:101], v[102:103], v[{acc(k)}:{acc(k)+1}]"
+FMA = lambda k: f"v_fma_f32 v{acc(k)}, v100, v103, v{acc(k)}"
+FMAC = lambda k: f"v_fmac_f32 v{acc(k)}, v100, v103"
+RSQ = lambda k: f"v_rsq_f32 v{acc(k)}, v{acc(k)}"
+MUL = lambda k: f"v_mul_f32 v{acc(k)}, v100, v{acc(k)}"
+variant("probe: 32 v_pk_fma_f32", [PK(k) for k in range(32)], pairs_per_iter=32)
+variant("probe: 32 v_fma_f32", [FMA(k) for k in range(32)], pairs_per_iter=32)
+variant("probe: 32 v_fmac_f32", [FMAC(k) for k in range(32)], pairs_per_iter=32)
+variant("probe: 16 v_pk_fma + 16 v_fma_f32 interleaved", [PK(k) if k % 2 == 0 else FMA(k) for k in range(32)], pairs_per_iter=32)
+variant("probe: 16 v_pk_fma + 16 v_fmac_f32 interleaved", [PK(k) if k % 2 == 0 else FMAC(k) for k in range(32)], pairs_per_iter=32)
+variant("probe: 16 v_pk_fma then 16 v_fma_f32 (blocks)", [PK(k) for k in range(16)] + [FMA(k) for k in range(16, 32)], pairs_per_iter=32)
+variant("probe: 8 v_rsq + 24 v_pk_fma interleaved", [RSQ(k) if k % 4 == 0 else PK(k) for k in range(32)], pairs_per_iter=32)
+variant("probe: 8 v_rsq + 24 v_fma_f32 interleaved", [RSQ(k) if k % 4 == 0 else FMA(k) for k in range(32)], pairs_per_iter=32)
+variant("probe: 32 v_rsq_f32", [RSQ(k) for k in range(32)], pairs_per_iter=32)
+variant("probe: 32 v_mul_f32", [MUL(k) for k in range(32)], pairs_per_iter=32)
+
 print("// GENERATED by tools/loop_microbench_gen.py -- do not edit")
 print("#include <hip/hip_runtime.h>\n#include <algorithm>\n#include <cstdio>\n#include <cstdlib>\n#include <vector>")
 clob = ", ".join(f'"v{r}"' for r in range(1, 128))
-for idx, (name, lines, _) in enumerate(variants):
+for idx, (name, lines, _, prologue) in enumerate(variants):
     print(f"__global__ __launch_bounds__(1024) void k{idx}(unsigned long long* out) {{")
     print("    extern __shared__ float4 lds[];")
     print("    lds[threadIdx.x] = make_float4(threadIdx.x, 1.f, 2.f, 1.f);")
@@ -79,6 +109,8 @@ for idx, (name, lines, _) in enumerate(variants):
     print("    asm volatile(")
     for r in range(1, 128):
         print(f'        "v_cvt_f32_u32 v{r}, %4\\n\\tv_mul_f32 v{r}, 0x3a83126f, v{r}\\n\\tv_add_f32 v{r}, 1.0, v{r}\\n\\t"')
+    for l in prologue:
+        print(f'        "{l}\\n\\t"')
     print(f'        "s_movk_i32 s40, {OUTER}\\n\\t"')
     print('        "s_memtime %0\\n\\t"')
     print('        "s_memrealtime %2\\n\\t"')
@@ -109,11 +141,22 @@ for idx, (name, lines, _) in enumerate(variants):
     print("}")
 print("struct T { const char* name; void (*k)(unsigned long long*); int pairs; };")
 print("static T tests[] = {")
-for idx, (name, _, pairs) in enumerate(variants):
+for idx, (name, _, pairs, _p) in enumerate(variants):
     print(f'    {{"{name}", k{idx}, {pairs}}},')
 print("};")
 print(f"constexpr int OUTER = {OUTER};")
 print(r"""
+static float run(void (*k)(unsigned long long*), int cus, int threads, unsigned long long* out, hipEvent_t e0, hipEvent_t e1, int warm) {
+    for (int r = 0; r < warm; ++r) hipLaunchKernelGGL(k, dim3(cus), dim3(threads), 64 * 1024, 0, out);  // reach the clock the chip holds under this load
+    (void)hipEventRecord(e0);
+    hipLaunchKernelGGL(k, dim3(cus), dim3(threads), 64 * 1024, 0, out);
+    (void)hipEventRecord(e1);
+    (void)hipEventSynchronize(e1);
+    float ms;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    return ms;
+}
+
 int main() {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, 0) != hipSuccess) return 1;
@@ -124,35 +167,40 @@ int main() {
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0);
     (void)hipEventCreate(&e1);
+    int index = 0;
     for (auto& t : tests) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(t.k), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-        for (int r = 0; r < 3; ++r) hipLaunchKernelGGL(t.k, dim3(cus), dim3(1024), 64 * 1024, 0, out);  // warm-up: reach the clock the chip holds under this load
-        (void)hipEventRecord(e0);
-        hipLaunchKernelGGL(t.k, dim3(cus), dim3(1024), 64 * 1024, 0, out);
-        (void)hipEventRecord(e1);
-        (void)hipEventSynchronize(e1);
-        float ms;
-        (void)hipEventElapsedTime(&ms, e0, e1);
-        (void)hipMemcpy(h.data(), out, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
-        // per workgroup (= per CU): busy span in shader cycles and in 100 MHz ticks
-        std::vector<double> span, clock;
-        for (int b = 0; b < cus; ++b) {
-            unsigned long long t0 = ~0ull, t1 = 0, r0 = ~0ull, r1 = 0;
-            for (int w = 0; w < 16; ++w) {
-                const unsigned long long* o = &h[(b * 16 + w) * 4];
-                t0 = std::min(t0, o[0]), t1 = std::max(t1, o[1]), r0 = std::min(r0, o[2]), r1 = std::max(r1, o[3]);
+        // the second test (the production unit-mass loop) is also run with 1, 2 and 3 waves per SIMD
+        for (int wps = (index == 1 ? 1 : 4); wps <= 4; ++wps) {
+            const float ms = run(t.k, cus, 256 * wps, out, e0, e1, 3);
+            (void)hipMemcpy(h.data(), out, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+            const int nw = 4 * wps;
+            // per workgroup (= per CU): busy span in shader cycles and in 100 MHz ticks
+            std::vector<double> span, clock;
+            for (int b = 0; b < cus; ++b) {
+                unsigned long long t0 = ~0ull, t1 = 0, r0 = ~0ull, r1 = 0;
+                for (int w = 0; w < nw; ++w) {
+                    const unsigned long long* o = &h[(b * 16 + w) * 4];
+                    t0 = std::min(t0, o[0]), t1 = std::max(t1, o[1]), r0 = std::min(r0, o[2]), r1 = std::max(r1, o[3]);
+                }
+                span.push_back(static_cast<double>(t1 - t0));
+                clock.push_back(static_cast<double>(t1 - t0) / static_cast<double>(r1 - r0) * 0.1);  // GHz
             }
-            span.push_back(static_cast<double>(t1 - t0));
-            clock.push_back(static_cast<double>(t1 - t0) / static_cast<double>(r1 - r0) * 0.1);  // GHz
+            std::sort(span.begin(), span.end());
+            std::sort(clock.begin(), clock.end());
+            const double iters = 32.0 * OUTER;
+            const double med   = span[span.size() / 2];
+            // each of the CU's 4 SIMDs time-shares `wps` waves: SIMD cycles per packed pair = span / (iters * pairs * wps)
+            printf("%-72s waves/SIMD %d  SIMD cycles/pair %6.2f (min %.2f max %.2f)  clock %.3f GHz -> %.2f ns/pair/SIMD  wall %.3f ms\n", t.name, wps, med / iters / t.pairs / wps,
+                   span.front() / iters / t.pairs / wps, span.back() / iters / t.pairs / wps, clock[clock.size() / 2], med / iters / t.pairs / wps / clock[clock.size() / 2], ms);
+            printf("      waves of workgroup 0, (t1 - min t0) / span:");
+            unsigned long long t0 = ~0ull, t1 = 0;
+            for (int w = 0; w < nw; ++w) t0 = std::min(t0, h[w * 4]), t1 = std::max(t1, h[w * 4 + 1]);
+            for (int w = 0; w < nw; ++w) printf(" %.2f", static_cast<double>(h[w * 4 + 1] - t0) / static_cast<double>(t1 - t0));
+            printf("\n");
+            fflush(stdout);
         }
-        std::sort(span.begin(), span.end());
-        std::sort(clock.begin(), clock.end());
-        const double iters = 32.0 * OUTER;
-        const double med   = span[span.size() / 2];
-        // the CU's 4 SIMDs each time-share 4 waves: SIMD cycles per packed pair = span / (iters * pairs * 4)
-        printf("%-52s SIMD cycles/pair %6.2f (CU span median; min %.2f max %.2f)   in-kernel clock %.3f GHz   -> %.2f ns/pair/SIMD   wall %.3f ms\n", t.name, med / iters / t.pairs / 4.0,
-               span.front() / iters / t.pairs / 4.0, span.back() / iters / t.pairs / 4.0, clock[clock.size() / 2], med / iters / t.pairs / 4.0 / clock[clock.size() / 2], ms);
-        fflush(stdout);
+        ++index;
     }
     return 0;
 }
