@@ -351,7 +351,7 @@ int nb_set_plan_override(int bodies_per_lane, int lanes_per_body, int tile_bodie
             if (v == a) return true;
         return false;
     };
-    if (!ok(bodies_per_lane, {0, 1, 2, 4}) || !ok(lanes_per_body, {0, 4, 8, 16, 64}) || !ok(tile_bodies, {0, 256, 512, 1024, 2048, 4096})) return NB_ERR_INVALID_ARGUMENT;
+    if (!ok(bodies_per_lane, {0, 1, 2, 4}) || !ok(lanes_per_body, {0, 4, 8, 16, 64}) || !ok(tile_bodies, {0, 256, 512, 1024, 2048})) return NB_ERR_INVALID_ARGUMENT;
     g_ovr_i.store(bodies_per_lane);
     g_ovr_s.store(lanes_per_body);
     g_ovr_tile.store(tile_bodies);

@@ -250,6 +250,27 @@ template <typename T, int R, int S, int LPT> __global__ __launch_bounds__(block_
     unsigned done = 0;
     if (lane == 0) mine[slot] = 0;
 
+    // fp32: a register sum only ever collects kFlush chunks (1 024 bodies j); it is then added to the lane's own second-level
+    // sum in LDS.  One running fp32 sum over N/S terms loses ~sqrt(N/S) ulp (1.6e-5 relative at 1 Mi bodies against an fp64
+    // direct sum); two levels of <= 1 024 and <= N/(1024 S) terms keep it at a few 1e-6 for any N.  (fp64 has the bits to spare.)
+    constexpr bool     kTwoLevel = sizeof(T) == 4;
+    constexpr unsigned kFlush    = 1024 / CH;
+    T* const second = reinterpret_cast<T*>(balance + 64) + static_cast<size_t>(wave) * (3 * I * 64) + lane;  // [S][3][I][64]
+    if constexpr (kTwoLevel) {
+#pragma unroll
+        for (int q = 0; q < 3 * I; ++q) second[q * 64] = 0;
+    }
+    auto flush = [&]() {
+#pragma unroll
+        for (int k = 0; k < I; ++k) {
+            second[(0 * I + k) * 64] += LT::get(ax[k / W], k % W);
+            second[(1 * I + k) * 64] += LT::get(ay[k / W], k % W);
+            second[(2 * I + k) * 64] += LT::get(az[k / W], k % W);
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) ax[r] = ay[r] = az[r] = LT::splat(0);
+    };
+
     int cur = 0;
     for (; c < n_chunks; c += S) {
         const bool have_next = (c + S) < n_chunks;
@@ -287,12 +308,23 @@ template <typename T, int R, int S, int LPT> __global__ __launch_bounds__(block_
 
         if (have_next) unit = store_chunk(cur ^ 1, regs);
         ++done;
+        if constexpr (kTwoLevel) {
+            if (done % kFlush == 0) flush();
+        }
         if (lane == 0) mine[slot] = done;
         wave_lds_sync();
         cur ^= 1;
     }
     if (lane == 0) mine[slot] = 0xffffffffu;  // finished: never the one the others defer to
     __builtin_amdgcn_s_setprio(0);
+    if constexpr (kTwoLevel) {
+#pragma unroll
+        for (int k = 0; k < I; ++k) {
+            LT::set(ax[k / W], k % W, second[(0 * I + k) * 64] + LT::get(ax[k / W], k % W));
+            LT::set(ay[k / W], k % W, second[(1 * I + k) * 64] + LT::get(ay[k / W], k % W));
+            LT::set(az[k / W], k % W, second[(2 * I + k) * 64] + LT::get(az[k / W], k % W));
+        }
+    }
 #ifdef NB_STAMPS
     if (lane == 0 && s.acc != nullptr && s.finalize && !s.acc_in) {
         unsigned long long* stamps = reinterpret_cast<unsigned long long*>(s.acc) + (static_cast<size_t>(blockIdx.x) * S + wave) * 2;
@@ -588,6 +620,7 @@ template <typename T> Plan plan_fast(unsigned i_count, unsigned j_count, int cu_
     const size_t tile_bytes = 2ull * tile * 4 * sizeof(T);
     const size_t red_bytes  = static_cast<size_t>(S - 1) * 3 * I * (block / S) * sizeof(T);
     p.lds_bytes             = static_cast<unsigned>(std::max(tile_bytes, red_bytes)) + 256u;  // + the waves' progress words
+    if (sizeof(T) == 4) p.lds_bytes += static_cast<unsigned>(S) * 3 * I * 64 * sizeof(T);       // + fp32: the lanes' second-level sums
     return p;
 }
 

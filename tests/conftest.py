@@ -49,5 +49,10 @@ def load_golden(n, tag):
     return np.load(os.path.join(GOLDEN_DIR, f"shell_n{n}_{tag}.npz"), allow_pickle=False)
 
 
+def golden_steps(g):
+    """the step counts a fixture holds besides 0 (N = 4096 stops at 10 to stay small)"""
+    return sorted(int(k[4:]) for k in g.files if k.startswith("pos_") and k != "pos_0")
+
+
 def xyz(a):
     return a.reshape(-1, 4)[:, :3]

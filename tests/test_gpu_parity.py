@@ -15,7 +15,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import load_golden, xyz
+from conftest import golden_steps, load_golden, xyz
 
 pytestmark = pytest.mark.gpu
 
@@ -34,12 +34,12 @@ def run_gpu(pkg, pos0, vel0, steps, mode, dt=DT, block_size=256, params=None):
 
 # ---------------------------------------------------------------------------------------------- strict
 @pytest.mark.parametrize("tag,dtype", [("f32", np.float32), ("f64", np.float64)])
-@pytest.mark.parametrize("n", [256, 1024])
+@pytest.mark.parametrize("n", [8, 256, 1024, 4096])
 def test_strict_matches_golden_bitwise(gpu, n, tag, dtype):
     g = load_golden(n, tag)
     system = gpu.BodySystemHIP(n, 256, gpu.NBodyParams(), dtype, g["pos_0"], g["vel_0"], mode=gpu.NB_MODE_STRICT)
     done = 0
-    for s in (1, 10, 100):
+    for s in golden_steps(g):
         for _ in range(s - done):
             system.update(dtype(DT))
         done = s
@@ -81,13 +81,17 @@ def rel_err(a, b):
     return np.linalg.norm(xyz(a).astype(np.float64) - xyz(b).astype(np.float64), axis=1) / np.linalg.norm(xyz(b).astype(np.float64), axis=1)
 
 
-@pytest.mark.parametrize("n", [256, 1024])
+@pytest.mark.parametrize("n", [8, 256, 1024, 4096])
 def test_fast_fp32_vs_golden(gpu, n):
+    """FAST against the CPU path's trajectory.  Measured max / p99 / median per horizon: DESIGN.md section 5 (table from
+    tools/fast_error_table.py, profiles/round2_fast_vs_cpu_path_errors.json).  The system is chaotic: by 100 steps single
+    bodies that went through a close encounter are off by 1e-3..1e-2 (as two roundings of the CPU code itself are), so
+    the 100-step bar is on the median and the 99th percentile, not the max."""
     g = load_golden(n, "f32")
     system = gpu.BodySystemHIP(n, 256, gpu.NBodyParams(), np.float32, g["pos_0"], g["vel_0"], mode=gpu.NB_MODE_FAST)
     done = 0
     errs = {}
-    for s in (1, 10, 100):
+    for s in golden_steps(g):
         for _ in range(s - done):
             system.update(DT)
         done = s
@@ -95,16 +99,18 @@ def test_fast_fp32_vs_golden(gpu, n):
     system.free()
     assert errs[1].max() <= 2e-6, errs[1].max()
     assert errs[10].max() <= 2e-5, errs[10].max()
-    assert np.median(errs[100]) <= 1e-4, np.median(errs[100])  # the north_star figure, on the median (chaos)
+    if 100 in errs:
+        assert np.median(errs[100]) <= 1e-4, np.median(errs[100])  # the north_star figure, on the median (chaos)
+        assert np.percentile(errs[100], 99) <= 5e-3, np.percentile(errs[100], 99)  # measured 8.5e-4 (N = 1024), 2.6e-5 (N = 256)
 
 
-@pytest.mark.parametrize("n", [256, 1024])
+@pytest.mark.parametrize("n", [8, 256, 1024, 4096])
 def test_fast_fp64_vs_golden(gpu, n):
     g = load_golden(n, "f64")
     system = gpu.BodySystemHIP(n, 256, gpu.NBodyParams(), np.float64, g["pos_0"], g["vel_0"], mode=gpu.NB_MODE_FAST)
     done = 0
     errs = {}
-    for s in (1, 10, 100):
+    for s in golden_steps(g):
         for _ in range(s - done):
             system.update(np.float64(DT))
         done = s
@@ -113,7 +119,8 @@ def test_fast_fp64_vs_golden(gpu, n):
     # fp64: Newton-refined v_rsq_f64 vs the CPU's sqrt and divide
     assert errs[1].max() <= 1e-14, errs[1].max()
     assert errs[10].max() <= 1e-12, errs[10].max()
-    assert errs[100].max() <= 1e-8, errs[100].max()
+    if 100 in errs:
+        assert errs[100].max() <= 1e-8, errs[100].max()
 
 
 def gpu_accel(gpu, pos, dtype, i_begin, i_count, j_begin, j_count, mode, acc_in=None):
@@ -135,7 +142,7 @@ def gpu_accel(gpu, pos, dtype, i_begin, i_count, j_begin, j_count, mode, acc_in=
 
 @pytest.mark.parametrize("plan", [(2, 4, 256), (2, 4, 512), (2, 4, 1024), (4, 4, 256), (4, 4, 512), (4, 4, 1024),
                                   (2, 8, 512), (2, 8, 1024), (2, 8, 2048), (4, 8, 512), (4, 8, 1024), (4, 8, 2048),
-                                  (2, 16, 1024), (2, 16, 2048), (2, 16, 4096), (4, 16, 1024), (4, 16, 2048), (4, 16, 4096),
+                                  (2, 16, 1024), (2, 16, 2048), (4, 16, 1024), (4, 16, 2048),
                                   (2, 64, 512), (2, 64, 1024), (4, 64, 512), (4, 64, 1024)])  # S = 64: wave-split layout
 def test_fast_force_error_every_geometry(gpu, oracle, plan):
     """Every (bodies/lane, lane-groups, tile) instantiation against an fp64 direct sum, ragged N and ranges."""
@@ -317,15 +324,123 @@ def test_full_size_strict_bitwise_on_a_sample(gpu, O, n, dtype):
         want_p, want_v = omp.update_subset(pos0, vel0, i0, ni, DT)
         assert strict_pos[4 * i0:4 * (i0 + ni)].tobytes() == want_p.tobytes(), (n, i0)
         assert strict_vel[4 * i0:4 * (i0 + ni)].tobytes() == want_v.tobytes(), (n, i0)
-    if n > 262144:
-        return  # at 1 Mi bodies the sequential fp32 sum of the CPU path is itself off by up to ~6e-3: nothing to learn
     fast_pos, fast_vel = run_gpu(gpu, pos0, vel0, 1, gpu.NB_MODE_FAST)
+    if n > 262144:
+        # At 1 Mi bodies the CPU path's own sequential fp32 sum over 1 Mi terms is the inaccurate side (it is off from an
+        # fp64 direct sum by up to ~6e-3), so FAST is held to the fp64 direct sum instead, on sampled bodies, through the
+        # accelerations themselves (nb_integrate_shard_* without FINALIZE).  Stated tolerance: 1e-5 relative (measured
+        # max 2e-6; the 5e-6 bar of test_fast_force_error_every_geometry is for N = 3 000).
+        assert dtype == np.float32
+        gpu.set_softening_squared(np.float32(0.1) * np.float32(0.1))
+        acc = gpu_accel(gpu, pos0, np.float32, 0, n, 0, n, gpu.NB_MODE_FAST).reshape(n, 4)
+        sample = np.arange(0, n, n // 64)[:64]
+        ref = np.concatenate([omp.accel_f64(pos0, int(i), 1) for i in sample])
+        err = np.linalg.norm(acc[sample, :3] - ref, axis=1) / np.linalg.norm(ref, axis=1)
+        assert err.max() < 1e-5, err.max()
+        # and the integrated step is that acceleration: v1 = (v0 + a dt) damping, p1 = p0 + v1 dt
+        v1 = xyz(vel0)[sample].astype(np.float64) + ref * float(DT)
+        scale = np.abs(v1).max()  # |a dt| ~ |v1| here: the force tolerance carries over to the step, relative to that scale
+        np.testing.assert_allclose(xyz(fast_vel)[sample], v1, rtol=0, atol=2e-5 * scale)
+        np.testing.assert_allclose(xyz(fast_pos)[sample], xyz(pos0)[sample].astype(np.float64) + v1 * float(DT), rtol=0, atol=2e-5 * scale * float(DT) + 1e-6)
+        return
     # fp32: the gap is dominated by the CPU path's own sequential fp32 summation over N terms (error ~ sqrt(N) ulp:
-    # 1.5e-5 measured at 262 144 bodies), not by the FAST kernel, whose 16-way split sums are the more accurate ones
+    # 1.5e-5 measured at 262 144 bodies), not by the FAST kernel, whose split sums are the more accurate ones
     # (test_full_size_properties_fp32 holds FAST to an fp64 direct sum).
     tol = 6e-8 * np.sqrt(n) if dtype == np.float32 else 1e-13
     assert rel_err(fast_pos, strict_pos).max() < tol
-    del dt
+    del dt, strict_vel
+
+
+@pytest.mark.parametrize("mode_name", ["fast", "strict"])
+def test_config4_shape_one_rank_of_eight_at_1mi_bodies(gpu, O, pkg, mode_name):
+    """BASELINE config 4 (1 048 576 bodies fp32 on 8 GPUs, bodies sharded): the launches rank 4 of 8 actually issues per
+    step -- i-slice of 131 072 bodies x the j chunks of sharded.chunk_schedule chained through acc with
+    NB_SHARD_ACC_IN / NB_SHARD_FINALIZE -- on one GPU at full size.
+      FAST   (own, below, above): accelerations of 512 sampled bodies vs an fp64 direct sum (tolerance 1e-5, as at 1 Mi
+             bodies elsewhere), and the finalized slice vs the single-pass nb_integrate_f32 step of the same state;
+      STRICT (below, own, above = ascending j): finalized slice bitwise == the CPU path (oracle.update_subset) on 512
+             sampled bodies, and bitwise == the single-pass STRICT step on the whole slice."""
+    import __graft_entry__ as entry
+
+    sharded = entry.load_package_module("sharded")
+    n, world, rank = 1048576, 8, 4
+    omp = O.Oracle(openmp=True)
+    omp.set_num_threads(min(16, os.cpu_count() or 1))
+    pos0, vel0 = omp.startup_state(n, np.float32)
+    mode = gpu.NB_MODE_STRICT if mode_name == "strict" else gpu.NB_MODE_FAST
+    i0, ni = sharded.slice_of(rank, world, n)
+    assert (i0, ni) == (524288, 131072)
+    schedule = sharded.chunk_schedule(i0, ni, n, ordered=(mode == gpu.NB_MODE_STRICT))
+    assert [c[:2] for c in schedule] == ([(0, i0), (i0, ni), (i0 + ni, n - i0 - ni)] if mode == gpu.NB_MODE_STRICT else [(i0, ni), (0, i0), (i0 + ni, n - i0 - ni)])
+    lib = gpu.lib()
+    gpu.set_softening_squared(np.float32(0.1) * np.float32(0.1))
+    d_old, d_new, d_vel, d_acc = (gpu.DeviceBuffer(pos0.nbytes) for _ in range(4))
+    d_old.upload(pos0), d_vel.upload(vel0)
+
+    def run_schedule(finalize):
+        last = len(schedule) - 1
+        for k, (j0, nj, _) in enumerate(schedule):
+            flags = (gpu.NB_SHARD_ACC_IN if k else 0) | (gpu.NB_SHARD_FINALIZE if (k == last and finalize) else 0)
+            gpu.check(lib.nb_integrate_shard_f32(d_new.ptr, d_old.ptr, d_vel.ptr, d_acc.ptr, i0, ni, j0, nj, flags, DT, np.float32(1), 256, mode, None))
+
+    sample = np.concatenate([np.arange(i0, i0 + 256), np.arange(i0 + ni // 2 - 100, i0 + ni // 2 + 92), np.arange(i0 + ni - 64, i0 + ni)])  # 512 bodies
+    if mode == gpu.NB_MODE_FAST:
+        run_schedule(finalize=False)
+        acc = d_acc.download(np.zeros(4 * n, np.float32)).reshape(n, 4)
+        ref = np.concatenate([omp.accel_f64(pos0, int(a), int(b - a)) for a, b in ((i0, i0 + 256), (i0 + ni // 2 - 100, i0 + ni // 2 + 92), (i0 + ni - 64, i0 + ni))])
+        err = np.linalg.norm(acc[sample, :3] - ref, axis=1) / np.linalg.norm(ref, axis=1)
+        assert err.max() < 1e-5, err.max()
+        assert not acc[:i0].any() and not acc[i0 + ni:].any()  # only the rank's slice is written
+    run_schedule(finalize=True)
+    gpu.check(lib.nb_device_synchronize())
+    new_pos = d_new.download(np.zeros(4 * n, np.float32)).reshape(n, 4)[i0:i0 + ni].copy()
+    new_vel = d_vel.download(np.zeros(4 * n, np.float32)).reshape(n, 4)[i0:i0 + ni].copy()
+    # the single-pass step of the same state (what one GPU alone computes)
+    d_vel.upload(vel0)
+    gpu.check(lib.nb_integrate_f32(d_new.ptr, d_old.ptr, d_vel.ptr, DT, np.float32(1), n, 256, mode, None))
+    one_pos = d_new.download(np.zeros(4 * n, np.float32)).reshape(n, 4)[i0:i0 + ni].copy()
+    one_vel = d_vel.download(np.zeros(4 * n, np.float32)).reshape(n, 4)[i0:i0 + ni].copy()
+    for b in (d_old, d_new, d_vel, d_acc):
+        b.free()
+    if mode == gpu.NB_MODE_STRICT:
+        assert new_pos.tobytes() == one_pos.tobytes() and new_vel.tobytes() == one_vel.tobytes()
+        for a, b in ((i0, i0 + 256), (i0 + ni // 2 - 100, i0 + ni // 2 + 92), (i0 + ni - 64, i0 + ni)):
+            want_p, want_v = omp.update_subset(pos0, vel0, a, b - a, DT)
+            assert new_pos[a - i0:b - i0].tobytes() == want_p.reshape(-1, 4).tobytes(), (a, b)
+            assert new_vel[a - i0:b - i0].tobytes() == want_v.reshape(-1, 4).tobytes(), (a, b)
+    else:
+        # three partial sums chained through acc instead of one pass: rounding-level differences only
+        vscale, pscale = np.abs(one_vel[:, :3]).max(), np.abs(one_pos[:, :3]).max()
+        # both are within the 1e-5 force tolerance of the exact step (|a dt| ~ |v| here), so within 1e-5 of each other
+        assert np.abs(new_vel[:, :3] - one_vel[:, :3]).max() <= 1e-5 * vscale, (np.abs(new_vel[:, :3] - one_vel[:, :3]).max(), vscale)
+        assert np.abs(new_pos[:, :3] - one_pos[:, :3]).max() <= 1e-5 * vscale * float(DT) + 1e-6 * pscale
+        assert np.all(new_pos[:, 3] == 1) and np.all(new_vel[:, 3] == 0)
+
+
+def test_graph_is_rebuilt_when_params_change(gpu, oracle):
+    """the captured step loop bakes damping and softening^2 in as kernel arguments, so update_params() must
+    not replay the old graph.  Replay, change both, replay again == eager steps with the same sequence of parameters."""
+    n = 1536
+    pos0, vel0 = oracle.startup_state(n, np.float32)
+    first, second = gpu.NBodyParams(softening=0.1, damping=1.0), gpu.NBodyParams(softening=1.0, damping=0.9)
+    for mode in (gpu.NB_MODE_STRICT, gpu.NB_MODE_FAST):
+        eager = gpu.BodySystemHIP(n, 256, first, np.float32, pos0, vel0, mode=mode)
+        graph = gpu.BodySystemHIP(n, 256, first, np.float32, pos0, vel0, mode=mode)
+        for _ in range(4):
+            eager.update(DT)
+        graph.update_many(DT, 4)
+        eager.update_params(second), graph.update_params(second)
+        for _ in range(4):
+            eager.update(DT)
+        graph.update_many(DT, 4)  # same dt / steps / read index / mode as the first replay: only the params differ
+        assert graph.get_position().tobytes() == eager.get_position().tobytes()
+        assert graph.get_velocity().tobytes() == eager.get_velocity().tobytes()
+        if mode == gpu.NB_MODE_STRICT:
+            ref_p, ref_v = pos0.copy(), vel0.copy()
+            oracle.update(ref_p, ref_v, DT, steps=4, softening=0.1, damping=1.0)
+            oracle.update(ref_p, ref_v, DT, steps=4, softening=1.0, damping=0.9)
+            assert graph.get_position().tobytes() == ref_p.tobytes()
+        eager.free(), graph.free()
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])

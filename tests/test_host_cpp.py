@@ -33,6 +33,8 @@ def host():
     lib.nbh_read_tipsy.restype = ctypes.c_long
     lib.nbh_write_tipsy.argtypes = [ctypes.c_char_p, f64p, f64p, ctypes.c_size_t, ctypes.c_int]
     lib.nbh_precision_switch_roundtrip.argtypes = [ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_int, f32p, f64p, f32p]
+    lib.nbh_compare_results.argtypes = [ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_double]
+    lib.nbh_run_demo.argtypes = [ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, f32p]
     return lib
 
 
@@ -112,7 +114,8 @@ def test_cli_argument_handling_without_gpu():
     # exit codes: help 0, bad CLI 1, invalid_argument 1   (nbody.cpp:332-338,396-408)
     r = run_cli("--help")
     assert r.returncode == 0 and "--numbodies" in r.stdout and "--blockSize" in r.stdout
-    for bad in (["--bogus"], ["--numbodies=0"], ["--numbodies"], ["--mode=turbo"], ["--tipsy=/no/such/file"], ["--benchmark=1"], ["stray"]):
+    for bad in (["--bogus"], ["--numbodies=0"], ["--numbodies"], ["--mode=turbo"], ["--tipsy=/no/such/file"], ["--benchmark=1"], ["stray"], ["--demo=7"], ["--demo"],
+                ["--inject-error=abc"]):
         r = run_cli(*bad)
         assert r.returncode == 1, bad
         assert "CRITICAL ERROR" in r.stderr
@@ -155,8 +158,68 @@ def test_cli_compare_passes(extra):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("fp64", [0, 1])
+def test_compare_can_fail(host, fp64):
+    """--compare is a check, so it must be able to fail (compute_cuda.cpp:310-323, exit code nbody.cpp:375-379): the same
+    state passes untouched, and fails -- with the reference's "Error:" line and exit code 1 -- once the FAST result is
+    perturbed by more than the 5e-4 tolerance; a perturbation inside the tolerance still passes."""
+    assert host.nbh_compare_results(2048, fp64, 0, 0.0) == 1
+    assert host.nbh_compare_results(2048, fp64, 0, 4.0e-4) == 1
+    assert host.nbh_compare_results(2048, fp64, 0, 6.0e-4) == 0
+    assert host.nbh_compare_results(2048, fp64, 1, -1.0e-3) == 0  # mapped host memory variant
+    flags = ["--fp64"] if fp64 else []
+    r = run_cli("--compare", "--numbodies=1024", "--inject-error=0.001", *flags)
+    assert r.returncode == 1 and "Error: (strict)" in r.stdout and "  OK" not in r.stdout
+    r = run_cli("--qatest", "--numbodies=1024", "--inject-error=0.0001", *flags)
+    assert r.returncode == 0 and "  OK" in r.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("demo", range(7))
+def test_demo_sets_strict_bitwise(host, oracle, O, demo):
+    """Compute::select_demo (compute.cpp:156-187, table compute.hpp:90-97) through the reference-shaped stack, STRICT, 5
+    steps: bit-identical to the CPU path run with THAT row's dt / softening / damping from the bodies the row's scales
+    draw.  rand() stream: three start-up resets, then the reset select_demo itself does (fourth segment)."""
+    n, steps = 1024, 5
+    rows = [(0.016, 1.54, 8.0, 0.1, 1.0), (0.016, 0.68, 20.0, 0.1, 1.0), (0.0006, 0.16, 1000.0, 1.0, 1.0), (0.0006, 0.16, 1000.0, 1.0, 1.0),
+            (0.0019, 0.32, 276.0, 1.0, 1.0), (0.0016, 0.32, 272.0, 0.145, 1.0), (0.016, 6.04, 0.0, 1.0, 1.0)]
+    dt, cluster, velocity, softening, damping = rows[demo]
+    out = np.zeros(8 * n, np.float32)
+    host.nbh_srand(1)
+    assert host.nbh_run_demo(n, demo, 0, steps, out.ctypes.data_as(ctypes.POINTER(ctypes.c_float))) == 0
+    oracle.startup_state(n, np.float32)  # consumes the three start-up segments
+    pos, vel = oracle.randomise(O.NBODY_CONFIG_SHELL, n, cluster, velocity, np.float32)
+    oracle.update(pos, vel, np.float32(dt), steps=steps, softening=softening, damping=damping)
+    assert out[:4 * n].tobytes() == pos.tobytes()
+    assert out[4 * n:].tobytes() == vel.tobytes()
+
+
+@pytest.mark.gpu
+def test_cli_demo_and_config_runs_bitwise(tmp_path, oracle, O):
+    """`--demo=k` and `--config=random|expand` through the command line, STRICT: the dumps equal the CPU path's."""
+    n = 512
+    dump = tmp_path / "demo.bin"
+    r = run_cli(f"--numbodies={n}", "--mode=strict", "--demo=5", "--steps=4", f"--dump={dump}")
+    assert r.returncode == 0, r.stderr
+    oracle.startup_state(n, np.float32)
+    pos, vel = oracle.randomise(O.NBODY_CONFIG_SHELL, n, 0.32, 272.0, np.float32)
+    oracle.update(pos, vel, np.float32(0.0016), steps=4, softening=0.145, damping=1.0)
+    raw = np.fromfile(dump, dtype=np.float32)
+    assert raw[:4 * n].tobytes() == pos.tobytes() and raw[4 * n:].tobytes() == vel.tobytes()
+    for cfg, code in (("random", O.NBODY_CONFIG_RANDOM), ("expand", O.NBODY_CONFIG_EXPAND)):
+        for flags, dtype in (([], np.float32), (["--fp64"], np.float64)):
+            dump = tmp_path / f"{cfg}{len(flags)}.bin"
+            r = run_cli(f"--numbodies={n}", "--mode=strict", f"--config={cfg}", "--steps=3", f"--dump={dump}", *flags)
+            assert r.returncode == 0, r.stderr
+            pos, vel = oracle.startup_state(n, dtype, config=code)
+            oracle.update(pos, vel, np.float32(0.016), steps=3)
+            raw = np.fromfile(dump, dtype=dtype)
+            assert raw[:4 * n].tobytes() == pos.tobytes() and raw[4 * n:].tobytes() == vel.tobytes(), (cfg, flags)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("tag,dtype,flags", [("f32", np.float32, []), ("f64", np.float64, ["--fp64"]), ("f32", np.float32, ["--hostmem"])])
-@pytest.mark.parametrize("n", [256, 1024])
+@pytest.mark.parametrize("n", [256, 1024, 4096])
 def test_cli_strict_run_reproduces_golden(tmp_path, n, tag, dtype, flags):
     """A fresh `nbody --numbodies=N --mode=strict --steps=10` process == the CPU path's 10-step trajectory, bitwise:
     exercises the rand() start-up sequence (three resets), the N-scaled params and the strict kernels through the CLI."""

@@ -3,7 +3,7 @@ against the committed golden vectors, against an independent numpy restatement, 
 import numpy as np
 import pytest
 
-from conftest import load_golden
+from conftest import golden_steps, load_golden
 
 DT = np.float32(0.016)
 
@@ -34,13 +34,13 @@ def test_randomise_matches_reference_build(O, oracle, dtype, config):
 
 
 @pytest.mark.parametrize("tag,dtype", [("f32", np.float32), ("f64", np.float64)])
-@pytest.mark.parametrize("n", [256, 1024])
+@pytest.mark.parametrize("n", [8, 256, 1024, 4096])
 def test_oracle_reproduces_golden(oracle, n, tag, dtype):
     g = load_golden(n, tag)
     pos, vel = oracle.startup_state(n, dtype)
     assert pos.tobytes() == g["pos_0"].tobytes() and vel.tobytes() == g["vel_0"].tobytes()
     done = 0
-    for s in (1, 10, 100):
+    for s in golden_steps(g):
         oracle.update(pos, vel, DT, steps=s - done)
         done = s
         assert pos.tobytes() == g[f"pos_{s}"].tobytes(), f"positions differ at step {s}"
