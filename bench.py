@@ -51,9 +51,11 @@ def parse_args():
     ap.add_argument("--cpu-sample-bodies", type=int, default=0, help="bodies i in the CPU sample (0 = auto, ~10 s)")
     ap.add_argument("--sweep", action="store_true", help="time every fast-kernel geometry (tuning aid), N=1 only")
     ap.add_argument("--plan", type=str, default="", help="I,S,TILE override for the fast kernel, e.g. 2,1,1024")
-    ap.add_argument("--exchange", choices=["rccl", "host"], default="rccl",
-                    help="host: gloo + host-staged all-gather, so that several ranks can share ONE GPU (functional rehearsal of the "
-                         "N-rank code path on a one-GPU box; RCCL refuses two ranks per device).  Never a performance number.")
+    ap.add_argument("--exchange", choices=["rccl", "allgather", "host"], default="rccl",
+                    help="rccl: the position all-gather issued as its G-1 tiles (one grouped RCCL send/recv pair per round, the kernel "
+                         "of tile k waiting only on round k); allgather: one all_gather_into_tensor per step; "
+                         "host: gloo + host-staged all-gather, so that several ranks can share ONE GPU (functional rehearsal of the "
+                         "N-rank code path on a one-GPU box; RCCL refuses two ranks per device).  host is never a performance number.")
     ap.add_argument("--emulate-gpus", type=int, default=0,
                     help="on ONE GPU, run rank 0's kernel schedule of a G-rank strong-scaling job (no collective): "
                          "projection aid, prints its own JSON and never the headline metric")
@@ -78,10 +80,39 @@ def self_launch(n_ranks: int) -> int:
 
 
 def make_bodies(n: int, dtype):
-    """The reference's start-up bodies (SHELL, rand() third segment) -- generated by the oracle's pinned
-    randomise_bodies restatement; "synthetic random bodies" of BASELINE.json."""
-    O = entry.load_oracle()
-    return O.Oracle().startup_state(n, dtype)
+    """The bodies a fresh `nbody --numbodies=N [--fp64]` process starts from, drawn by the PRODUCT's randomise_bodies
+    (libnbody_host.so, pinned bit-for-bit to the reference's own code in tests/test_host_cpp.py): SHELL configuration,
+    third segment of the unseeded rand() stream (fp32 reset, fp64 reset with demo_params[0] scales, then the active
+    precision with the N-scaled params).  "synthetic random bodies" of BASELINE.json."""
+    host = ctypes.CDLL(os.path.join(ROOT, "cuda-nbody_amd", "libnbody_host.so"))
+    f32p, f64p = ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_double)
+    host.nbh_srand.argtypes = [ctypes.c_uint]
+    host.nbh_randomise_f32.argtypes = [ctypes.c_int, f32p, f32p, ctypes.c_size_t, ctypes.c_float, ctypes.c_float]
+    host.nbh_randomise_f64.argtypes = [ctypes.c_int, f64p, f64p, ctypes.c_size_t, ctypes.c_float, ctypes.c_float]
+    host.nbh_scale_params_for.argtypes = [ctypes.c_size_t, f32p, f32p]
+    shell = 1  # NBodyConfig::NBODY_CONFIG_SHELL
+
+    def draw(T, cluster, velocity):
+        pos, vel = np.zeros(4 * n, T), np.zeros(4 * n, T)
+        if T == np.float32:
+            host.nbh_randomise_f32(shell, pos.ctypes.data_as(f32p), vel.ctypes.data_as(f32p), n, cluster, velocity)
+        else:
+            host.nbh_randomise_f64(shell, pos.ctypes.data_as(f64p), vel.ctypes.data_as(f64p), n, cluster, velocity)
+        return pos, vel
+
+    host.nbh_srand(1)
+    draw(np.float32, 1.54, 8.0)
+    draw(np.float64, 1.54, 8.0)
+    c, v = ctypes.c_float(1.54), ctypes.c_float(8.0)
+    host.nbh_scale_params_for(n, ctypes.byref(c), ctypes.byref(v))
+    return draw(dtype, c.value, v.value)
+
+
+# What the instruction mix of the production loop can do at best on this chip: the unit-mass inner loop run in isolation
+# (tools/loop_microbench_gen.py, profiles/round2_loop_microbench.txt) sustains one packed interaction pair per 61.5 SIMD cycles
+# with 3-4 runnable waves (11 v_pk_* at ~4 cycles + 2 v_rsq_f32 at ~8.3); at the nominal 2.4 GHz that is
+# 1024 SIMDs x 128 interactions / 61.5 cycles = 5.115e12 interactions/s = 65.0 % of the 157.3 TFLOP/s "20 flop" roofline.
+FP32_ISSUE_CEILING_INTERACTIONS_PER_S = 1024 * 128 * 2.4e9 / 61.5
 
 
 def main():
@@ -172,14 +203,22 @@ def main():
                 full.copy_(staged)
                 return _Done()
 
-        system = sharded.ShardedBodySystem(pos_t, vel_t, launch, ordered=(mode == pkg.NB_MODE_STRICT), gather=host_gather)
+        form = "tiles" if args.exchange == "rccl" else "allgather"
+        system = sharded.ShardedBodySystem(pos_t, vel_t, launch, ordered=(mode == pkg.NB_MODE_STRICT), gather=host_gather, exchange=form)
         step = system.update
         finish = system.finish
         if world > 1:
             # bring RCCL's all-gather path up (communicator, channels, first-call setup) outside any timed step, whatever
             # --warmup says; every rank holds identical positions at this point, so gathering them is a no-op on the data
-            first = system._gather(system.pos[0], system.pos[0][system.i0:system.i0 + system.ni])
-            first.wait()
+            try:
+                system.exchange_once(system.pos[0])
+            except RuntimeError as exc:  # the tile form could not be brought up: say so and use the single collective
+                if system.exchange != "tiles":
+                    raise
+                print(f"[bench rank {rank}] tile exchange failed at bring-up ({exc!r}); falling back to one all-gather per step", file=sys.stderr, flush=True)
+                system = sharded.ShardedBodySystem(pos_t, vel_t, launch, ordered=(mode == pkg.NB_MODE_STRICT), exchange="allgather")
+                step, finish = system.update, system.finish
+                system.exchange_once(system.pos[0])
             torch.cuda.synchronize()
     else:
         bufs = [pos_t, pos_t.clone()]
@@ -316,7 +355,7 @@ def main():
     launches = kernel_launches[0] - launches_before
 
     if distributed:
-        t = torch.tensor([elapsed], device=dev if args.exchange == "rccl" else "cpu", dtype=torch.float64)
+        t = torch.tensor([elapsed], device=dev if args.exchange != "host" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -333,6 +372,8 @@ def main():
         # HBM traffic cannot be counted from inside this process: it comes from the separate rocprofv3 --pmc passes
         # of this same command (tools/profile.sh -> tools/summarize_prof.py), committed under profiles/.
         traffic, traffic_src = None, None
+        plan_now = {"bodies_per_lane": plan.bodies_per_lane, "lane_groups": plan.lanes_per_body, "lds_tile_bodies": plan.tile_bodies,
+                    "grid": plan.grid_blocks, "lds_bytes": plan.lds_bytes}
         if world == 1 and args.mode == "fast":
             import glob
 
@@ -340,8 +381,12 @@ def main():
             found = sorted(glob.glob(os.path.join(ROOT, "profiles", f"round*_{tag}_pmc_summary.json")))
             if found:
                 with open(found[-1]) as fh:
-                    traffic = json.load(fh)["derived"].get("hbm_bytes_per_launch")
-                traffic_src = os.path.relpath(found[-1], ROOT)
+                    summary = json.load(fh)
+                if summary.get("kernel_plan") == plan_now:  # counters of another geometry say nothing about this run
+                    traffic = summary["derived"].get("hbm_bytes_per_launch")
+                    traffic_src = os.path.relpath(found[-1], ROOT)
+                else:
+                    traffic_src = f"{os.path.relpath(found[-1], ROOT)} was taken with another launch plan: re-run tools/profile.sh"
         line = {
             "metric": "body-body interactions/s, all-pairs N-body step (reference convention N^2 per step)",
             "value": value,
@@ -360,10 +405,12 @@ def main():
                             f"{'fp64' if args.fp64 else 'fp32'}, dt 0.016, softening 0.1, damping 1.0, mode {args.mode}",
                 "bodies": n,
                 "bodies_per_gpu": n // world,
-                "exchange": "none" if world == 1 else ("RCCL all-gather of new positions per step, overlapped with the own-slice j chunk"
-                                                       if args.exchange == "rccl" else "REHEARSAL: gloo, host-staged gather, ranks share one GPU"),
-                "kernel_plan": {"bodies_per_lane": plan.bodies_per_lane, "lane_groups": plan.lanes_per_body,
-                                "lds_tile_bodies": plan.tile_bodies, "grid": plan.grid_blocks, "lds_bytes": plan.lds_bytes},
+                "exchange": "none" if world == 1 else (
+                    "REHEARSAL: gloo, host-staged gather, ranks share one GPU" if args.exchange == "host" else
+                    "RCCL all-gather of the new positions per step, issued as G-1 position tiles (grouped send/recv rounds on RCCL's stream); "
+                    "the kernel of tile k waits only on round k, the own-slice chunk runs first" if system.exchange == "tiles" else
+                    "RCCL all_gather_into_tensor of the new positions per step, overlapped with the own-slice j chunk"),
+                "kernel_plan": plan_now,
                 "device": info.name.decode(),
                 "arch": info.arch.decode(),
             },
@@ -377,6 +424,10 @@ def main():
                 "frac": achieved_tflops / peak,
                 "traffic": traffic,  # HBM bytes per launch, rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes (tools/profile.sh)
                 "traffic_source": traffic_src,
+                # achieved / what this instruction mix can issue at best on the chip (see FP32_ISSUE_CEILING_...): how close
+                # the kernel is to ITS ceiling; `frac` above is against the nominal "20 flop" peak
+                "issue_ceiling_frac": (value / world / FP32_ISSUE_CEILING_INTERACTIONS_PER_S) if not args.fp64 else None,
+                "issue_ceiling_interactions_per_s": FP32_ISSUE_CEILING_INTERACTIONS_PER_S if not args.fp64 else None,
                 "kernel_ms": ms_per_launch,
                 "algorithmic_flops_per_launch": flops_per * per_launch_interactions,
                 "algorithmic_hbm_bytes_per_launch": (128 if args.fp64 else 64) * (n // world),
@@ -385,7 +436,9 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             O = entry.load_oracle()
             orc1 = O.Oracle()
-            pos_h, _ = orc1.startup_state(n, dtype)
+            pos_h, vel_h = orc1.startup_state(n, dtype)
+            # the workload above came from the product's randomise_bodies; the checker's must be the same bytes
+            assert pos_h.tobytes() == pos0.tobytes() and vel_h.tobytes() == vel0.tobytes(), "product and oracle start-up bodies differ"
             sample = args.cpu_sample_bodies or max(8, min(n, int(2.0e10 // n) // 8 * 8))
             base = {}
             # OpenMP leg: the reference's fp32 loop forks INSIDE the j loop (bodysystemcpu.cpp:156-168), i.e. one
@@ -421,7 +474,7 @@ def main():
             fence()
             t1 = time.perf_counter()
             for _ in range(10):
-                system._gather(full, own).wait()
+                system.exchange_once(full)
             torch.cuda.synchronize()
             exchange_ms = (time.perf_counter() - t1) / 10 * 1e3
             fence()

@@ -107,6 +107,21 @@ SIGNATURES = {
     "nb_graph_create_f64": (_ci, [_P(_vp), _vp, _vp, _vp, _cd, _cd, _cu, _ci, _ci, _cu]),
     "nb_graph_launch": (_ci, [_vp, _vp]),
     "nb_graph_destroy": (_ci, [_vp]),
+    "nb_comm_unique_id": (_ci, [_vp]),
+    "nb_comm_init_rank": (_ci, [_P(_vp), _vp, _ci, _ci]),
+    "nb_comm_init_all": (_ci, [_P(_vp), _ci, _P(_ci)]),
+    "nb_comm_destroy": (_ci, [_vp]),
+    "nb_comm_info": (_ci, [_vp, _P(_ci), _P(_ci), _P(_ci)]),
+    "nb_sharded_step_f32": (_ci, [_vp, _vp, _vp, _vp, _vp, _cu, _cf, _cf, _ci, _ci, _vp]),
+    "nb_sharded_step_f64": (_ci, [_vp, _vp, _vp, _vp, _vp, _cu, _cd, _cd, _ci, _ci, _vp]),
+    "nb_sharded_step_all_f32": (_ci, [_P(_vp), _ci, _P(_vp), _P(_vp), _P(_vp), _P(_vp), _cu, _cf, _cf, _ci, _ci, _P(_vp)]),
+    "nb_sharded_step_all_f64": (_ci, [_P(_vp), _ci, _P(_vp), _P(_vp), _P(_vp), _P(_vp), _cu, _cd, _cd, _ci, _ci, _P(_vp)]),
+    "nb_exchange_tiles_f32": (_ci, [_vp, _vp, _cu, _vp]),
+    "nb_exchange_tiles_f64": (_ci, [_vp, _vp, _cu, _vp]),
+    "nb_allgather_f32": (_ci, [_vp, _vp, _cu, _vp]),
+    "nb_allgather_f64": (_ci, [_vp, _vp, _cu, _vp]),
+    "nb_exchange_wait_tile": (_ci, [_vp, _ci, _vp]),
+    "nb_exchange_wait_all": (_ci, [_vp, _vp]),
     "nb_plan_f32": (_ci, [_cu, _cu, _P(LaunchPlan)]),
     "nb_plan_f64": (_ci, [_cu, _cu, _P(LaunchPlan)]),
     "nb_set_plan_override": (_ci, [_ci, _ci, _ci]),

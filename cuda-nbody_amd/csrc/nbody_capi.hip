@@ -6,6 +6,7 @@
 #include "../../include/nbody_hip.h"
 
 #include "nbody_kernels.h"
+#include "rand_stream_guard.h"
 
 #include <atomic>
 #include <cstdint>
@@ -22,38 +23,6 @@ std::atomic<double> g_softening_sq_f64{0.0};
 
 std::atomic<int> g_ovr_i{0}, g_ovr_s{0}, g_ovr_tile{0};
 
-// The reference's initial conditions are drawn from the process-global libc rand() stream
-// (randomise_bodies.cpp:37-43), so a drop-in must not disturb that stream.  The HIP runtime does: its first
-// pageable host-to-device copy consumes rand() draws (tools/rand_probe.cpp).  Every entry point that reaches
-// the runtime therefore parks the caller's random()/rand() state and lends the runtime a scratch one.
-// initstate/setstate swap a process-global pointer, so the swap-call-restore sequence is serialised across threads.
-class RandStreamGuard {
- public:
-    RandStreamGuard() : lock_(mutex()) {
-        static char scratch[128];
-        static bool seeded = false;
-        if (!seeded) {
-            prev_  = initstate(0x9e3779b9u, scratch, sizeof(scratch));
-            seeded = true;
-        } else {
-            prev_ = setstate(scratch);
-        }
-    }
-    ~RandStreamGuard() {
-        if (prev_ != nullptr) (void)setstate(prev_);
-    }
-    RandStreamGuard(const RandStreamGuard&)            = delete;
-    RandStreamGuard& operator=(const RandStreamGuard&) = delete;
-
- private:
-    static std::recursive_mutex& mutex() {
-        static std::recursive_mutex m;  // recursive: nb_graph_create_* calls the launch path under its own guard
-        return m;
-    }
-    std::lock_guard<std::recursive_mutex> lock_;
-    char*                       prev_ = nullptr;
-};
-#define NB_KEEP_RAND_STREAM RandStreamGuard nb_rand_stream_guard_
 
 int cu_count_cached() {
     static std::atomic<int> cached[64] = {};
@@ -170,6 +139,12 @@ const char* nb_error_string(int code) {
         case 0: return "success";
         case NB_ERR_INVALID_ARGUMENT: return "NB_ERR_INVALID_ARGUMENT";
         case NB_ERR_UNSUPPORTED: return "NB_ERR_UNSUPPORTED";
+        case NB_ERR_RCCL_BASE + 1: return "RCCL: unhandled HIP error";
+        case NB_ERR_RCCL_BASE + 2: return "RCCL: system error";
+        case NB_ERR_RCCL_BASE + 3: return "RCCL: internal error";
+        case NB_ERR_RCCL_BASE + 4: return "RCCL: invalid argument";
+        case NB_ERR_RCCL_BASE + 5: return "RCCL: invalid usage";
+        case NB_ERR_RCCL_BASE + 6: return "RCCL: remote error";
         default: return hipGetErrorName(static_cast<hipError_t>(code));
     }
 }

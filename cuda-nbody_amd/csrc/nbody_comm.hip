@@ -1,0 +1,418 @@
+// nbody_comm.hip -- multi-GPU body sharding behind the C-ABI (include/nbody_hip.h, section "multi-GPU").  gfx950 only.
+//
+// New design: the reference is single-GPU (no NCCL / peer copies anywhere in /root/reference).  Rank r of
+// G owns the contiguous slice of bodies [r*N/G, (r+1)*N/G): their velocities and their slice of each new position
+// array; every array is full-size and indexed by global body id.  The one exchange step of the path is the all-gather of
+// the new positions, issued as its G-1 position TILES over RCCL (= xGMI inside a node): in round s = 1..G-1 every rank
+// sends its slice to rank r-s and receives the slice of rank r+s -- one grouped ncclSend/ncclRecv pair per round on the
+// communicator's own high-priority stream, an event after each round.  Accumulation is additive over j chunks, so a
+// step starts with the chunk that is already local (j in the rank's own slice) and then takes the tiles in arrival order,
+// the kernel of tile k waiting only for round k: the exchange of tile k+1 runs under the force compute of tile k.
+// STRICT keeps the CPU path's summation order (ascending j): tiles in rank order, each waiting for its own round,
+// bit-identical to one GPU.
+//
+// Two process models, one code path: one process per GPU (nb_comm_init_rank; a group of 1 local rank) or one process
+// driving several GPUs (nb_comm_init_all; every RCCL round is then one ncclGroup over the local ranks).
+// RCCL is dlopen'ed on first use (librccl.so.1): a single-GPU run never pays for loading it, and inside a torch process
+// the copy torch already loaded is the one that gets bound (same SONAME).
+#include "../../include/nbody_hip.h"
+
+#include "rand_stream_guard.h"
+
+#include <hip/hip_runtime.h>
+
+#include <dlfcn.h>
+
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+namespace {
+
+// ---- the few RCCL entry points used, resolved at run time (declarations as in /opt/rocm/include/rccl/rccl.h) ----------
+using ncclComm_t = struct ncclComm*;
+struct ncclUniqueId {
+    char internal[128];
+};
+static_assert(sizeof(ncclUniqueId) == NB_COMM_ID_BYTES, "nb_comm_unique_id hands out exactly one ncclUniqueId");
+enum { ncclFloat32 = 7, ncclFloat64 = 8 };
+
+struct Rccl {
+    void* handle = nullptr;
+    int (*GetUniqueId)(ncclUniqueId*)                                                    = nullptr;
+    int (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int)                             = nullptr;
+    int (*CommInitAll)(ncclComm_t*, int, const int*)                                     = nullptr;
+    int (*CommDestroy)(ncclComm_t)                                                       = nullptr;
+    int (*Send)(const void*, size_t, int, int, ncclComm_t, hipStream_t)                  = nullptr;
+    int (*Recv)(void*, size_t, int, int, ncclComm_t, hipStream_t)                        = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, ncclComm_t, hipStream_t)           = nullptr;
+    int (*GroupStart)()                                                                  = nullptr;
+    int (*GroupEnd)()                                                                    = nullptr;
+    const char* (*GetErrorString)(int)                                                   = nullptr;
+};
+
+Rccl* rccl() {
+    static Rccl           lib;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        // The RCCL to bind is the one that belongs to the HIP runtime this process already runs on: a torch process carries
+        // its own copies of both (torch/lib), a plain process the ones under /opt/rocm; the two generations do not mix.
+        std::string beside_hip;
+        Dl_info     info{};
+        if (dladdr(reinterpret_cast<const void*>(&hipGetDeviceCount), &info) != 0 && info.dli_fname != nullptr) {
+            beside_hip = info.dli_fname;
+            const auto slash = beside_hip.rfind('/');
+            beside_hip       = slash == std::string::npos ? std::string() : beside_hip.substr(0, slash + 1);
+        }
+        const std::string a = beside_hip.empty() ? std::string() : beside_hip + "librccl.so.1", b = beside_hip.empty() ? std::string() : beside_hip + "librccl.so";
+        const char* override_path = std::getenv("NBODY_RCCL_LIB");
+        for (const char* name : {override_path, a.empty() ? nullptr : a.c_str(), b.empty() ? nullptr : b.c_str(), "librccl.so.1", "/opt/rocm/lib/librccl.so.1"}) {
+            if (name == nullptr) continue;
+            lib.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (lib.handle != nullptr) break;
+        }
+        if (lib.handle == nullptr) return;
+        auto sym = [](const char* n) { return dlsym(lib.handle, n); };
+        lib.GetUniqueId    = reinterpret_cast<decltype(lib.GetUniqueId)>(sym("ncclGetUniqueId"));
+        lib.CommInitRank   = reinterpret_cast<decltype(lib.CommInitRank)>(sym("ncclCommInitRank"));
+        lib.CommInitAll    = reinterpret_cast<decltype(lib.CommInitAll)>(sym("ncclCommInitAll"));
+        lib.CommDestroy    = reinterpret_cast<decltype(lib.CommDestroy)>(sym("ncclCommDestroy"));
+        lib.Send           = reinterpret_cast<decltype(lib.Send)>(sym("ncclSend"));
+        lib.Recv           = reinterpret_cast<decltype(lib.Recv)>(sym("ncclRecv"));
+        lib.AllGather      = reinterpret_cast<decltype(lib.AllGather)>(sym("ncclAllGather"));
+        lib.GroupStart     = reinterpret_cast<decltype(lib.GroupStart)>(sym("ncclGroupStart"));
+        lib.GroupEnd       = reinterpret_cast<decltype(lib.GroupEnd)>(sym("ncclGroupEnd"));
+        lib.GetErrorString = reinterpret_cast<decltype(lib.GetErrorString)>(sym("ncclGetErrorString"));
+        if (!lib.GetUniqueId || !lib.CommInitRank || !lib.CommInitAll || !lib.CommDestroy || !lib.Send || !lib.Recv || !lib.AllGather || !lib.GroupStart || !lib.GroupEnd) {
+            dlclose(lib.handle);
+            lib.handle = nullptr;
+        }
+    });
+    return lib.handle != nullptr ? &lib : nullptr;
+}
+
+// ---- one local rank ------------------------------------------------------------------------------------------------------
+struct Comm {
+    ncclComm_t  nccl   = nullptr;
+    int         rank   = 0;
+    int         world  = 1;
+    int         device = 0;
+    hipStream_t stream = nullptr;          // the exchange runs here (high priority: its few workgroups must not queue behind a force kernel)
+    hipEvent_t  ready  = nullptr;          // "what the exchange has to wait for has been enqueued" (recorded on the compute stream)
+    std::vector<hipEvent_t> arrived;       // [world]: arrived[p] = the round that brings rank p's tile is done
+    const void* in_flight = nullptr;       // the array whose tiles are (or were last) being exchanged
+    std::vector<Comm*> group;              // all local ranks of this communicator (just {this} with one process per GPU)
+};
+
+inline Comm* as_comm(nb_comm_t c) { return static_cast<Comm*>(c); }
+inline int   nccl_status(int r) { return r == 0 ? 0 : NB_ERR_RCCL_BASE + r; }
+
+class DeviceScope {  // switch device for a few calls, restore on exit (single-process multi-GPU)
+ public:
+    explicit DeviceScope(int device) {
+        (void)hipGetDevice(&saved_);
+        if (saved_ != device) (void)hipSetDevice(device);
+    }
+    ~DeviceScope() {
+        int now = 0;
+        (void)hipGetDevice(&now);
+        if (now != saved_) (void)hipSetDevice(saved_);
+    }
+
+ private:
+    int saved_ = 0;
+};
+
+int make_resources(Comm* c) {
+    DeviceScope scope(c->device);
+    int         lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);  // "greatest" priority is the numerically lowest
+    auto err = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, hi);
+    if (err != hipSuccess) return static_cast<int>(err);
+    err = hipEventCreateWithFlags(&c->ready, hipEventDisableTiming);
+    if (err != hipSuccess) return static_cast<int>(err);
+    c->arrived.assign(static_cast<size_t>(c->world), nullptr);
+    for (auto& e : c->arrived) {
+        err = hipEventCreateWithFlags(&e, hipEventDisableTiming);
+        if (err != hipSuccess) return static_cast<int>(err);
+    }
+    return 0;
+}
+
+void free_resources(Comm* c) {
+    DeviceScope scope(c->device);
+    for (auto e : c->arrived)
+        if (e) (void)hipEventDestroy(e);
+    if (c->ready) (void)hipEventDestroy(c->ready);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+}
+
+// The G-1 rounds for every local rank of a communicator.  `bytes_per_body` = 4 * sizeof(T).
+int exchange_tiles(const std::vector<Comm*>& locals, void* const* positions, unsigned num_bodies, size_t bytes_per_body, int nccl_type, const hipStream_t* after) {
+    Rccl* lib = rccl();
+    if (lib == nullptr) return NB_ERR_UNSUPPORTED;
+    const int G = locals.front()->world;
+    if (num_bodies % static_cast<unsigned>(G)) return NB_ERR_INVALID_ARGUMENT;
+    const size_t slice_bodies = num_bodies / static_cast<unsigned>(G);
+    const size_t slice_values = slice_bodies * 4;
+    for (size_t k = 0; k < locals.size(); ++k) {  // the exchange may only start once the producers of the own slice have run
+        Comm*       c = locals[k];
+        DeviceScope scope(c->device);
+        auto        err = hipEventRecord(c->ready, after[k]);
+        if (err == hipSuccess) err = hipStreamWaitEvent(c->stream, c->ready, 0);
+        if (err != hipSuccess) return static_cast<int>(err);
+        c->in_flight = positions[k];
+    }
+    for (int s = 1; s < G; ++s) {
+        int rc = lib->GroupStart();
+        for (size_t k = 0; k < locals.size() && rc == 0; ++k) {
+            Comm*      c    = locals[k];
+            const int  dst  = (c->rank - s + G) % G, src = (c->rank + s) % G;
+            char*      base = static_cast<char*>(positions[k]);
+            rc              = lib->Send(base + static_cast<size_t>(c->rank) * slice_bodies * bytes_per_body, slice_values, nccl_type, dst, c->nccl, c->stream);
+            if (rc == 0) rc = lib->Recv(base + static_cast<size_t>(src) * slice_bodies * bytes_per_body, slice_values, nccl_type, src, c->nccl, c->stream);
+        }
+        const int end = lib->GroupEnd();
+        if (rc == 0) rc = end;
+        if (rc != 0) return nccl_status(rc);
+        for (Comm* c : locals) {
+            DeviceScope scope(c->device);
+            const auto  err = hipEventRecord(c->arrived[static_cast<size_t>((c->rank + s) % G)], c->stream);
+            if (err != hipSuccess) return static_cast<int>(err);
+        }
+    }
+    return 0;
+}
+
+template <typename T> struct Api;
+template <> struct Api<float> {
+    static constexpr int nccl_type = ncclFloat32;
+    static int shard(float* np, const float* op, float* v, float* a, unsigned i0, unsigned ni, unsigned j0, unsigned nj, unsigned flags, float dt, float damping, int bs, int mode, nb_stream_t s) {
+        return nb_integrate_shard_f32(np, op, v, a, i0, ni, j0, nj, flags, dt, damping, bs, mode, s);
+    }
+};
+template <> struct Api<double> {
+    static constexpr int nccl_type = ncclFloat64;
+    static int shard(double* np, const double* op, double* v, double* a, unsigned i0, unsigned ni, unsigned j0, unsigned nj, unsigned flags, double dt, double damping, int bs, int mode, nb_stream_t s) {
+        return nb_integrate_shard_f64(np, op, v, a, i0, ni, j0, nj, flags, dt, damping, bs, mode, s);
+    }
+};
+
+// One step for every local rank: kernels of the own slice and of each tile as it arrives, integrate, start the next exchange.
+template <typename T>
+int sharded_step(nb_comm_t const* comms, int n_local, T* const* new_pos, const T* const* old_pos, T* const* vel, T* const* acc, unsigned num_bodies, T dt, T damping, int block_size, int mode, const nb_stream_t* streams) {
+    NB_KEEP_RAND_STREAM;
+    if (comms == nullptr || n_local < 1 || !new_pos || !old_pos || !vel || !acc || !streams) return NB_ERR_INVALID_ARGUMENT;
+    std::vector<Comm*> locals(static_cast<size_t>(n_local));
+    for (int k = 0; k < n_local; ++k) {
+        locals[static_cast<size_t>(k)] = as_comm(comms[k]);
+        if (locals[static_cast<size_t>(k)] == nullptr) return NB_ERR_INVALID_ARGUMENT;
+    }
+    const int G = locals.front()->world;
+    if (num_bodies == 0 || num_bodies % static_cast<unsigned>(G)) return NB_ERR_INVALID_ARGUMENT;  // pad with zero-mass bodies (as tipsy.cpp:111-119 does)
+    const unsigned ni = num_bodies / static_cast<unsigned>(G);
+    for (int k = 0; k < n_local; ++k) {
+        Comm*         c = locals[static_cast<size_t>(k)];
+        DeviceScope   scope(c->device);
+        hipStream_t   stream   = reinterpret_cast<hipStream_t>(streams[k]);
+        const bool    waiting  = c->in_flight == static_cast<const void*>(old_pos[k]);  // else: every rank holds the whole array already
+        const unsigned i0      = static_cast<unsigned>(c->rank) * ni;
+        for (int t = 0; t < G; ++t) {
+            // FAST: own slice, then the tiles in arrival order (rank+1, rank+2, ...); STRICT: ascending rank = ascending j
+            const int  peer = mode == NB_MODE_STRICT ? t : (c->rank + t) % G;
+            if (peer != c->rank && waiting) {
+                const auto err = hipStreamWaitEvent(stream, c->arrived[static_cast<size_t>(peer)], 0);
+                if (err != hipSuccess) return static_cast<int>(err);
+            }
+            const unsigned flags = (t > 0 ? NB_SHARD_ACC_IN : 0u) | (t == G - 1 ? NB_SHARD_FINALIZE : 0u);
+            const int      rc    = Api<T>::shard(new_pos[k], old_pos[k], vel[k], acc[k], i0, ni, static_cast<unsigned>(peer) * ni, ni, flags, dt, damping, block_size, mode, streams[k]);
+            if (rc != 0) return rc;
+        }
+    }
+    if (G == 1) return 0;
+    std::vector<void*>       arrays(static_cast<size_t>(n_local));
+    std::vector<hipStream_t> after(static_cast<size_t>(n_local));
+    for (int k = 0; k < n_local; ++k) arrays[static_cast<size_t>(k)] = new_pos[k], after[static_cast<size_t>(k)] = reinterpret_cast<hipStream_t>(streams[k]);
+    return exchange_tiles(locals, arrays.data(), num_bodies, 4 * sizeof(T), Api<T>::nccl_type, after.data());
+}
+
+}  // namespace
+
+extern "C" {
+
+int nb_comm_unique_id(void* id) {
+    NB_KEEP_RAND_STREAM;
+    Rccl* lib = rccl();
+    if (lib == nullptr) return NB_ERR_UNSUPPORTED;
+    if (id == nullptr) return NB_ERR_INVALID_ARGUMENT;
+    ncclUniqueId uid;
+    const int    rc = lib->GetUniqueId(&uid);
+    if (rc == 0) std::memcpy(id, uid.internal, sizeof(uid.internal));
+    return nccl_status(rc);
+}
+
+int nb_comm_init_rank(nb_comm_t* comm, const void* id, int world, int rank) {
+    NB_KEEP_RAND_STREAM;
+    if (!comm || !id || world < 1 || rank < 0 || rank >= world) return NB_ERR_INVALID_ARGUMENT;
+    *comm     = nullptr;
+    Rccl* lib = rccl();
+    if (lib == nullptr) return NB_ERR_UNSUPPORTED;
+    auto* c  = new Comm;
+    c->rank  = rank;
+    c->world = world;
+    if (const auto err = hipGetDevice(&c->device); err != hipSuccess) {
+        delete c;
+        return static_cast<int>(err);
+    }
+    ncclUniqueId uid;
+    std::memcpy(uid.internal, id, sizeof(uid.internal));
+    int rc = nccl_status(lib->CommInitRank(&c->nccl, world, uid, rank));
+    if (rc == 0) rc = make_resources(c);
+    if (rc != 0) {
+        if (c->nccl) (void)lib->CommDestroy(c->nccl);
+        free_resources(c);
+        delete c;
+        return rc;
+    }
+    c->group = {c};
+    *comm    = c;
+    return 0;
+}
+
+int nb_comm_init_all(nb_comm_t* comms, int num_devices, const int* devices) {
+    NB_KEEP_RAND_STREAM;
+    if (!comms || num_devices < 1) return NB_ERR_INVALID_ARGUMENT;
+    Rccl* lib = rccl();
+    if (lib == nullptr) return NB_ERR_UNSUPPORTED;
+    std::vector<int> devs(static_cast<size_t>(num_devices));
+    for (int k = 0; k < num_devices; ++k) devs[static_cast<size_t>(k)] = devices ? devices[k] : k;
+    std::vector<ncclComm_t> raw(static_cast<size_t>(num_devices), nullptr);
+    int                     rc = nccl_status(lib->CommInitAll(raw.data(), num_devices, devs.data()));
+    if (rc != 0) return rc;
+    std::vector<Comm*> made;
+    for (int k = 0; k < num_devices && rc == 0; ++k) {
+        auto* c   = new Comm;
+        c->nccl   = raw[static_cast<size_t>(k)];
+        c->rank   = k;
+        c->world  = num_devices;
+        c->device = devs[static_cast<size_t>(k)];
+        made.push_back(c);
+        rc = make_resources(c);
+    }
+    if (rc != 0) {
+        for (size_t k = 0; k < raw.size(); ++k) (void)lib->CommDestroy(raw[k]);
+        for (Comm* c : made) {
+            free_resources(c);
+            delete c;
+        }
+        return rc;
+    }
+    for (Comm* c : made) c->group = made;
+    for (int k = 0; k < num_devices; ++k) comms[k] = made[static_cast<size_t>(k)];
+    return 0;
+}
+
+int nb_comm_destroy(nb_comm_t comm) {
+    NB_KEEP_RAND_STREAM;
+    Comm* c = as_comm(comm);
+    if (c == nullptr) return NB_ERR_INVALID_ARGUMENT;
+    Rccl* lib = rccl();
+    {
+        DeviceScope scope(c->device);
+        (void)hipStreamSynchronize(c->stream);
+    }
+    if (lib != nullptr && c->nccl != nullptr) (void)lib->CommDestroy(c->nccl);
+    free_resources(c);
+    delete c;
+    return 0;
+}
+
+int nb_comm_info(nb_comm_t comm, int* rank, int* world, int* device) {
+    Comm* c = as_comm(comm);
+    if (c == nullptr) return NB_ERR_INVALID_ARGUMENT;
+    if (rank) *rank = c->rank;
+    if (world) *world = c->world;
+    if (device) *device = c->device;
+    return 0;
+}
+
+static int exchange_one(nb_comm_t comm, void* positions, unsigned num_bodies, size_t bytes_per_body, int type, nb_stream_t after) {
+    NB_KEEP_RAND_STREAM;
+    Comm* c = as_comm(comm);
+    if (c == nullptr || positions == nullptr) return NB_ERR_INVALID_ARGUMENT;
+    if (c->group.size() != 1) return NB_ERR_INVALID_ARGUMENT;  // several local ranks: use the *_all form (one ncclGroup per round)
+    if (c->world == 1) return 0;
+    void*       arrays[1] = {positions};
+    hipStream_t streams[1] = {reinterpret_cast<hipStream_t>(after)};
+    return exchange_tiles(c->group, arrays, num_bodies, bytes_per_body, type, streams);
+}
+int nb_exchange_tiles_f32(nb_comm_t comm, float* positions, unsigned num_bodies, nb_stream_t after) { return exchange_one(comm, positions, num_bodies, 16, ncclFloat32, after); }
+int nb_exchange_tiles_f64(nb_comm_t comm, double* positions, unsigned num_bodies, nb_stream_t after) { return exchange_one(comm, positions, num_bodies, 32, ncclFloat64, after); }
+
+int nb_exchange_wait_tile(nb_comm_t comm, int peer, nb_stream_t stream) {
+    NB_KEEP_RAND_STREAM;
+    Comm* c = as_comm(comm);
+    if (c == nullptr || peer < 0 || peer >= c->world) return NB_ERR_INVALID_ARGUMENT;
+    if (peer == c->rank || c->in_flight == nullptr) return 0;
+    DeviceScope scope(c->device);
+    return static_cast<int>(hipStreamWaitEvent(reinterpret_cast<hipStream_t>(stream), c->arrived[static_cast<size_t>(peer)], 0));
+}
+
+int nb_exchange_wait_all(nb_comm_t comm, nb_stream_t stream) {
+    Comm* c = as_comm(comm);
+    if (c == nullptr) return NB_ERR_INVALID_ARGUMENT;
+    for (int p = 0; p < c->world; ++p) {
+        const int rc = nb_exchange_wait_tile(comm, p, stream);
+        if (rc != 0) return rc;
+    }
+    return 0;
+}
+
+static int allgather_one(nb_comm_t comm, void* positions, unsigned num_bodies, size_t bytes_per_body, int type, nb_stream_t after) {
+    NB_KEEP_RAND_STREAM;
+    Comm* c = as_comm(comm);
+    Rccl* lib = rccl();
+    if (lib == nullptr) return NB_ERR_UNSUPPORTED;
+    if (c == nullptr || positions == nullptr || c->group.size() != 1 || num_bodies % static_cast<unsigned>(c->world)) return NB_ERR_INVALID_ARGUMENT;
+    if (c->world == 1) return 0;
+    DeviceScope  scope(c->device);
+    const size_t slice = num_bodies / static_cast<unsigned>(c->world);
+    auto         err   = hipEventRecord(c->ready, reinterpret_cast<hipStream_t>(after));
+    if (err == hipSuccess) err = hipStreamWaitEvent(c->stream, c->ready, 0);
+    if (err != hipSuccess) return static_cast<int>(err);
+    c->in_flight = positions;
+    char* base   = static_cast<char*>(positions);
+    // in place: the own slice already sits at its offset, RCCL moves the others
+    const int rc = lib->AllGather(base + static_cast<size_t>(c->rank) * slice * bytes_per_body, base, slice * 4, type, c->nccl, c->stream);
+    if (rc != 0) return nccl_status(rc);
+    for (int p = 0; p < c->world; ++p) {  // one collective: every tile "arrives" with it
+        err = hipEventRecord(c->arrived[static_cast<size_t>(p)], c->stream);
+        if (err != hipSuccess) return static_cast<int>(err);
+    }
+    return 0;
+}
+int nb_allgather_f32(nb_comm_t comm, float* positions, unsigned num_bodies, nb_stream_t after) { return allgather_one(comm, positions, num_bodies, 16, ncclFloat32, after); }
+int nb_allgather_f64(nb_comm_t comm, double* positions, unsigned num_bodies, nb_stream_t after) { return allgather_one(comm, positions, num_bodies, 32, ncclFloat64, after); }
+
+int nb_sharded_step_f32(nb_comm_t comm, float* new_positions, const float* old_positions, float* velocities, float* acc, unsigned num_bodies, float dt, float damping, int block_size, int mode, nb_stream_t stream) {
+    Comm* c = as_comm(comm);
+    if (c == nullptr || c->group.size() != 1) return NB_ERR_INVALID_ARGUMENT;
+    return sharded_step<float>(&comm, 1, &new_positions, &old_positions, &velocities, &acc, num_bodies, dt, damping, block_size, mode, &stream);
+}
+int nb_sharded_step_f64(nb_comm_t comm, double* new_positions, const double* old_positions, double* velocities, double* acc, unsigned num_bodies, double dt, double damping, int block_size, int mode, nb_stream_t stream) {
+    Comm* c = as_comm(comm);
+    if (c == nullptr || c->group.size() != 1) return NB_ERR_INVALID_ARGUMENT;
+    return sharded_step<double>(&comm, 1, &new_positions, &old_positions, &velocities, &acc, num_bodies, dt, damping, block_size, mode, &stream);
+}
+int nb_sharded_step_all_f32(const nb_comm_t* comms, int num_local, float* const* new_positions, const float* const* old_positions, float* const* velocities, float* const* acc, unsigned num_bodies, float dt, float damping,
+                            int block_size, int mode, const nb_stream_t* streams) {
+    return sharded_step<float>(comms, num_local, new_positions, old_positions, velocities, acc, num_bodies, dt, damping, block_size, mode, streams);
+}
+int nb_sharded_step_all_f64(const nb_comm_t* comms, int num_local, double* const* new_positions, const double* const* old_positions, double* const* velocities, double* const* acc, unsigned num_bodies, double dt,
+                            double damping, int block_size, int mode, const nb_stream_t* streams) {
+    return sharded_step<double>(comms, num_local, new_positions, old_positions, velocities, acc, num_bodies, dt, damping, block_size, mode, streams);
+}
+
+}  // extern "C"

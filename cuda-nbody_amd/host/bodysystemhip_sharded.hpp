@@ -1,0 +1,47 @@
+// bodysystemhip_sharded.hpp -- the body system spread over several GPUs of one node (--numdevices / --devices).
+//
+// New: the reference is single-GPU (NVIDIA's original sample had a -numdevices mode; this fork removed it, SURVEY
+// section 0).  Same interface as every other BodySystemHIP<T>, so ComputeHIP / Compute / the command line drive it
+// unchanged.  One process, one host thread, G devices: device g owns bodies [g*N/G, (g+1)*N/G) -- its velocities, its
+// slice of each new position array -- and holds full-size position arrays; every update() is one
+// nb_sharded_step_all_* call (include/nbody_hip.h): per device the kernels of the own slice and of each position tile as
+// it arrives over RCCL / xGMI, then the tile exchange of the new positions.  STRICT mode is bit-identical to one GPU.
+#pragma once
+
+#include "bodysystemhip.hpp"
+#include "device_array.hpp"
+
+#include <span>
+#include <vector>
+
+template <std::floating_point T> class BodySystemHIPSharded final : public BodySystemHIP<T> {
+ public:
+    BodySystemHIPSharded(unsigned int nb_bodies, unsigned int blockSize, const NBodyParams& params, std::span<const int> devices);
+    BodySystemHIPSharded(unsigned int nb_bodies, unsigned int blockSize, const NBodyParams& params, std::span<const int> devices, std::vector<T> positions, std::vector<T> velocities);
+    ~BodySystemHIPSharded() override;
+
+    auto get_position() const -> std::span<const T> override;
+    auto get_velocity() const -> std::span<const T> override;
+    auto set_position(std::span<const T> data) -> void override;
+    auto set_velocity(std::span<const T> data) -> void override;
+    auto update(T deltaTime) -> void override;
+
+    auto nb_devices() const noexcept { return shards_.size(); }
+
+ private:
+    struct Shard {
+        int            device = 0;
+        DeviceArray<T> pos[2];
+        DeviceArray<T> vel;
+        DeviceArray<T> acc;
+    };
+    auto allocate(std::span<const int> devices) -> void;
+
+    std::vector<Shard>     shards_;
+    std::vector<nb_comm_t> comms_;
+    mutable std::vector<T> host_pos_;
+    mutable std::vector<T> host_vel_;
+};
+
+extern template class BodySystemHIPSharded<float>;
+extern template class BodySystemHIPSharded<double>;

@@ -33,7 +33,7 @@ Compute::~Compute() noexcept = default;
 
 // compute.cpp:27-103
 Compute::Compute(bool enable_fp64, bool enable_cpu, [[maybe_unused]] bool enable_compare_to_cpu, [[maybe_unused]] bool enable_benchmark, bool enable_host_memory, int block_size, std::size_t nb_bodies,
-                 const std::filesystem::path& tipsy_file, NBodyConfig initial_configuration)
+                 const std::filesystem::path& tipsy_file, NBodyConfig initial_configuration, std::vector<int> devices)
     : fp64_enabled_(enable_fp64) {
     if (enable_cpu) {
         // The reference's --cpu path (BodySystemCPU) exists in this repository only as the test oracle
@@ -53,9 +53,9 @@ Compute::Compute(bool enable_fp64, bool enable_cpu, [[maybe_unused]] bool enable
             throw std::invalid_argument("--numbodies does not match the tipsy file (" + std::to_string(file_bodies) + " bodies after padding to a multiple of 256)");
         }
         compute_hip_ = std::make_unique<ComputeHIP>(enable_host_memory, block_size, enable_fp64, file_bodies, active_params_, tipsy_data_fp32_.positions, tipsy_data_fp32_.velocities, tipsy_data_fp64_.positions,
-                                                    tipsy_data_fp64_.velocities);
+                                                    tipsy_data_fp64_.velocities, std::move(devices));
     } else {
-        compute_hip_ = std::make_unique<ComputeHIP>(enable_host_memory, block_size, enable_fp64, nb_bodies, active_params_);
+        compute_hip_ = std::make_unique<ComputeHIP>(enable_host_memory, block_size, enable_fp64, nb_bodies, active_params_, std::move(devices));
     }
     num_bodies_ = compute_hip_->nb_bodies();
 

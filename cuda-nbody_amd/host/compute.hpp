@@ -35,9 +35,9 @@ class Compute {
     static auto scale_params_for(std::size_t nb_bodies, NBodyParams& params) noexcept -> void;
 
     // Argument order of the reference's constructor (compute.hpp:19-27) without enable_cycle_demo; the trailing
-    // parameter is an extension (the reference always starts from the shell configuration).
+    // parameters are extensions (the reference always starts from the shell configuration, on one GPU).
     Compute(bool enable_fp64, bool enable_cpu, bool enable_compare_to_cpu, bool enable_benchmark, bool enable_host_memory, int block_size, std::size_t nb_bodies, const std::filesystem::path& tipsy_file,
-            NBodyConfig initial_configuration = NBodyConfig::NBODY_CONFIG_SHELL);
+            NBodyConfig initial_configuration = NBodyConfig::NBODY_CONFIG_SHELL, std::vector<int> devices = {});
     Compute(const Compute&)                    = delete;
     auto operator=(const Compute&) -> Compute& = delete;
     ~Compute() noexcept;

@@ -1,6 +1,7 @@
 #include "compute_hip.hpp"
 
 #include "bodysystemhip.hpp"
+#include "bodysystemhip_sharded.hpp"
 #include "bodysystemhip_storage.hpp"
 #include "integrate_nbody_hip.hpp"
 #include "text.hpp"
@@ -27,12 +28,22 @@ auto get_main_device() -> nb_device_info_t {
 
 }  // namespace
 
-ComputeHIP::ComputeHIP(bool enable_host_mem, int block_size, bool fp64_enabled, std::size_t num_bodies, const NBodyParams& params) : ComputeHIP(enable_host_mem, block_size, fp64_enabled, num_bodies, params, {}, {}, {}, {}) {}
+ComputeHIP::ComputeHIP(bool enable_host_mem, int block_size, bool fp64_enabled, std::size_t num_bodies, const NBodyParams& params, std::vector<int> devices)
+    : ComputeHIP(enable_host_mem, block_size, fp64_enabled, num_bodies, params, {}, {}, {}, {}, std::move(devices)) {}
 
 // compute_cuda.cpp:55-150
 ComputeHIP::ComputeHIP(bool enable_host_mem, int block_size, bool fp64_enabled, std::size_t num_bodies, const NBodyParams& params, std::vector<float> positions_fp32, std::vector<float> velocities_fp32,
-                       std::vector<double> positions_fp64, std::vector<double> velocities_fp64)
+                       std::vector<double> positions_fp64, std::vector<double> velocities_fp64, std::vector<int> devices)
     : block_size_(block_size), fp64_enabled_(fp64_enabled), use_host_mem_(enable_host_mem) {
+    if (!devices.empty()) {
+        int count = 0;
+        hip_check(nb_device_count(&count), "nb_device_count");
+        for (const auto d : devices) {
+            if (d < 0 || d >= count) throw std::invalid_argument("--devices: device " + std::to_string(d) + " does not exist (" + std::to_string(count) + " visible)");
+        }
+        if (enable_host_mem) throw std::invalid_argument("--hostmem and --numdevices/--devices cannot be combined");
+        hip_check(nb_set_device(devices.front()), "nb_set_device");
+    }
     const auto device = get_main_device();
 
     std::printf("> %s HIP device: [%s], %d compute units\n", device.arch, device.name, device.compute_units);
@@ -62,6 +73,12 @@ ComputeHIP::ComputeHIP(bool enable_host_mem, int block_size, bool fp64_enabled, 
         nb_bodies_ = static_cast<std::size_t>(block_size_) * 4u * static_cast<std::size_t>(device.compute_units);
     }
 
+    if (!devices.empty()) {
+        if (nb_bodies_ % devices.size() != 0) {
+            throw std::invalid_argument("the number of bodies (" + std::to_string(nb_bodies_) + ") must be a multiple of the number of devices (" + std::to_string(devices.size()) + ")");
+        }
+        std::printf("> %zu Devices used for simulation (bodies sharded, %zu per device)\n", devices.size(), nb_bodies_ / devices.size());
+    }
     std::printf("> Simulation data stored in %s memory\n", use_host_mem_ ? "system" : "video");
     std::printf("> %s precision floating point simulation\n", fp64_enabled_ ? "Double" : "Single");
 
@@ -76,7 +93,17 @@ ComputeHIP::ComputeHIP(bool enable_host_mem, int block_size, bool fp64_enabled, 
             nbody_fp64_ = std::make_unique<System64>(n, b, params);
         }
     };
-    if (use_host_mem_) {
+    if (!devices.empty()) {
+        const auto n = static_cast<unsigned int>(nb_bodies_);
+        const auto b = static_cast<unsigned int>(block_size_);
+        if (!positions_fp32.empty()) {
+            nbody_fp32_ = std::make_unique<BodySystemHIPSharded<float>>(n, b, params, devices, std::move(positions_fp32), std::move(velocities_fp32));
+            nbody_fp64_ = std::make_unique<BodySystemHIPSharded<double>>(n, b, params, devices, std::move(positions_fp64), std::move(velocities_fp64));
+        } else {
+            nbody_fp32_ = std::make_unique<BodySystemHIPSharded<float>>(n, b, params, devices);
+            nbody_fp64_ = std::make_unique<BodySystemHIPSharded<double>>(n, b, params, devices);
+        }
+    } else if (use_host_mem_) {
         allocate.template operator()<BodySystemHIPHostMemory<float>, BodySystemHIPHostMemory<double>>();
     } else {
         allocate.template operator()<BodySystemHIPDefault<float>, BodySystemHIPDefault<double>>();

@@ -22,9 +22,11 @@ class ComputeHIP {
     using Milliseconds = std::chrono::duration<float, std::milli>;
 
     // ---- construction: device checks, N rounding (or #CUs * 4 * blockSize when N == 0), storage variant ------------
-    ComputeHIP(bool enable_host_mem, int block_size, bool fp64_enabled, std::size_t num_bodies, const NBodyParams& params);
+    // `devices`: empty = the current device (the reference's behaviour); otherwise the bodies are sharded over these GPUs
+    // (--numdevices / --devices: BodySystemHIPSharded, position tiles exchanged over RCCL)
+    ComputeHIP(bool enable_host_mem, int block_size, bool fp64_enabled, std::size_t num_bodies, const NBodyParams& params, std::vector<int> devices = {});
     ComputeHIP(bool enable_host_mem, int block_size, bool fp64_enabled, std::size_t num_bodies, const NBodyParams& params, std::vector<float> positions_fp32, std::vector<float> velocities_fp32,
-               std::vector<double> positions_fp64, std::vector<double> velocities_fp64);
+               std::vector<double> positions_fp64, std::vector<double> velocities_fp64, std::vector<int> devices = {});
     ~ComputeHIP() noexcept;
 
     // ---- state ---------------------------------------------------------------------------------------------------

@@ -4,7 +4,8 @@
 //
 //   reference flags : --fullscreen --fp64 --hostmem --benchmark --numbodies=<n> --compare --qatest --cpu
 //                     --tipsy=<file> -i,--iterations=<n> --blockSize=<n>      (single-dash spellings accepted too)
-//   extensions      : --mode=fast|strict  --config=shell|random|expand  --demo=<0..6>  --steps=<n>  --dump=<file>
+//   extensions      : --numdevices=<n> | --devices=<list> (the NVIDIA sample's -numdevices, which this fork of it dropped)
+//                     --mode=fast|strict  --config=shell|random|expand  --demo=<0..6>  --steps=<n>  --dump=<file>
 //                     --seed=<n>  --graph  --inject-error=<x> (test hook for --compare)
 #include "compute.hpp"
 #include "integrate_nbody_hip.hpp"
@@ -22,6 +23,7 @@
 #include <string>
 #include <string_view>
 #include <utility>
+#include <vector>
 
 namespace {
 
@@ -46,6 +48,7 @@ struct Options {
     std::filesystem::path dump;
     std::optional<unsigned> seed;
     bool                  graph = false;
+    std::vector<int>      devices;  // --numdevices=<n> (devices 0..n-1) or --devices=<a,b,...>: bodies sharded over several GPUs
     std::optional<std::size_t> demo;   // row of Compute::demo_params (the reference reaches them from the viewer's keys only)
     double                inject_error = 0.0;
 };
@@ -68,6 +71,8 @@ Options:
   --blockSize INT [256]       Workgroup / LDS tile size of the strict kernels (multiple of 64); a hint for the fast ones
   --mode TEXT [fast]          fast | strict (strict bit-reproduces the reference's CPU BodySystem path)
   --config TEXT [shell]       shell | random | expand initial configuration
+  --numdevices UINT           Shard the bodies over GPUs 0..n-1 of this node (position tiles exchanged over RCCL / xGMI)
+  --devices LIST              ... or over the GPUs in this comma-separated list
   --demo UINT                 Select row 0..6 of the demo parameter table (dt, scales, softening, damping) and reset
   --steps UINT                Advance this many steps (untimed) before --dump
   --dump TEXT                 Write final positions then velocities (raw little-endian T[4N] each) to this file
@@ -160,6 +165,25 @@ auto parse_args(int argc, char** argv) -> std::pair<Status, Options> {
             const auto v = take_value();
             ok           = v.has_value();
             if (ok) options.dump = std::filesystem::path(std::string(*v));
+        } else if (name == "numdevices") {
+            const auto v = take_value();
+            int        n = 0;
+            ok           = v && parse_number(*v, n) && n >= 1;
+            if (!ok) return error("--numdevices: Value not in range 1 to " + std::to_string(std::numeric_limits<int>::max()));
+            options.devices.clear();
+            for (int d = 0; d < n; ++d) options.devices.push_back(d);
+        } else if (name == "devices") {
+            const auto v = take_value();
+            ok           = v.has_value() && !v->empty();
+            options.devices.clear();
+            auto rest = ok ? *v : std::string_view{};
+            while (ok && !rest.empty()) {
+                const auto comma = rest.find(',');
+                int        d     = -1;
+                ok               = parse_number(rest.substr(0, comma), d) && d >= 0;
+                options.devices.push_back(d);
+                rest = comma == std::string_view::npos ? std::string_view{} : rest.substr(comma + 1);
+            }
         } else if (name == "demo") {
             const auto  v = take_value();
             std::size_t d = 0;
@@ -222,7 +246,7 @@ auto main(int argc, char** argv) -> int {
             throw std::invalid_argument("the interactive OpenGL viewer is out of scope on a headless accelerator: pass --benchmark, --compare/--qatest or --steps/--dump");
         }
 
-        auto compute = Compute(cmd_options.fp64, cmd_options.cpu, compare_to_cpu, cmd_options.benchmark, cmd_options.hostmem, cmd_options.block_size, cmd_options.numbodies, cmd_options.tipsy, cmd_options.config);
+        auto compute = Compute(cmd_options.fp64, cmd_options.cpu, compare_to_cpu, cmd_options.benchmark, cmd_options.hostmem, cmd_options.block_size, cmd_options.numbodies, cmd_options.tipsy, cmd_options.config, cmd_options.devices);
 
         compute.use_graph(cmd_options.graph);
         if (cmd_options.demo) compute.select_demo(*cmd_options.demo);

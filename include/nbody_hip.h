@@ -32,6 +32,7 @@ extern "C" {
 /* Host-side argument errors (outside hipError_t's range). */
 #define NB_ERR_INVALID_ARGUMENT 10001
 #define NB_ERR_UNSUPPORTED      10002
+#define NB_ERR_RCCL_BASE        20000 /* 20000 + ncclResult_t for a failed RCCL call of the multi-GPU entry points */
 
 /* Arithmetic mode of the integrate entry points. */
 enum {
@@ -110,8 +111,8 @@ NB_API int nb_get_softening_sq_f64(double* softening_sq);
  *  (self-interaction included, exactly 0 for eps > 0), v = (v + a*dt)*damping, p += v*dt, written to
  *  new_positions (must not alias old_positions) and, in place, to velocities.  Asynchronous on
  *  `stream`.  Unlike the reference kernel (wrong unless N % blockSize == 0, :153-155) any N >= 1 works.
- *  `block_size` is the reference's --blockSize: in STRICT mode it is the LDS tile / workgroup size
- *  (multiple of 64, <= 1024); FAST mode treats it as a hint and picks its own tiling. ---------------- */
+ *  `block_size` is the reference's --blockSize (a multiple of 64, <= 1024, validated in STRICT mode): results
+ *  never depend on it and both modes pick their own launch geometry, so it is a hint only. ------------ */
 NB_API int nb_integrate_f32(float* new_positions, const float* old_positions, float* velocities,
                             float delta_time, float damping, unsigned num_bodies, int block_size,
                             int mode, nb_stream_t stream);
@@ -134,6 +135,44 @@ NB_API int nb_integrate_shard_f64(double* new_positions, const double* old_posit
                                   unsigned i_begin, unsigned i_count, unsigned j_begin, unsigned j_count,
                                   unsigned flags, double delta_time, double damping, int block_size, int mode,
                                   nb_stream_t stream);
+
+/* ---- multi-GPU: bodies sharded over the GPUs of one node, position tiles exchanged over RCCL / xGMI (new: the reference
+ *  is single-GPU).  Rank r of G owns bodies [r*N/G, (r+1)*N/G) -- N must be a multiple of G; pad with zero-mass bodies
+ *  as tipsy.cpp:111-119 does -- i.e. their velocities and their slice of every new position array; all arrays stay
+ *  full-size.  The one exchange step is the all-gather of the new positions, issued as G-1 position TILES: in round s
+ *  rank r sends its slice to r-s and receives the slice of r+s (one grouped RCCL send/recv pair per round on the
+ *  communicator's own high-priority stream, an event per round).  nb_sharded_step_* = the kernels of the own slice,
+ *  then of each tile as it arrives (STRICT: ascending rank order, bit-identical to one GPU), integrate, and the start
+ *  of the exchange of new_positions -- everything asynchronous; the caller ping-pongs the two position arrays exactly
+ *  as with nb_integrate_*.  Process models: one process per GPU (nb_comm_unique_id on rank 0, ship the 128 bytes to
+ *  the others by any means, nb_comm_init_rank on each) or one process driving several GPUs (nb_comm_init_all +
+ *  the *_all step, which takes one array of each kind per local device).  RCCL is loaded on first use. -------------- */
+#define NB_COMM_ID_BYTES 128
+typedef void* nb_comm_t;
+NB_API int nb_comm_unique_id(void* id /* NB_COMM_ID_BYTES */);
+NB_API int nb_comm_init_rank(nb_comm_t* comm, const void* id, int world_size, int rank);  /* on the current device */
+NB_API int nb_comm_init_all(nb_comm_t* comms /* [num_devices] */, int num_devices, const int* devices /* NULL = 0..n-1 */);
+NB_API int nb_comm_destroy(nb_comm_t comm);
+NB_API int nb_comm_info(nb_comm_t comm, int* rank, int* world_size, int* device);
+NB_API int nb_sharded_step_f32(nb_comm_t comm, float* new_positions, const float* old_positions, float* velocities, float* acc,
+                               unsigned num_bodies, float delta_time, float damping, int block_size, int mode, nb_stream_t stream);
+NB_API int nb_sharded_step_f64(nb_comm_t comm, double* new_positions, const double* old_positions, double* velocities, double* acc,
+                               unsigned num_bodies, double delta_time, double damping, int block_size, int mode, nb_stream_t stream);
+NB_API int nb_sharded_step_all_f32(const nb_comm_t* comms, int num_local, float* const* new_positions, const float* const* old_positions,
+                                   float* const* velocities, float* const* acc, unsigned num_bodies, float delta_time, float damping,
+                                   int block_size, int mode, const nb_stream_t* streams);
+NB_API int nb_sharded_step_all_f64(const nb_comm_t* comms, int num_local, double* const* new_positions, const double* const* old_positions,
+                                   double* const* velocities, double* const* acc, unsigned num_bodies, double delta_time, double damping,
+                                   int block_size, int mode, const nb_stream_t* streams);
+/* The exchange on its own (what nb_sharded_step_* ends with): tiles of `positions` start moving once the work already
+ * enqueued on `after_stream` is done; nb_exchange_wait_tile makes `stream` wait for the tile of rank `peer`.
+ * nb_allgather_* is the same exchange as ONE in-place ncclAllGather (every tile then arrives with it). */
+NB_API int nb_exchange_tiles_f32(nb_comm_t comm, float* positions, unsigned num_bodies, nb_stream_t after_stream);
+NB_API int nb_exchange_tiles_f64(nb_comm_t comm, double* positions, unsigned num_bodies, nb_stream_t after_stream);
+NB_API int nb_allgather_f32(nb_comm_t comm, float* positions, unsigned num_bodies, nb_stream_t after_stream);
+NB_API int nb_allgather_f64(nb_comm_t comm, double* positions, unsigned num_bodies, nb_stream_t after_stream);
+NB_API int nb_exchange_wait_tile(nb_comm_t comm, int peer, nb_stream_t stream);
+NB_API int nb_exchange_wait_all(nb_comm_t comm, nb_stream_t stream);
 
 /* ---- hipGraph form of the step loop (new).  Small systems are launch-bound (a 1 024-body step is ~2 us of GPU work):
  *  `steps` consecutive nb_integrate_* launches, ping-ponging between position_a (read first) and position_b, are

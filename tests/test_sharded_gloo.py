@@ -51,7 +51,7 @@ def _oracle_shard_launch(n, dt, damping, eps2):
     return launch
 
 
-def _worker(rank, world, port, n, steps, ordered, out_dir):
+def _worker(rank, world, port, n, steps, ordered, exchange, out_dir):
     sys.path.insert(0, ROOT)
     import torch
     import torch.distributed as dist
@@ -68,7 +68,7 @@ def _worker(rank, world, port, n, steps, ordered, out_dir):
         eps2 = orc.softening_sq(0.1, np.float32)
         launch = _oracle_shard_launch(n, np.float32(0.016), np.float32(1.0), eps2)
         system = sharded.ShardedBodySystem(torch.from_numpy(pos0.reshape(n, 4).copy()), torch.from_numpy(vel0.reshape(n, 4).copy()),
-                                           launch, ordered=ordered)
+                                           launch, ordered=ordered, exchange=exchange)
         for _ in range(steps):
             system.update()
         pos = system.positions().numpy().copy()
@@ -79,13 +79,14 @@ def _worker(rank, world, port, n, steps, ordered, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,ordered", [(2, True), (2, False), (4, False)])
-def test_sharded_step_matches_single_process_oracle(tmp_path, oracle, world, ordered):
+@pytest.mark.parametrize("world,ordered,exchange", [(2, True, "tiles"), (2, False, "tiles"), (4, False, "tiles"), (4, True, "tiles"), (3, False, "tiles"),
+                                                    (2, True, "allgather"), (2, False, "allgather"), (4, False, "allgather")])
+def test_sharded_step_matches_single_process_oracle(tmp_path, oracle, world, ordered, exchange):
     import torch.multiprocessing as mp
 
-    n, steps = 256, 3
+    n, steps = (256, 3) if world != 3 else (264, 3)
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, n, steps, ordered, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, n, steps, ordered, exchange, str(tmp_path)), nprocs=world, join=True)
     ref_pos, ref_vel = oracle.startup_state(n, np.float32)
     oracle.update(ref_pos, ref_vel, np.float32(0.016), steps=steps)
     for rank in range(world):
@@ -119,6 +120,16 @@ def test_chunk_schedule_and_slices():
     # strict order: ascending j, everything behind the gather
     assert sh.chunk_schedule(64, 64, 256, True) == [(0, 64, True), (64, 64, True), (128, 128, True)]
     assert sh.chunk_schedule(0, 256, 256, False) == [(0, 256, False)]
+    # tile exchange: own slice first, then the peers in arrival order (rank+1, rank+2, ...); STRICT: ascending rank
+    assert sh.tile_schedule(1, 4, 256, False) == [(64, 64, None), (128, 64, 2), (192, 64, 3), (0, 64, 0)]
+    assert sh.tile_schedule(1, 4, 256, True) == [(0, 64, 0), (64, 64, None), (128, 64, 2), (192, 64, 3)]
+    assert sh.tile_schedule(0, 1, 256, False) == [(0, 256, None)]
+    for world in (1, 2, 4, 8):
+        for rank in range(world):
+            for ordered in (False, True):
+                sched = sh.tile_schedule(rank, world, 1024, ordered)
+                assert sorted(j0 for j0, _, _ in sched) == [k * (1024 // world) for k in range(world)]
+                assert [p for _, _, p in sched].count(None) == 1 and sorted(p for _, _, p in sched if p is not None) == [q for q in range(world) if q != rank]
     # the chunks always tile [0, n) exactly once
     for world in (1, 2, 4, 8):
         for rank in range(world):

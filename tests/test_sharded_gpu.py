@@ -90,3 +90,90 @@ def test_two_ranks_on_one_gpu_match_the_oracle(tmp_path, oracle, mode_name):
     else:
         np.testing.assert_allclose(pos[0], ref_pos, rtol=1e-5, atol=1e-5)
         np.testing.assert_allclose(vel, ref_vel, rtol=1e-4, atol=1e-4)
+
+
+# ------------------------------------------------------------------------------------------------ through the C-ABI
+@pytest.mark.parametrize("mode_name", ["strict", "fast"])
+@pytest.mark.parametrize("how", ["init_rank", "init_all"])
+def test_capi_sharded_step_world_size_one(pkg, oracle, mode_name, how):
+    """The multi-GPU entry points of include/nbody_hip.h (nb_comm_*, nb_sharded_step_*) with the one GPU there is:
+    a communicator of size 1, created either way (unique id + init_rank, or init_all), must reproduce nb_integrate_*
+    bit for bit -- same kernels, same chunking (one chunk), the exchange a no-op; STRICT also == the CPU path."""
+    import ctypes
+
+    lib = pkg.lib()
+    pkg.check(lib.nb_set_device(0))
+    n, steps = 2048, 4
+    dt = np.float32(0.016)
+    pos0, vel0 = oracle.startup_state(n, np.float32)
+    mode = pkg.NB_MODE_STRICT if mode_name == "strict" else pkg.NB_MODE_FAST
+    comm = ctypes.c_void_p()
+    if how == "init_rank":
+        uid = ctypes.create_string_buffer(128)
+        pkg.check(lib.nb_comm_unique_id(uid), "nb_comm_unique_id")
+        pkg.check(lib.nb_comm_init_rank(ctypes.byref(comm), uid, 1, 0), "nb_comm_init_rank")
+    else:
+        pkg.check(lib.nb_comm_init_all(ctypes.byref(comm), 1, None), "nb_comm_init_all")
+    rank, world, device = ctypes.c_int(-1), ctypes.c_int(-1), ctypes.c_int(-1)
+    pkg.check(lib.nb_comm_info(comm, ctypes.byref(rank), ctypes.byref(world), ctypes.byref(device)))
+    assert (rank.value, world.value, device.value) == (0, 1, 0)
+    pkg.check(lib.nb_set_softening_sq_f32(np.float32(0.1) * np.float32(0.1)))
+    bufs = [pkg.DeviceBuffer(pos0.nbytes) for _ in range(4)]  # pos a, pos b, vel, acc
+    bufs[0].upload(pos0), bufs[2].upload(vel0)
+    read = 0
+    for _ in range(steps):
+        if how == "init_rank":
+            pkg.check(lib.nb_sharded_step_f32(comm, bufs[1 - read].ptr, bufs[read].ptr, bufs[2].ptr, bufs[3].ptr, n, dt, np.float32(1), 256, mode, None), "nb_sharded_step_f32")
+        else:
+            arr = lambda b: (ctypes.c_void_p * 1)(b.ptr)  # noqa: E731
+            pkg.check(lib.nb_sharded_step_all_f32(ctypes.byref(comm), 1, arr(bufs[1 - read]), arr(bufs[read]), arr(bufs[2]), arr(bufs[3]), n, dt, np.float32(1), 256, mode,
+                                                  (ctypes.c_void_p * 1)(None)), "nb_sharded_step_all_f32")
+        read = 1 - read
+    pkg.check(lib.nb_exchange_wait_all(comm, None))
+    pkg.check(lib.nb_exchange_tiles_f32(comm, bufs[read].ptr, n, None))  # world 1: nothing to move
+    pkg.check(lib.nb_allgather_f32(comm, bufs[read].ptr, n, None))
+    got_pos = bufs[read].download(np.zeros_like(pos0)).copy()
+    got_vel = bufs[2].download(np.zeros_like(vel0)).copy()
+    # one GPU through nb_integrate_f32
+    single = pkg.BodySystemHIP(n, 256, pkg.NBodyParams(), np.float32, pos0, vel0, mode=mode)
+    for _ in range(steps):
+        single.update(dt)
+    assert got_pos.tobytes() == single.get_position().tobytes() and got_vel.tobytes() == single.get_velocity().tobytes()
+    if mode == pkg.NB_MODE_STRICT:
+        ref_p, ref_v = pos0.copy(), vel0.copy()
+        oracle.update(ref_p, ref_v, dt, steps=steps)
+        assert got_pos.tobytes() == ref_p.tobytes() and got_vel.tobytes() == ref_v.tobytes()
+    # argument checking
+    assert lib.nb_sharded_step_f32(None, bufs[1].ptr, bufs[0].ptr, bufs[2].ptr, bufs[3].ptr, n, dt, np.float32(1), 256, mode, None) == 10001
+    assert lib.nb_exchange_wait_tile(comm, 5, None) == 10001
+    single.free()
+    pkg.check(lib.nb_comm_destroy(comm))
+    for b in bufs:
+        b.free()
+
+
+def test_cli_numdevices_one_is_the_single_gpu_run(tmp_path):
+    """`nbody --numdevices=1` drives BodySystemHIPSharded (nb_comm_init_all + nb_sharded_step_all_*): STRICT dumps are
+    bit-identical to the default single-GPU run and to the golden trajectory; a device that does not exist, a body count
+    the devices do not divide and --hostmem are rejected with exit code 1."""
+    import subprocess
+
+    from conftest import load_golden
+
+    cli = os.path.join(ROOT, "cuda-nbody_amd", "nbody")
+    n = 1024
+    for flags, dtype, tag in (([], np.float32, "f32"), (["--fp64"], np.float64, "f64")):
+        dump = tmp_path / f"sharded_{tag}.bin"
+        r = subprocess.run([cli, f"--numbodies={n}", "--mode=strict", "--steps=10", "--numdevices=1", f"--dump={dump}", *flags], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        assert "> 1 Devices used for simulation" in r.stdout
+        raw = np.fromfile(dump, dtype=dtype)
+        g = load_golden(n, tag)
+        assert raw[:4 * n].tobytes() == g["pos_10"].tobytes() and raw[4 * n:].tobytes() == g["vel_10"].tobytes()
+    r = subprocess.run([cli, "--benchmark", "--numbodies=4096", "--devices=0", "-i", "4"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "billion interactions per second" in r.stdout
+    r = subprocess.run([cli, "--compare", "--numbodies=2048", "--numdevices=1"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "  OK" in r.stdout
+    for bad in (["--devices=0,7"], ["--numdevices=1", "--hostmem"], ["--devices=x"]):
+        r = subprocess.run([cli, "--benchmark", "--numbodies=1024", *bad], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 1, bad

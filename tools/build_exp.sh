@@ -9,7 +9,8 @@ S=cuda-nbody_amd/csrc
 $C -ffp-contract=off -fno-slp-vectorize -mllvm -amdgpu-sched-strategy=max-ilp -c $S/nbody_strict.hip -o exp/strict_$1.o &
 $C -c $S/nbody_fast.hip -o exp/fast_$1.o &
 $C -c $S/nbody_capi.hip -o exp/capi_$1.o &
+$C -c $S/nbody_comm.hip -o exp/comm_$1.o &
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o exp/libnbody_hip_$1.so exp/strict_$1.o exp/fast_$1.o exp/capi_$1.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o exp/libnbody_hip_$1.so exp/strict_$1.o exp/fast_$1.o exp/capi_$1.o exp/comm_$1.o -ldl
 rm -f exp/*_$1.o
 ls -la exp/libnbody_hip_$1.so

@@ -57,6 +57,13 @@ if "GRBM_GUI_ACTIVE" in counters:
         d["valu_busy_fraction"] = counters["SQ_ACTIVE_INST_VALU"] * 4 / (cycles * 1024)
 if "SQ_INSTS_VALU" in counters:
     d["valu_wave_instructions_per_launch"] = counters["SQ_INSTS_VALU"]
+# the launch plan and commit the counters belong to (bench.py only quotes `traffic` from a summary whose plan matches its own)
+try:
+    with open(os.path.join(src, "trace.log")) as fh:
+        line = next(l for l in reversed(fh.read().splitlines()) if l.startswith("{") and "kernel_plan" in l)
+    out["kernel_plan"] = json.loads(line)["config"]["kernel_plan"]
+except (OSError, StopIteration, KeyError, ValueError):
+    out["kernel_plan"] = None
 json.dump(out, open(f"{prefix}_pmc_summary.json", "w"), indent=1)
 print(json.dumps(out["derived"], indent=1))
 print("kernel avg ms", out["kernel_trace_avg_ms"])
