@@ -24,17 +24,38 @@ std::atomic<double> g_softening_sq_f64{0.0};
 std::atomic<int> g_ovr_i{0}, g_ovr_s{0}, g_ovr_tile{0};
 
 
-int cu_count_cached() {
-    static std::atomic<int> cached[64] = {};
-    int                     dev        = 0;
+// The HIP runtime sets parts of itself up lazily, on the first call that needs them (the null stream, the first event,
+// the staging path of the first pageable copy), and some of that set-up draws from libc rand().  Do all of it ONCE per
+// device, under the guard, so that the launch path (kernel launches, event records, stream waits) can stay lock-free
+// without ever being the call that triggers a lazy initialisation.
+int current_device_ready() {
+    static std::atomic<int> cu_count[64] = {};
+    int                     dev          = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
-    int v = cached[dev].load(std::memory_order_relaxed);
+    int v = cu_count[dev].load(std::memory_order_acquire);
     if (v == 0) {
+        NB_KEEP_RAND_STREAM;
         if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
-        cached[dev].store(v, std::memory_order_relaxed);
+        void* scratch = nullptr;
+        if (hipMalloc(&scratch, 256) == hipSuccess) {
+            const unsigned word  = 0;
+            hipEvent_t     event = nullptr;
+            (void)hipMemcpy(scratch, &word, sizeof(word), hipMemcpyHostToDevice);  // pageable copy: the known consumer of rand() draws
+            (void)hipMemsetAsync(scratch, 0, 256, nullptr);
+            if (hipEventCreate(&event) == hipSuccess) {
+                (void)hipEventRecord(event, nullptr);
+                (void)hipStreamWaitEvent(nullptr, event, 0);
+                (void)hipEventSynchronize(event);
+                (void)hipEventDestroy(event);
+            }
+            (void)hipStreamSynchronize(nullptr);
+            (void)hipFree(scratch);
+        }
+        cu_count[dev].store(v, std::memory_order_release);
     }
     return v;
 }
+inline int cu_count_cached() { return current_device_ready(); }
 
 inline hipStream_t as_stream(nb_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 inline hipEvent_t  as_event(nb_event_t e) { return reinterpret_cast<hipEvent_t>(e); }
@@ -43,7 +64,8 @@ template <typename T> bool aligned_vec4(const void* p) { return (reinterpret_cas
 
 template <typename T>
 int integrate_shard(T* new_pos, const T* old_pos, T* vel, T* acc, unsigned i_begin, unsigned i_count, unsigned j_begin, unsigned j_count, unsigned flags, T dt, T damping, T eps2, int block_size, int mode, nb_stream_t stream) {
-    NB_KEEP_RAND_STREAM;
+    // (no rand()-stream guard here: a kernel launch draws nothing -- tests/test_gpu_parity.py checks it -- and the hot path
+    // stays free of the guard's process-wide lock)
     const bool acc_in   = (flags & NB_SHARD_ACC_IN) != 0;
     const bool finalize = (flags & NB_SHARD_FINALIZE) != 0;
     if (!old_pos || i_count == 0) return NB_ERR_INVALID_ARGUMENT;
@@ -58,13 +80,14 @@ int integrate_shard(T* new_pos, const T* old_pos, T* vel, T* acc, unsigned i_beg
     s.acc_in = acc_in, s.finalize = finalize;
     s.dt = dt, s.damping = damping, s.eps2 = eps2;
 
+    const int cu_count = current_device_ready();
     if (mode == NB_MODE_STRICT) {
         if (block_size <= 0) block_size = 256;  // the reference's default --blockSize (nbody.cpp:285)
         if (block_size % 64 != 0 || block_size > 1024) return NB_ERR_INVALID_ARGUMENT;
-        return static_cast<int>(nb::launch_strict<T>(s, block_size, cu_count_cached(), as_stream(stream)));
+        return static_cast<int>(nb::launch_strict<T>(s, block_size, cu_count, as_stream(stream)));
     }
     if (mode == NB_MODE_FAST) {
-        const nb::Plan p = nb::plan_fast<T>(i_count, j_count, cu_count_cached(), g_ovr_i.load(), g_ovr_s.load(), g_ovr_tile.load());
+        const nb::Plan p = nb::plan_fast<T>(i_count, j_count, cu_count, g_ovr_i.load(), g_ovr_s.load(), g_ovr_tile.load());
         return static_cast<int>(nb::launch_fast<T>(s, p, as_stream(stream)));
     }
     return NB_ERR_INVALID_ARGUMENT;
@@ -119,7 +142,6 @@ template <typename T> int graph_create(nb_graph_t* out, T* pos_a, T* pos_b, T* v
 
 template <typename T> int plan_query(unsigned i_count, unsigned j_count, nb_launch_plan_t* out) {
     if (!out || i_count == 0) return NB_ERR_INVALID_ARGUMENT;
-    NB_KEEP_RAND_STREAM;
     const nb::Plan p     = nb::plan_fast<T>(i_count, j_count, cu_count_cached(), g_ovr_i.load(), g_ovr_s.load(), g_ovr_tile.load());
     out->bodies_per_lane = p.bodies_per_lane;
     out->lanes_per_body  = p.lanes_per_body;
@@ -157,7 +179,11 @@ int nb_device_count(int* count) {
     return static_cast<int>(hipGetDeviceCount(count));
 }
 int nb_set_device(int device) {
-    NB_KEEP_RAND_STREAM; return static_cast<int>(hipSetDevice(device)); }
+    NB_KEEP_RAND_STREAM;
+    const auto err = hipSetDevice(device);
+    if (err == hipSuccess) (void)current_device_ready();
+    return static_cast<int>(err);
+}
 int nb_get_device(int* device) {
     NB_KEEP_RAND_STREAM;
     if (!device) return NB_ERR_INVALID_ARGUMENT;
@@ -237,7 +263,8 @@ int nb_stream_destroy(nb_stream_t stream) {
 int nb_stream_synchronize(nb_stream_t stream) {
     NB_KEEP_RAND_STREAM; return static_cast<int>(hipStreamSynchronize(as_stream(stream))); }
 int nb_stream_wait_event(nb_stream_t stream, nb_event_t event) {
-    NB_KEEP_RAND_STREAM; return static_cast<int>(hipStreamWaitEvent(as_stream(stream), as_event(event), 0)); }
+    (void)current_device_ready();
+    return static_cast<int>(hipStreamWaitEvent(as_stream(stream), as_event(event), 0)); }
 
 int nb_event_create(nb_event_t* event) {
     NB_KEEP_RAND_STREAM;
@@ -250,11 +277,11 @@ int nb_event_create(nb_event_t* event) {
 int nb_event_destroy(nb_event_t event) {
     NB_KEEP_RAND_STREAM; return static_cast<int>(hipEventDestroy(as_event(event))); }
 int nb_event_record(nb_event_t event, nb_stream_t stream) {
-    NB_KEEP_RAND_STREAM; return static_cast<int>(hipEventRecord(as_event(event), as_stream(stream))); }
+    (void)current_device_ready();
+    return static_cast<int>(hipEventRecord(as_event(event), as_stream(stream))); }
 int nb_event_synchronize(nb_event_t event) {
     NB_KEEP_RAND_STREAM; return static_cast<int>(hipEventSynchronize(as_event(event))); }
 int nb_event_elapsed_ms(float* ms, nb_event_t start, nb_event_t stop) {
-    NB_KEEP_RAND_STREAM;
     if (!ms) return NB_ERR_INVALID_ARGUMENT;
     return static_cast<int>(hipEventElapsedTime(ms, as_event(start), as_event(stop)));
 }
@@ -304,7 +331,7 @@ int nb_graph_create_f64(nb_graph_t* graph, double* position_a, double* position_
 }
 int nb_graph_launch(nb_graph_t graph, nb_stream_t stream) {
     if (!graph) return NB_ERR_INVALID_ARGUMENT;
-    NB_KEEP_RAND_STREAM;
+    (void)current_device_ready();
     return static_cast<int>(hipGraphLaunch(static_cast<StepGraph*>(graph)->exec, as_stream(stream)));
 }
 int nb_graph_destroy(nb_graph_t graph) {

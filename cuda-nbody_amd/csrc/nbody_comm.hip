@@ -153,6 +153,7 @@ void free_resources(Comm* c) {
 int exchange_tiles(const std::vector<Comm*>& locals, void* const* positions, unsigned num_bodies, size_t bytes_per_body, int nccl_type, const hipStream_t* after) {
     Rccl* lib = rccl();
     if (lib == nullptr) return NB_ERR_UNSUPPORTED;
+    NB_KEEP_RAND_STREAM;  // RCCL calls below; a world of one never gets here
     const int G = locals.front()->world;
     if (num_bodies % static_cast<unsigned>(G)) return NB_ERR_INVALID_ARGUMENT;
     const size_t slice_bodies = num_bodies / static_cast<unsigned>(G);
@@ -203,7 +204,6 @@ template <> struct Api<double> {
 // One step for every local rank: kernels of the own slice and of each tile as it arrives, integrate, start the next exchange.
 template <typename T>
 int sharded_step(nb_comm_t const* comms, int n_local, T* const* new_pos, const T* const* old_pos, T* const* vel, T* const* acc, unsigned num_bodies, T dt, T damping, int block_size, int mode, const nb_stream_t* streams) {
-    NB_KEEP_RAND_STREAM;
     if (comms == nullptr || n_local < 1 || !new_pos || !old_pos || !vel || !acc || !streams) return NB_ERR_INVALID_ARGUMENT;
     std::vector<Comm*> locals(static_cast<size_t>(n_local));
     for (int k = 0; k < n_local; ++k) {
@@ -352,7 +352,6 @@ int nb_exchange_tiles_f32(nb_comm_t comm, float* positions, unsigned num_bodies,
 int nb_exchange_tiles_f64(nb_comm_t comm, double* positions, unsigned num_bodies, nb_stream_t after) { return exchange_one(comm, positions, num_bodies, 32, ncclFloat64, after); }
 
 int nb_exchange_wait_tile(nb_comm_t comm, int peer, nb_stream_t stream) {
-    NB_KEEP_RAND_STREAM;
     Comm* c = as_comm(comm);
     if (c == nullptr || peer < 0 || peer >= c->world) return NB_ERR_INVALID_ARGUMENT;
     if (peer == c->rank || c->in_flight == nullptr) return 0;

@@ -12,6 +12,14 @@
  * reference's print+exit(1) / throw behaviour is reproduced by the C++ wrappers in
  * cuda-nbody_amd/host/integrate_nbody_hip.hpp so a host can keep its own error policy.
  *
+ * The reference draws its initial conditions from the process-global libc rand() stream, and the HIP runtime
+ * consumes draws from it (its first pageable host-to-device copy does).  The entry points that set up state --
+ * device selection and query, allocation, copies, the blocking synchronize calls, graph creation, communicator creation and
+ * the RCCL exchange -- therefore park the caller's rand() state for the duration of the call (a process-wide lock around
+ * initstate/setstate: another thread calling rand() inside that window draws from a scratch state).  The launch path --
+ * nb_integrate_*, nb_integrate_shard_*, nb_graph_launch, nb_event_record, nb_stream_wait_event, and nb_sharded_step_* in
+ * a world of one -- takes no lock and touches no such state.
+ *
  * All reference citations are relative to j-horner/cuda-nbody (/root/reference/).
  *
  * Data layout (identical to the reference's, src/nbody/bodysystemcuda.cu:148):

@@ -44,6 +44,9 @@ def build(with_ref: bool | None = None) -> None:
 
 
 def _load(name: str) -> ctypes.CDLL:
+    override = os.environ.get("NBODY_ORACLE_LIB")  # `make test-sanitize`: the ASan/UBSan build of the single-thread checker
+    if override and name == "liboracle.so":
+        return ctypes.CDLL(override)
     path = os.path.join(HERE, name)
     if not os.path.exists(path):
         build()

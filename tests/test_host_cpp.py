@@ -13,12 +13,12 @@ import pytest
 from conftest import ROOT, load_golden
 
 PKG = os.path.join(ROOT, "cuda-nbody_amd")
-CLI = os.path.join(PKG, "nbody")
+CLI = os.environ.get("NBODY_CLI", os.path.join(PKG, "nbody"))  # `make test-sanitize` points these at the ASan/UBSan builds
 
 
 @pytest.fixture(scope="module")
 def host():
-    path = os.path.join(PKG, "libnbody_host.so")
+    path = os.environ.get("NBODY_HOST_LIB", os.path.join(PKG, "libnbody_host.so"))
     if not os.path.exists(path):
         subprocess.run(["make", "-s", "-C", os.path.join(PKG, "csrc")], check=True)
         subprocess.run(["make", "-s", "-C", os.path.join(PKG, "host")], check=True)
