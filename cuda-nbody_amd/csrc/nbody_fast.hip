@@ -101,6 +101,14 @@ __device__ __forceinline__ void interact(const typename Lane<T>::vec4 bj, const 
     using L   = Lane<T>;
     using vec = typename L::vec;
     const vec bx = L::splat(bj.x), by = L::splat(bj.y), bz = L::splat(bj.z), bm = L::splat(bj.w);
+    if constexpr (UNIT && sizeof(T) == 4) {
+        // Keep the whole 16-byte body in registers although the unit-mass loop never reads .w: z then stays the low half
+        // of the aligned pair {z, w} it was loaded into and is broadcast from there by op_sel.  Reading only 12 bytes frees
+        // the upper register, the allocator reuses it, and z gets copied out first (3 v_mov_b32 per 4 bodies j): +2.1 %
+        // measured with the full load (A/B on one box, profiles/round2_keep_w_ab.txt).  (Storing {x, y, m, z} instead, to
+        // rid the generic loop of its 4 mass copies per 4 bodies, made both loops worse.)
+        asm volatile("" : : "v"(bj.w));
+    }
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const vec dx   = bx - px[r];
@@ -114,6 +122,8 @@ __device__ __forceinline__ void interact(const typename Lane<T>::vec4 bj, const 
         ay[r]          = L::fma(dy, s, ay[r]);
         az[r]          = L::fma(dz, s, az[r]);
     }
+    // generic loop: keep {z, w} where it was loaded until the body is done with (rids the loop of 26 hazard s_nop per 4 bodies j)
+    if constexpr (!UNIT && sizeof(T) == 4) asm volatile("" : : "v"(bj.z), "v"(bj.w));
 }
 
 // The mass every sum of a j range is expressed in units of: the first body's, when 1/m is a well-behaved number

@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--mode", choices=["fast", "strict"], default="fast")
     ap.add_argument("--data", choices=["normal", "shell", "zeros"], default="normal", help="positions: standard normal / the reference's SHELL start-up / all bodies at the origin")
+    ap.add_argument("--masses", choices=["equal", "varied"], default="equal", help="varied: every chunk takes the generic (mass-multiplying) loop")
     ap.add_argument("plans", nargs="*", default=["0,0,0"])
     args = ap.parse_args()
     pkg = entry.load_package()
@@ -43,6 +44,9 @@ def main():
         pos, vel = p0.reshape(n, 4), v0.reshape(n, 4)
     elif args.data == "zeros":
         pos[:, :3] = 0
+    if args.masses == "varied":
+        pos = pos.copy()
+        pos[:, 3] = (0.5 + rng.random(n)).astype(dtype)
     mode = pkg.NB_MODE_FAST if args.mode == "fast" else pkg.NB_MODE_STRICT
     system = pkg.BodySystemHIP(n, 256, pkg.NBodyParams(), dtype, pos.ravel(), vel.ravel(), mode=mode)
     flops = 30 if args.fp64 else 20
@@ -61,7 +65,7 @@ def main():
         e1.record()
         e1.synchronize()
         ms = e0.elapsed_ms(e1) / args.steps
-        print(json.dumps({"data": args.data, "plan": plan, "I": p.bodies_per_lane, "S": p.lanes_per_body, "tile": p.tile_bodies, "grid": p.grid_blocks, "lds": p.lds_bytes,
+        print(json.dumps({"data": args.data, "masses": args.masses, "plan": plan, "I": p.bodies_per_lane, "S": p.lanes_per_body, "tile": p.tile_bodies, "grid": p.grid_blocks, "lds": p.lds_bytes,
                           "ms": round(ms, 4), "ginter_per_s": round(n * n / ms * 1e-6, 1), "frac": round(flops * n * n / (ms * 1e-3) / peak, 4)}), flush=True)
     pkg.set_plan_override(0, 0, 0)
 
