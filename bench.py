@@ -244,14 +244,17 @@ def main():
         sharded = entry.load_package_module("sharded")
         G = args.emulate_gpus
         i0, ni = sharded.slice_of(G // 2, G, n)
-        sched = sharded.chunk_schedule(i0, ni, n, False)
+        sched = sharded.tile_schedule(G // 2, G, n, False) if args.exchange == "rccl" else sharded.chunk_schedule(i0, ni, n, False)
         acc_t = torch.zeros_like(pos_t)
         nxt = pos_t.clone()
         rows = []
-        for I in ((1, 2, 4) if args.fp64 else (2, 4, 8)):
-            for S in (1, 2, 4, 8, 16):
-                for tile in (512, 1024, 2048, 4096):
-                    if tile < (256 if S <= 4 else 64 * S) or tile // (256 if S <= 4 else 64 * S) not in (1, 2, 4):
+        for I in ((1, 2, 4) if args.fp64 else (2, 4)):
+            for S in (4, 8, 16, 64):
+                for tile in (256, 512, 1024, 2048):
+                    if S == 64:
+                        if tile not in (512, 1024):
+                            continue
+                    elif tile < 64 * S or tile // (64 * S) not in (1, 2, 4):
                         continue
                     if lib.nb_set_plan_override(I, S, tile) != 0:
                         continue
@@ -313,10 +316,10 @@ def main():
 
     if args.sweep and world == 1:
         results = []
-        for I in ((1, 2, 4) if args.fp64 else (2, 4, 8)):
-            for S in (1, 2, 4, 8, 16, 64):
+        for I in ((1, 2, 4) if args.fp64 else (2, 4)):
+            for S in (4, 8, 16, 64):
                 for tile in (256, 512, 1024, 2048):
-                    blk = 256 if S <= 4 or S == 64 else 64 * S
+                    blk = 256 if S == 64 else 64 * S
                     if tile < blk or tile // blk not in (1, 2, 4):
                         continue
                     if S == 64 and (tile not in (512, 1024) or I > (2 if args.fp64 else 4)):

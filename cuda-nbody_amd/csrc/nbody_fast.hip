@@ -592,7 +592,11 @@ template <typename T> Plan plan_fast(unsigned i_count, unsigned j_count, int cu_
         const double eff    = static_cast<double>(blocks) / static_cast<double>(rounds * cu_count) * (cand == kMaxI ? 1.0 : 0.97);
         if (eff >= best_eff) best_eff = eff, I = cand;
     }
-    int S = 8;
+    // S = 8 (two 512-thread workgroups per CU) once there are more than two rounds of workgroups per CU; with fewer, one
+    // 1024-thread workgroup per CU (S = 16) keeps four waves on every SIMD where S = 8 would leave two
+    // (profiles/round2_plan_sweep.txt: 65 536 bodies 0.92 vs 0.94-0.97 ms, 32 768-body shard 0.246 vs 0.26-0.28 ms).
+    const long blocks_at_i = (static_cast<long>(i_count) + 64L * I - 1) / (64L * I);
+    int        S           = blocks_at_i <= 2L * cu_count ? 16 : 8;
     // The wave-split layout has no such quantisation (its workgroups are 64-256x smaller) but runs at ~0.78 (fp32) /
     // ~0.62 (fp64) of the tile layout's full rate (tools/layout_crossover.py): take it when the tile layout would
     // fill the chip worse than that.

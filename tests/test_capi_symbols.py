@@ -64,12 +64,12 @@ def test_launch_plan_heuristics_without_gpu(pkg):
     # full-size fp32 systems: 8 waves per 512-thread workgroup (two workgroups per CU), 4 bodies (2 packed pairs) per lane,
     # 128 bodies j per wave and chunk
     assert plan(262144, 262144) == (4, 8, 1024, 512, 1024)
-    assert plan(65536, 65536) == (4, 8, 1024, 512, 256)
+    assert plan(65536, 65536) == (4, 16, 2048, 1024, 256)  # one workgroup per CU: 1024 threads, so that every SIMD still holds four waves
     assert plan(1048576, 1048576) == (4, 8, 1024, 512, 4096)
     # strong-scaling shards of 262 144 bodies on 2 / 4 / 8 GPUs keep whole rounds of 256 workgroups
-    assert plan(131072, 262144)[:2] + plan(131072, 262144)[4:] == (4, 8, 512)
-    assert plan(65536, 262144)[:2] + plan(65536, 262144)[4:] == (4, 8, 256)
-    assert plan(32768, 262144)[:2] + plan(32768, 262144)[4:] == (2, 8, 256)
+    assert plan(131072, 262144)[:2] + plan(131072, 262144)[4:] == (4, 16, 512)
+    assert plan(65536, 262144)[:2] + plan(65536, 262144)[4:] == (4, 16, 256)
+    assert plan(32768, 262144)[:2] + plan(32768, 262144)[4:] == (2, 16, 256)
     # small or awkward sizes: wave-split layout (lanes_per_body == 64), 256-thread workgroups
     for n in (1, 1024, 4096, 16384, 40960):
         assert plan(n, n)[1] == 64 and plan(n, n)[3] == 256, n
