@@ -93,6 +93,15 @@ variant("probe: 8 v_rsq + 24 v_fma_f32 interleaved", [RSQ(k) if k % 4 == 0 else 
 variant("probe: 32 v_rsq_f32", [RSQ(k) for k in range(32)], pairs_per_iter=32)
 variant("probe: 32 v_mul_f32", [MUL(k) for k in range(32)], pairs_per_iter=32)
 
+
+# ---- s_setprio semantics: the two older waves of every SIMD (wave < 8) at level a, the two younger ones at level b -------
+if len(loops) > 1:
+    unit = loops[1][1]
+    for a in range(4):
+        for b in range(4):
+            pro = ["v_lshrrev_b32 v1, 9, %4", "v_readfirstlane_b32 s41, v1", "s_cmp_eq_u32 s41, 0", "s_cbranch_scc0 11f", f"s_setprio {a}", "s_branch 12f", "11:", f"s_setprio {b}", "12:"]
+            variant(f"setprio: waves 0-7 level {a}, waves 8-15 level {b}", unit, prologue=pro)
+
 print("// GENERATED by tools/loop_microbench_gen.py -- do not edit")
 print("#include <hip/hip_runtime.h>\n#include <algorithm>\n#include <cstdio>\n#include <cstdlib>\n#include <vector>")
 clob = ", ".join(f'"v{r}"' for r in range(1, 128))
