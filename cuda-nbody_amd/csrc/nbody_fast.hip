@@ -56,12 +56,20 @@ template <> struct Lane<float> {
     static __device__ __forceinline__ vec  fma(vec a, vec b, vec c) { return __builtin_elementwise_fma(a, b, c); }
     // s = m * d2^(-3/2): 2 x v_rsq_f32 (1 ulp, what the reference's rsqrtf is) + 3 v_pk_mul_f32   (bodysystemcuda.cu:110-115);
     // UNIT: the body's relative mass is 1 -> 2 v_pk_mul_f32
-    template <bool UNIT> static __device__ __forceinline__ vec coupling(vec m, vec d2) {
+    // `zm` is the register pair {z, m} of the body j as loaded: the mass is broadcast from its HIGH half by op_sel (written
+    // as one inline instruction: left to itself hipcc copies the mass into the low half of another pair first)
+    template <bool UNIT> static __device__ __forceinline__ vec coupling(vec zm, vec d2) {
         const vec inv  = vec{__builtin_amdgcn_rsqf(d2.x), __builtin_amdgcn_rsqf(d2.y)};
         const vec inv2 = inv * inv;
-        if constexpr (UNIT) return inv * inv2;
-        return (m * inv) * inv2;
+        const vec inv3 = inv * inv2;
+        if constexpr (UNIT) return inv3;
+        // (the inline instruction must not read a v_rsq result directly: gfx950 needs a wait state between a transcendental
+        // and a VALU op that uses its result, and hipcc's hazard pass does not look inside inline asm -- it multiplies inv^3)
+        vec s;
+        asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(s) : "v"(zm), "v"(inv3));
+        return s;
     }
+    static __device__ __forceinline__ vec z_and_mass(const vec4& b) { return vec{b.z, b.w}; }
     static __device__ __forceinline__ float get(vec a, int w) { return w == 0 ? a.x : a.y; }
     static __device__ __forceinline__ void  set(vec& a, int w, float v) {
         if (w == 0) a.x = v; else a.y = v;
@@ -79,6 +87,7 @@ template <> struct Lane<double> {
     // iterating on y: with r = 1 - d2*y0^2 (|r| <= 2^-22),  d2^(-3/2) = y0^3 (1-r)^(-3/2) = y0^3 (1 + 3/2 r + 15/8 r^2 + O(r^3)),
     // truncation 35/16 r^3 < 2^-64.  7 DP ops + the seed, against 10 for two Newton steps on y followed by the cube
     // (the reference calls CUDA's <= 1 ulp rsqrt(double) here, bodysystemcuda.cu:82-84,110-115).  UNIT: 6 DP ops.
+    static __device__ __forceinline__ vec z_and_mass(const vec4& b) { return b.w; }
     template <bool UNIT> static __device__ __forceinline__ vec coupling(vec m, vec d2) {
         const double y0 = __builtin_amdgcn_rsq(d2);
         const double t0 = y0 * y0;
@@ -100,7 +109,7 @@ __device__ __forceinline__ void interact(const typename Lane<T>::vec4 bj, const 
                                          typename Lane<T>::vec (&ay)[R], typename Lane<T>::vec (&az)[R], const typename Lane<T>::vec eps2) {
     using L   = Lane<T>;
     using vec = typename L::vec;
-    const vec bx = L::splat(bj.x), by = L::splat(bj.y), bz = L::splat(bj.z), bm = L::splat(bj.w);
+    const vec bx = L::splat(bj.x), by = L::splat(bj.y), bz = L::splat(bj.z), bm = L::z_and_mass(bj);
     if constexpr (UNIT && sizeof(T) == 4) {
         // Keep the whole 16-byte body in registers although the unit-mass loop never reads .w: z then stays the low half
         // of the aligned pair {z, w} it was loaded into and is broadcast from there by op_sel.  Reading only 12 bytes frees

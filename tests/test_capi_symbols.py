@@ -83,3 +83,28 @@ def test_launch_plan_heuristics_without_gpu(pkg):
     finally:
         pkg.set_plan_override(0, 0, 0)
     assert plan(262144, 262144)[1] == 8
+
+
+def test_inline_asm_never_consumes_a_transcendental_result_directly():
+    """gfx950 needs a wait state between a transcendental op (v_rsq_f32 ...) and a VALU op that reads its result; hipcc's
+    hazard pass inserts it but does not look inside inline asm.  The FAST kernels carry ONE inline instruction (the packed
+    multiply that broadcasts the mass from the high half of {z, m}); its operands must therefore never be the direct output
+    of a v_rsq/v_rcp (it multiplies inv^3, the output of an ordinary v_pk_mul).  Checked on the compiled ISA of every
+    instantiation: no inline v_pk_mul may have a transcendental writing one of its source registers among the two
+    instructions before it."""
+    import subprocess
+
+    csrc = os.path.join(ROOT, "cuda-nbody_amd", "csrc")
+    subprocess.run(["make", "-s", "-C", csrc, "asm"], check=True, capture_output=True)
+    lines = open(os.path.join(csrc, "nbody_fast.s")).read().split("\n")
+    inline = 0
+    for i, line in enumerate(lines):
+        if "v_pk_mul_f32" in line and "op_sel:[1,0] op_sel_hi:[1,1]" in line:
+            inline += 1
+            m = re.search(r"v_pk_mul_f32 v\[(\d+):(\d+)\], v\[(\d+):(\d+)\], v\[(\d+):(\d+)\]", line)
+            sources = {int(m.group(k)) for k in (3, 4, 5, 6)}
+            before = [x.strip() for x in lines[max(0, i - 8):i] if x.strip() and not x.strip().startswith(";")][-2:]
+            for prev in before:
+                t = re.match(r"v_(rsq|rcp|sqrt|exp|log|sin|cos)_f32(_e32|_e64)? v(\d+),", prev)
+                assert not (t and int(t.group(3)) in sources), (i, prev, line)
+    assert inline > 0  # the instruction is there (otherwise this test checks nothing)
