@@ -58,7 +58,9 @@ template <> struct Lane<float> {
     // UNIT: the body's relative mass is 1 -> 2 v_pk_mul_f32
     // `zm` is the register pair {z, m} of the body j as loaded: the mass is broadcast from its HIGH half by op_sel (written
     // as one inline instruction: left to itself hipcc copies the mass into the low half of another pair first)
-    template <bool UNIT> static __device__ __forceinline__ vec coupling(vec zm, vec d2) {
+    struct Consts {};
+    static __device__ __forceinline__ Consts make_consts() { return {}; }
+    template <bool UNIT> static __device__ __forceinline__ vec coupling(vec zm, vec d2, const Consts&) {
         const vec inv  = vec{__builtin_amdgcn_rsqf(d2.x), __builtin_amdgcn_rsqf(d2.y)};
         const vec inv2 = inv * inv;
         const vec inv3 = inv * inv2;
@@ -88,13 +90,24 @@ template <> struct Lane<double> {
     // truncation 35/16 r^3 < 2^-64.  7 DP ops + the seed, against 10 for two Newton steps on y followed by the cube
     // (the reference calls CUDA's <= 1 ulp rsqrt(double) here, bodysystemcuda.cu:82-84,110-115).  UNIT: 6 DP ops.
     static __device__ __forceinline__ vec z_and_mass(const vec4& b) { return b.w; }
-    template <bool UNIT> static __device__ __forceinline__ vec coupling(vec m, vec d2) {
+    // 15/8 and 3/2 are not inline constants of the ISA; left as literals hipcc rebuilds 1.5 in a register pair before
+    // every v_fmac_f64 (2 v_mov_b32 per interaction).  Pinned in registers once per kernel they feed a 3-operand v_fma_f64.
+    struct Consts {
+        double c1875, c15;
+    };
+    static __device__ __forceinline__ Consts make_consts() {
+        Consts c{1.875, 1.5};
+        asm volatile("" : "+v"(c.c1875), "+v"(c.c15));
+        return c;
+    }
+    template <bool UNIT> static __device__ __forceinline__ vec coupling(vec m, vec d2, const Consts& k) {
+        const double c1875 = k.c1875, c15 = k.c15;
         const double y0 = __builtin_amdgcn_rsq(d2);
         const double t0 = y0 * y0;
         const double r  = __builtin_fma(-d2, t0, 1.0);
         double       mc = y0 * t0;
         if constexpr (!UNIT) mc = m * mc;
-        const double w  = r * __builtin_fma(r, 1.875, 1.5);
+        const double w  = r * __builtin_fma(r, c1875, c15);
         return __builtin_fma(mc, w, mc);
     }
     static __device__ __forceinline__ double get(vec a, int) { return a; }
@@ -106,7 +119,7 @@ template <> struct Lane<double> {
 // bj.w is the body's mass relative to the range's reference mass; UNIT: it is exactly 1 and never read.
 template <typename T, int R, bool UNIT>
 __device__ __forceinline__ void interact(const typename Lane<T>::vec4 bj, const typename Lane<T>::vec (&px)[R], const typename Lane<T>::vec (&py)[R], const typename Lane<T>::vec (&pz)[R], typename Lane<T>::vec (&ax)[R],
-                                         typename Lane<T>::vec (&ay)[R], typename Lane<T>::vec (&az)[R], const typename Lane<T>::vec eps2) {
+                                         typename Lane<T>::vec (&ay)[R], typename Lane<T>::vec (&az)[R], const typename Lane<T>::vec eps2, const typename Lane<T>::Consts& consts) {
     using L   = Lane<T>;
     using vec = typename L::vec;
     const vec bx = L::splat(bj.x), by = L::splat(bj.y), bz = L::splat(bj.z), bm = L::z_and_mass(bj);
@@ -126,7 +139,7 @@ __device__ __forceinline__ void interact(const typename Lane<T>::vec4 bj, const 
         vec       d2   = L::fma(dx, dx, eps2);
         d2             = L::fma(dy, dy, d2);
         d2             = L::fma(dz, dz, d2);
-        const vec s    = L::template coupling<UNIT>(bm, d2);
+        const vec s    = L::template coupling<UNIT>(bm, d2, consts);
         ax[r]          = L::fma(dx, s, ax[r]);
         ay[r]          = L::fma(dy, s, ay[r]);
         az[r]          = L::fma(dz, s, az[r]);
@@ -204,6 +217,7 @@ template <typename T, int R, int S, int LPT> __global__ __launch_bounds__(block_
     }
     vec eps2 = LT::splat(s.eps2);
     LT::keep_in_vgpr(eps2);
+    const typename LT::Consts consts = LT::make_consts();
 
     const unsigned j_end    = s.j_begin + s.j_count;
     const unsigned n_chunks = (s.j_count + CH - 1) / CH;
@@ -315,13 +329,13 @@ template <typename T, int R, int S, int LPT> __global__ __launch_bounds__(block_
 #pragma unroll 1
             for (int jj = 0; jj < CH; jj += U) {
 #pragma unroll
-                for (int u = 0; u < U; ++u) interact<T, R, true>(chunk[jj + u], px, py, pz, ax, ay, az, eps2);
+                for (int u = 0; u < U; ++u) interact<T, R, true>(chunk[jj + u], px, py, pz, ax, ay, az, eps2, consts);
             }
         } else {
 #pragma unroll 1
             for (int jj = 0; jj < CH; jj += U) {
 #pragma unroll
-                for (int u = 0; u < U; ++u) interact<T, R, false>(chunk[jj + u], px, py, pz, ax, ay, az, eps2);
+                for (int u = 0; u < U; ++u) interact<T, R, false>(chunk[jj + u], px, py, pz, ax, ay, az, eps2, consts);
             }
         }
 
@@ -451,6 +465,7 @@ template <typename T, int R, int LPT> __global__ __launch_bounds__(256) void int
     for (int r = 0; r < R; ++r) ax[r] = ay[r] = az[r] = LT::splat(0);
     vec eps2 = LT::splat(s.eps2);
     LT::keep_in_vgpr(eps2);
+    const typename LT::Consts consts = LT::make_consts();
 
     const unsigned j_end   = s.j_begin + s.j_count;
     const unsigned n_tiles = (s.j_count + TILE - 1) / TILE;
@@ -483,7 +498,7 @@ template <typename T, int R, int LPT> __global__ __launch_bounds__(256) void int
 #pragma unroll 1
         for (int jj = 0; jj < TILE; jj += 64 * U) {
 #pragma unroll
-            for (int u = 0; u < U; ++u) interact<T, R, false>(mine[jj + 64 * u], px, py, pz, ax, ay, az, eps2);
+            for (int u = 0; u < U; ++u) interact<T, R, false>(mine[jj + 64 * u], px, py, pz, ax, ay, az, eps2, consts);
         }
         if (have_next) store_tile(cur ^ 1, regs);
         __syncthreads();
