@@ -51,11 +51,12 @@ def parse_args():
     ap.add_argument("--cpu-sample-bodies", type=int, default=0, help="bodies i in the CPU sample (0 = auto, ~10 s)")
     ap.add_argument("--sweep", action="store_true", help="time every fast-kernel geometry (tuning aid), N=1 only")
     ap.add_argument("--plan", type=str, default="", help="I,S,TILE override for the fast kernel, e.g. 2,1,1024")
-    ap.add_argument("--exchange", choices=["rccl", "allgather", "host"], default="rccl",
+    ap.add_argument("--exchange", choices=["rccl", "allgather", "host", "host-tiles"], default="rccl",
                     help="rccl: the position all-gather issued as its G-1 tiles (one grouped RCCL send/recv pair per round, the kernel "
                          "of tile k waiting only on round k); allgather: one all_gather_into_tensor per step; "
                          "host: gloo + host-staged all-gather, so that several ranks can share ONE GPU (functional rehearsal of the "
-                         "N-rank code path on a one-GPU box; RCCL refuses two ranks per device).  host is never a performance number.")
+                         "N-rank code path on a one-GPU box; RCCL refuses two ranks per device); host-tiles: the same rehearsal with the TILE "
+                         "schedule (gloo send/recv rounds on device tensors).  host* is never a performance number.")
     ap.add_argument("--emulate-gpus", type=int, default=0,
                     help="on ONE GPU, run rank 0's kernel schedule of a G-rank strong-scaling job (no collective): "
                          "projection aid, prints its own JSON and never the headline metric")
@@ -142,7 +143,7 @@ def main():
     if args.plan:
         pkg.set_plan_override(*[int(x) for x in args.plan.split(",")])
 
-    if args.exchange == "host":
+    if args.exchange.startswith("host"):
         local_rank = 0  # every rank on the one GPU
     torch.cuda.set_device(local_rank)
     pkg.check(lib.nb_set_device(local_rank), "nb_set_device")
@@ -156,7 +157,7 @@ def main():
         # RCCL's all-gather kernel competes with the force kernel for CUs (a 1024-thread workgroup fills a CU's VGPRs):
         # a high-priority stream lets its few workgroups dispatch first, so the exchange overlaps the own-slice chunk
         # instead of queueing behind it.
-        if args.exchange == "host":
+        if args.exchange.startswith("host"):
             dist.init_process_group("gloo")
         else:
             try:
@@ -203,7 +204,7 @@ def main():
                 full.copy_(staged)
                 return _Done()
 
-        form = "tiles" if args.exchange == "rccl" else "allgather"
+        form = "tiles" if args.exchange in ("rccl", "host-tiles") else "allgather"
         system = sharded.ShardedBodySystem(pos_t, vel_t, launch, ordered=(mode == pkg.NB_MODE_STRICT), gather=host_gather, exchange=form)
         step = system.update
         finish = system.finish
@@ -361,7 +362,7 @@ def main():
     launches = kernel_launches[0] - launches_before
 
     if distributed:
-        t = torch.tensor([elapsed], device=dev if args.exchange != "host" else "cpu", dtype=torch.float64)
+        t = torch.tensor([elapsed], device="cpu" if args.exchange.startswith("host") else dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -413,6 +414,7 @@ def main():
                 "bodies_per_gpu": n // world,
                 "exchange": "none" if world == 1 else (
                     "REHEARSAL: gloo, host-staged gather, ranks share one GPU" if args.exchange == "host" else
+                    "REHEARSAL: gloo send/recv rounds (tile schedule) on device tensors, ranks share one GPU" if args.exchange == "host-tiles" else
                     "RCCL all-gather of the new positions per step, issued as G-1 position tiles (grouped send/recv rounds on RCCL's stream); "
                     "the kernel of tile k waits only on round k, the own-slice chunk runs first" if system.exchange == "tiles" else
                     "RCCL all_gather_into_tensor of the new positions per step, overlapped with the own-slice j chunk"),

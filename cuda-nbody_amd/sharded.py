@@ -117,17 +117,30 @@ class ShardedBodySystem:
     def _start_tiles(self, full) -> None:
         """Round s = 1..G-1: send the own slice to rank-s, receive the slice of rank+s into its place in `full`.
         One grouped send/recv pair per round (batch_isend_irecv = ncclGroupStart/End on RCCL): the rounds complete in
-        order on RCCL's stream, and the kernel of a tile waits only for its own round."""
+        order on RCCL's stream, and the kernel of a tile waits only for its own round.
+        gloo with device tensors (the one-GPU rehearsal): gloo is not stream-aware, so the slices are staged through host
+        memory -- own slice copied out after a stream synchronize, tiles copied in when their round is waited for."""
         dist, G, r, ni = self.dist, self.world, self.rank, self.ni
         own = full[self.i0:self.i0 + ni]
+        staged = full.is_cuda and dist.get_backend(self.group) == "gloo"
+        if staged:
+            import torch
+
+            torch.cuda.current_stream().synchronize()
+            own = own.cpu()
         for s in range(1, G):
             dst, src = (r - s) % G, (r + s) % G
-            ops = [dist.P2POp(dist.isend, own, dst, group=self.group), dist.P2POp(dist.irecv, full[src * ni:(src + 1) * ni], src, group=self.group)]
-            self.arrivals[src] = dist.batch_isend_irecv(ops)
+            target = full[src * ni:(src + 1) * ni]
+            landing = own.new_empty(own.shape) if staged else target
+            ops = [dist.P2POp(dist.isend, own, dst, group=self.group), dist.P2POp(dist.irecv, landing, src, group=self.group)]
+            self.arrivals[src] = (dist.batch_isend_irecv(ops), landing if staged else None, target)
 
     def _wait_tile(self, peer) -> None:
-        for work in self.arrivals.pop(peer, ()):
+        works, landing, target = self.arrivals.pop(peer, ((), None, None))
+        for work in works:
             work.wait()  # RCCL: the compute stream waits for the round's event, the host does not block
+        if landing is not None:
+            target.copy_(landing)
 
     def exchange_once(self, full) -> None:
         """One exchange of `full` outside any step (communicator bring-up / diagnostics)."""

@@ -19,7 +19,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, n, steps, mode_name, out_dir):
+def _worker(rank, world, port, n, steps, mode_name, out_dir, exchange="allgather"):
     sys.path.insert(0, ROOT)
     import ctypes
 
@@ -60,7 +60,10 @@ def _worker(rank, world, port, n, steps, mode_name, out_dir):
             return Done()
 
         sharded = entry.load_package_module("sharded")
-        system = sharded.ShardedBodySystem(pos_t, vel_t, launch, ordered=(mode == pkg.NB_MODE_STRICT), gather=gather)
+        if exchange == "tiles":  # gloo send/recv rounds on the device tensors themselves: the production tile schedule
+            system = sharded.ShardedBodySystem(pos_t, vel_t, launch, ordered=(mode == pkg.NB_MODE_STRICT), exchange="tiles")
+        else:
+            system = sharded.ShardedBodySystem(pos_t, vel_t, launch, ordered=(mode == pkg.NB_MODE_STRICT), gather=gather)
         for _ in range(steps):
             system.update()
         pos = system.positions().cpu().numpy()
@@ -72,12 +75,14 @@ def _worker(rank, world, port, n, steps, mode_name, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode_name", ["strict", "fast"])
-def test_two_ranks_on_one_gpu_match_the_oracle(tmp_path, oracle, mode_name):
+@pytest.mark.parametrize("mode_name,exchange,world", [("strict", "allgather", 2), ("fast", "allgather", 2), ("strict", "tiles", 4), ("fast", "tiles", 4)])
+def test_ranks_sharing_one_gpu_match_the_oracle(tmp_path, oracle, mode_name, exchange, world):
+    """2 ranks with the all-gather form (host-staged), 4 ranks with the TILE form (gloo send/recv rounds straight on the device
+    tensors: own slice first, then the tiles in arrival order, each kernel waiting on its own round; STRICT in rank order)."""
     import torch.multiprocessing as mp
 
-    n, steps, world = 4096, 3, 2
-    mp.spawn(_worker, args=(world, _free_port(), n, steps, mode_name, str(tmp_path)), nprocs=world, join=True)
+    n, steps = 4096, 3
+    mp.spawn(_worker, args=(world, _free_port(), n, steps, mode_name, str(tmp_path), exchange), nprocs=world, join=True)
     ref_pos, ref_vel = oracle.startup_state(n, np.float32)
     oracle.update(ref_pos, ref_vel, np.float32(0.016), steps=steps)
     ref_pos, ref_vel = ref_pos.reshape(n, 4), ref_vel.reshape(n, 4)
