@@ -102,6 +102,7 @@ template <typename T> int graph_create(nb_graph_t* out, T* pos_a, T* pos_b, T* v
     if (!out || !pos_a || !pos_b || !vel || pos_a == pos_b || n == 0 || steps < 2 || (steps & 1u)) return NB_ERR_INVALID_ARGUMENT;
     NB_KEEP_RAND_STREAM;
     *out = nullptr;
+    (void)current_device_ready();  // the one-time device warm-up allocates and copies: never inside a capture
     if (mode == NB_MODE_FAST) {  // arm the >64 KiB dynamic-LDS attribute outside the capture
         nb::Shard<T> probe{};
         probe.i_count = n, probe.j_count = n;
@@ -211,6 +212,7 @@ int nb_device_info(int device, nb_device_info_t* out) {
 int nb_alloc(void** device_ptr, size_t bytes) {
     NB_KEEP_RAND_STREAM;
     if (!device_ptr) return NB_ERR_INVALID_ARGUMENT;
+    (void)current_device_ready();
     return static_cast<int>(hipMalloc(device_ptr, bytes));
 }
 int nb_free(void* device_ptr) {
@@ -238,6 +240,7 @@ int nb_d2d(void* device_dst, const void* device_src, size_t bytes, nb_stream_t s
 int nb_host_alloc_mapped(void** host_ptr, void** device_ptr, size_t bytes) {
     NB_KEEP_RAND_STREAM;
     if (!host_ptr || !device_ptr) return NB_ERR_INVALID_ARGUMENT;
+    (void)current_device_ready();
     auto err = hipHostMalloc(host_ptr, bytes, hipHostMallocMapped | hipHostMallocPortable);
     if (err != hipSuccess) return static_cast<int>(err);
     err = hipHostGetDevicePointer(device_ptr, *host_ptr, 0);
@@ -253,6 +256,7 @@ int nb_host_free(void* host_ptr) {
 int nb_stream_create(nb_stream_t* stream) {
     NB_KEEP_RAND_STREAM;
     if (!stream) return NB_ERR_INVALID_ARGUMENT;
+    (void)current_device_ready();
     hipStream_t s   = nullptr;
     const auto  err = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
     *stream         = s;
@@ -269,6 +273,7 @@ int nb_stream_wait_event(nb_stream_t stream, nb_event_t event) {
 int nb_event_create(nb_event_t* event) {
     NB_KEEP_RAND_STREAM;
     if (!event) return NB_ERR_INVALID_ARGUMENT;
+    (void)current_device_ready();
     hipEvent_t e   = nullptr;
     const auto err = hipEventCreate(&e);
     *event         = e;

@@ -18,7 +18,9 @@
  * the RCCL exchange -- therefore park the caller's rand() state for the duration of the call (a process-wide lock around
  * initstate/setstate: another thread calling rand() inside that window draws from a scratch state).  The launch path --
  * nb_integrate_*, nb_integrate_shard_*, nb_graph_launch, nb_event_record, nb_stream_wait_event, and nb_sharded_step_* in
- * a world of one -- takes no lock and touches no such state.
+ * a world of one -- takes no lock and touches no such state.  The first call on a device (normally nb_set_device or
+ * nb_alloc) warms the runtime up once, under that guard, with a small allocation and copy; a caller that allocates
+ * with its own hipMalloc and wants to capture nb_integrate_* into a graph of its own calls nb_set_device first.
  *
  * All reference citations are relative to j-horner/cuda-nbody (/root/reference/).
  *
