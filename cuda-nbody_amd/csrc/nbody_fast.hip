@@ -308,10 +308,8 @@ template <typename T, int R, int S, int LPT> __global__ __launch_bounds__(block_
     for (; c < n_chunks; c += S) {
         const bool have_next = (c + S) < n_chunks;
         if (have_next) load_chunk(c + S, regs);  // global loads in flight across the compute below
-#ifndef NB_EXP_BALANCE
-#define NB_EXP_BALANCE 1
-#endif
-#if NB_EXP_BALANCE == 1  // a wave that is not ahead of any wave of its SIMD (same workgroup) runs at priority 3, the others at 0
+#ifndef NB_NO_BALANCE  // (diagnostic builds switch it off: tools/stamp_probe.py)
+        // a wave that is not ahead of any wave of its SIMD (same workgroup) runs at priority 3, the others at 0
         {
             unsigned least = done;
 #pragma unroll
