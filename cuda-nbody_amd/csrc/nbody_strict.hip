@@ -26,6 +26,7 @@
 //       div  : r = rcp(d); e = fma(-d,r,1); r = fma(e,r,r); q = n*r; e = fma(-d,q,n); q = fma(e,r,q); e = fma(-d,q,n); q = fma(e,r,q)
 //              is hipcc's own sequence with the identity scalings removed; == n/d on 1.7e10 random + structured pairs
 //     (profiles/round2_strict_fastpath_check.txt).  28 packed ops + 6 adds + 4 transcendentals per two interactions.
+//   * fast (fp64): one interaction at a time (no packed fp64), the same scaling-free divide and sqrt with its own window.
 #include "nbody_kernels.h"
 
 namespace nb {
@@ -133,6 +134,54 @@ __device__ __forceinline__ void interact_jpairs_fast(const v2f (&bx)[U], const v
     }
 }
 
+// fp64 has no packed form, but the same scaling-free divide and sqrt apply: hipcc's own sequences (v_rcp_f64 + two Newton
+// steps + quotient + one residual correction; v_rsq_f64 + Goldschmidt step + two residual corrections) without
+// v_div_scale / v_div_fmas' scaling / v_div_fixup / the 2^256 pre-scaling and the class check of sqrt, all of which are the
+// identity inside the window: |coordinate| <= 2^100, softening^2 in [2^-100, 2^100], mass +0 or 2^-100 <= |m| <= 2^100
+// (r2 in [2^-100, 2^203], r2^2 in [2^-200, 2^406], quotient in [2^-506, 2^300]).  Checked on 1.7e10 random + structured
+// operands and by asking v_div_scale_f64 itself over the window's exponent range (tools/strict_fastpath_check.hip).
+__device__ __forceinline__ double fast_sqrt_f64(double x) {
+    const double y = __builtin_amdgcn_rsq(x);
+    double       g = x * y;
+    double       h = y * 0.5;
+    const double r = __builtin_fma(-h, g, 0.5);
+    g              = __builtin_fma(g, r, g);
+    h              = __builtin_fma(h, r, h);
+    double d       = __builtin_fma(-g, g, x);
+    g              = __builtin_fma(d, h, g);
+    d              = __builtin_fma(-g, g, x);
+    return __builtin_fma(d, h, g);
+}
+__device__ __forceinline__ double fast_div_f64(double n, double d) {
+    double r = __builtin_amdgcn_rcp(d);
+    double e = __builtin_fma(-d, r, 1.0);
+    r        = __builtin_fma(r, e, r);
+    e        = __builtin_fma(-d, r, 1.0);
+    r        = __builtin_fma(r, e, r);
+    const double q = n * r;
+    e              = __builtin_fma(-d, q, n);
+    return __builtin_fma(e, r, q);
+}
+__device__ __forceinline__ void interact_fast_f64(const double4 bj, double pix, double piy, double piz, double& ax, double& ay, double& az, double eps2) {
+    const double dx  = bj.x - pix;
+    const double dy  = bj.y - piy;
+    const double dz  = bj.z - piz;
+    const double r2  = r2_T(dx * dx, dy * dy, dz * dz, eps2);
+    const double r   = fast_sqrt_f64(r2);
+    const double mr4 = fast_div_f64(bj.w, r2 * r2);
+    const double mr3 = mr4 * r;
+    ax               = ax + mr3 * dx;
+    ay               = ay + mr3 * dy;
+    az               = az + mr3 * dz;
+}
+__device__ __forceinline__ bool coord_in_window(double c) { return __builtin_fabs(c) <= 0x1p100; }  // false for NaN / inf
+__device__ __forceinline__ bool mass_in_window(double m) {
+    const double a = __builtin_fabs(m);
+    return __double_as_longlong(m) == 0ll || (a >= 0x1p-100 && a <= 0x1p100);
+}
+__device__ __forceinline__ bool softening_in_window(float e2) { return e2 >= 0x1p-39f && e2 <= 0x1p38f; }
+__device__ __forceinline__ bool softening_in_window(double e2) { return e2 >= 0x1p-100 && e2 <= 0x1p100; }
+
 // operand window of the fast form (see the header)
 __device__ __forceinline__ bool coord_in_window(float c) { return __builtin_fabsf(c) <= 0x1p18f; }  // false for NaN / inf
 __device__ __forceinline__ bool mass_in_window(float m) {
@@ -171,10 +220,10 @@ template <typename T> __global__ __launch_bounds__(512, 4) void integrate_bodies
     const T eps2 = s.eps2;
 
     // fast form: decided per wave for the bodies i ...
-    bool wave_in_window = false;
-    if constexpr (sizeof(T) == 4) {
+    bool wave_in_window;
+    {
         const bool mine = coord_in_window(pi.x) && coord_in_window(pi.y) && coord_in_window(pi.z);
-        wave_in_window  = __builtin_amdgcn_ballot_w64(!mine) == 0 && eps2 >= 0x1p-39f && eps2 <= 0x1p38f;
+        wave_in_window  = __builtin_amdgcn_ballot_w64(!mine) == 0 && softening_in_window(eps2);
     }
 
     // The SIMD arbiter is strictly oldest-first, and one wave alone reaches only 3/4 of a SIMD's issue rate: without help
@@ -205,11 +254,8 @@ template <typename T> __global__ __launch_bounds__(512, 4) void integrate_bodies
     auto store_chunk = [&](int buf, const vec4 v) -> bool {
         T* dst = ring + buf * (4 * kChunk) + lane;
         dst[0 * kChunk] = v.x, dst[1 * kChunk] = v.y, dst[2 * kChunk] = v.z, dst[3 * kChunk] = v.w;
-        if constexpr (sizeof(T) == 4) {
-            const bool ok = coord_in_window(v.x) && coord_in_window(v.y) && coord_in_window(v.z) && mass_in_window(v.w);
-            return __builtin_amdgcn_ballot_w64(!ok) == 0;
-        }
-        return false;
+        const bool ok = coord_in_window(v.x) && coord_in_window(v.y) && coord_in_window(v.z) && mass_in_window(v.w);
+        return __builtin_amdgcn_ballot_w64(!ok) == 0;
     };
 
     bool chunk_in_window = false;
@@ -260,6 +306,16 @@ template <typename T> __global__ __launch_bounds__(512, 4) void integrate_bodies
                     const v2f bx[1] = {*reinterpret_cast<const v2f*>(cx + k)}, by[1] = {*reinterpret_cast<const v2f*>(cy + k)};
                     const v2f bz[1] = {*reinterpret_cast<const v2f*>(cz + k)}, bm[1] = {*reinterpret_cast<const v2f*>(cm + k)};
                     interact_jpairs_fast<1>(bx, by, bz, bm, pi.x, pi.y, pi.z, ax, ay, az, e2);
+                }
+            }
+        }
+        if constexpr (sizeof(T) == 8) {
+            if (wave_in_window && chunk_in_window) {
+#pragma unroll 4
+                for (; k < cnt; ++k) {
+                    vec4 bj;
+                    bj.x = cx[k], bj.y = cy[k], bj.z = cz[k], bj.w = cm[k];
+                    interact_fast_f64(bj, pi.x, pi.y, pi.z, ax, ay, az, eps2);
                 }
             }
         }

@@ -494,46 +494,52 @@ def test_strict_bitwise_on_extreme_values(gpu, oracle, dtype):
     assert got_vel.tobytes() == ref_vel.tobytes()
 
 
-def test_strict_fast_form_window_edges_bitwise(gpu, oracle):
-    """The fp32 STRICT kernel runs divide and sqrt without scaling/fix-up steps while every operand sits inside a
-    checked window (|coordinate| <= 2^18, 2^-40 <= |mass| <= 2^40 or +0, softening^2 in [2^-39, 2^38]) and falls back to
-    the generic IEEE expansions per 64-body chunk otherwise.  Systems that sit ON the window's edges, mix in-window and
-    out-of-window chunks, produce denormal products (tiny separations) and carry -0 / zero masses must all stay 0 ulp."""
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_strict_fast_form_window_edges_bitwise(gpu, oracle, dtype):
+    """The STRICT kernels run divide and sqrt without scaling/fix-up steps while every operand sits inside a checked
+    window (fp32: |coordinate| <= 2^18, 2^-40 <= |mass| <= 2^40 or +0, softening^2 in [2^-39, 2^38]; fp64: 2^100, 2^+-100,
+    [2^-100, 2^100]) and fall back to the generic IEEE expansions per 64-body chunk otherwise.  Systems that sit ON the
+    window's edges, mix in-window and out-of-window chunks, produce denormal products (tiny separations) and carry -0 /
+    zero masses must all stay 0 ulp."""
     rng = np.random.default_rng(7)
     n = 64 * 9 + 17  # ragged last chunk
+    f32 = dtype == np.float32
+    cexp, mexp = (18, 40) if f32 else (100, 100)
+    ulp = 2.0 ** -23 if f32 else 2.0 ** -52
+    soft_lo, soft_hi = (2.0 ** -39, 2.0 ** 38) if f32 else (2.0 ** -100, 2.0 ** 100)  # softening^2 window
 
     def system(coord_scale, mass_lo, mass_hi):
-        pos = np.zeros((n, 4), np.float32)
-        pos[:, :3] = (rng.uniform(-1, 1, (n, 3)) * coord_scale).astype(np.float32)
-        pos[:, 3] = (2.0 ** rng.uniform(mass_lo, mass_hi, n)).astype(np.float32)
-        vel = (rng.standard_normal((n, 4)) * 0.1).astype(np.float32)
+        pos = np.zeros((n, 4), dtype)
+        pos[:, :3] = (rng.uniform(-1, 1, (n, 3)) * coord_scale).astype(dtype)
+        pos[:, 3] = (2.0 ** rng.uniform(mass_lo, mass_hi, n)).astype(dtype)
+        vel = (rng.standard_normal((n, 4)) * 0.1).astype(dtype)
         vel[:, 3] = 0
         return pos, vel
 
     cases = []
     # (a) exactly on the coordinate edge, masses on both mass edges
-    pos, vel = system(2.0 ** 18, -40, 40)
-    pos[0, :3] = 2.0 ** 18
-    pos[1, :3] = -(2.0 ** 18)
-    pos[2, 3], pos[3, 3] = 2.0 ** -40, 2.0 ** 40
+    pos, vel = system(2.0 ** cexp, -mexp, mexp)
+    pos[0, :3] = 2.0 ** cexp
+    pos[1, :3] = -(2.0 ** cexp)
+    pos[2, 3], pos[3, 3] = 2.0 ** -mexp, 2.0 ** mexp
     cases.append(("edges", pos, vel, 0.1))
-    # (b) one chunk just outside (coordinate 2^18 * (1 + 2^-23), mass 2^41, mass -0.0, inf, NaN-free), the others inside
+    # (b) single chunks just outside (coordinate one ulp above the edge, mass 2^(mexp+1), mass -0.0), the others inside
     pos, vel = system(100.0, -3, 3)
-    pos[64 * 2 + 5, 0] = np.float32(2.0 ** 18) * np.float32(1 + 2.0 ** -23)
-    pos[64 * 4 + 1, 3] = 2.0 ** 41
+    pos[64 * 2 + 5, 0] = dtype(2.0 ** cexp) * dtype(1 + ulp)
+    pos[64 * 4 + 1, 3] = 2.0 ** (mexp + 1)
     pos[64 * 6 + 9, 3] = -0.0
     pos[64 * 7 + 2, 3] = 0.0
     pos[64 * 8 + 3, 3] = -1.5  # negative masses are in the window too
     cases.append(("mixed chunks", pos, vel, 0.1))
-    # (c) tiny separations: dx^2 underflows / goes denormal, softening at the window's lower edge
+    # (c) tiny separations: dx^2 underflows / goes denormal (fp32), softening at the window's lower edge
     pos, vel = system(1.0, -2, 2)
-    pos[1::2, :3] = pos[0::2, :3][: pos[1::2].shape[0]] + np.float32(2.0 ** -70)
-    pos[5, :3] = pos[4, :3] * np.float32(1 + 2.0 ** -23)
-    cases.append(("tiny separations", pos, vel, float(np.sqrt(np.float32(2.0 ** -39)))))
+    pos[1::2, :3] = pos[0::2, :3][: pos[1::2].shape[0]] + dtype(2.0 ** -70)
+    pos[5, :3] = pos[4, :3] * dtype(1 + ulp)
+    cases.append(("tiny separations", pos, vel, float(np.sqrt(np.float32(soft_lo))) if f32 else 2.0 ** -50))
     # (d) softening outside the window (too small / too large): whole run on the generic form
     pos, vel = system(10.0, -2, 2)
-    cases.append(("softening below window", pos, vel, 2.0 ** -21))
-    cases.append(("softening above window", pos, vel, 2.0 ** 19.5))
+    cases.append(("softening below window", pos, vel, 2.0 ** -21 if f32 else 2.0 ** -60))
+    cases.append(("softening above window", pos, vel, 2.0 ** 19.5 if f32 else 2.0 ** 60))
     for name, pos, vel, softening in cases:
         pos0, vel0 = pos.reshape(-1).copy(), vel.reshape(-1).copy()
         params = gpu.NBodyParams(softening=softening, damping=0.999)

@@ -44,6 +44,29 @@ __device__ __forceinline__ float fast_div(float n, float d) {
     return __builtin_fmaf(e3, r, q);
 }
 
+__device__ __forceinline__ double fast_sqrt_f64(double x) {
+    const double y = __builtin_amdgcn_rsq(x);
+    double       g = x * y;
+    double       h = y * 0.5;
+    const double r = __builtin_fma(-h, g, 0.5);
+    g              = __builtin_fma(g, r, g);
+    h              = __builtin_fma(h, r, h);
+    double d       = __builtin_fma(-g, g, x);
+    g              = __builtin_fma(d, h, g);
+    d              = __builtin_fma(-g, g, x);
+    return __builtin_fma(d, h, g);
+}
+__device__ __forceinline__ double fast_div_f64(double n, double d) {
+    double r = __builtin_amdgcn_rcp(d);
+    double e = __builtin_fma(-d, r, 1.0);
+    r        = __builtin_fma(r, e, r);
+    e        = __builtin_fma(-d, r, 1.0);
+    r        = __builtin_fma(r, e, r);
+    const double q = n * r;
+    e              = __builtin_fma(-d, q, n);
+    return __builtin_fma(e, r, q);
+}
+
 struct Report {
     unsigned long long mismatches;
     unsigned long long tested;
@@ -128,6 +151,75 @@ __global__ void check_div_structured(Report* rep, int nexp, int dexp) {
     atomicAdd(&rep->tested, n);
 }
 
+__device__ void record64(Report* rep, unsigned long long a, unsigned long long b, double got, double want) {
+    const unsigned long long k = atomicAdd(&rep->mismatches, 1ull);
+    if (k < 8) {
+        rep->first_a[k] = static_cast<uint32_t>(a >> 32), rep->first_b[k] = static_cast<uint32_t>(b >> 32);
+        rep->got[k] = static_cast<uint32_t>(__double_as_longlong(got) & 0xffffffff), rep->want[k] = static_cast<uint32_t>(__double_as_longlong(want) & 0xffffffff);
+    }
+}
+__device__ __forceinline__ unsigned long long f64_bits(int exponent, unsigned long long mantissa, unsigned long long sign) {
+    return (sign << 63) | (static_cast<unsigned long long>(exponent + 1023) << 52) | (mantissa & 0xfffffffffffffull);
+}
+__device__ unsigned long long pattern64(unsigned i) {  // 128 structured mantissas
+    if (i < 52) return 1ull << i;
+    if (i < 104) return (0xfffffffffffffull << (i - 52)) & 0xfffffffffffffull;
+    if (i == 104) return 0;
+    if (i == 105) return 0xfffffffffffffull;
+    return (i - 105) * 2 + 1;
+}
+
+// fp64: sqrt over x in [2^-100, 2^203], divide over n in {0} U 2^+-nexp, d in 2^[dlo, dhi]
+__global__ void check_f64_random(Report* rep, int nexp, int dlo, int dhi, int slo, int shi, unsigned per_thread, uint64_t seed) {
+    uint64_t           s = seed + (static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) * 0x632be59bd9b4e019ull;
+    unsigned long long n = 0;
+    for (unsigned k = 0; k < per_thread; ++k) {
+        const uint64_t r1 = splitmix(s), r2 = splitmix(s), r3 = splitmix(s);
+        const int      ne = static_cast<int>(r3 % (2 * nexp + 1)) - nexp, de = dlo + static_cast<int>((r3 >> 20) % (dhi - dlo + 1)), se = slo + static_cast<int>((r3 >> 40) % (shi - slo + 1));
+        unsigned long long nb = f64_bits(ne, r1, r3 >> 63);
+        if (((r3 >> 52) & 0xff) == 0) nb = 0;  // +0 numerator now and then
+        const unsigned long long db = f64_bits(de, r2, 0), sb = f64_bits(se, r1 ^ r2, 0);
+        const double a = __longlong_as_double(nb), d = __longlong_as_double(db), x = __longlong_as_double(sb);
+        const double wq = a / d, gq = fast_div_f64(a, d);
+        if (__double_as_longlong(wq) != __double_as_longlong(gq)) record64(rep, nb, db, gq, wq);
+        const double ws = sqrt(x), gs = fast_sqrt_f64(x);
+        if (__double_as_longlong(ws) != __double_as_longlong(gs)) record64(rep, sb, 0, gs, ws);
+        n += 2;
+    }
+    atomicAdd(&rep->tested, n);
+}
+__global__ void check_f64_structured(Report* rep, int nexp, int dlo, int dhi) {
+    const unsigned pi = blockIdx.x, pj = threadIdx.x;  // 128 x 128 mantissa patterns
+    unsigned long long n = 0;
+    for (int ne = -nexp; ne <= nexp; ne += 7)
+        for (int de = dlo; de <= dhi; de += 13) {
+            const unsigned long long nb = f64_bits(ne, pattern64(pi), 0), db = f64_bits(de, pattern64(pj), 0);
+            const double a = __longlong_as_double(nb), d = __longlong_as_double(db);
+            const double wq = a / d, gq = fast_div_f64(a, d);
+            if (__double_as_longlong(wq) != __double_as_longlong(gq)) record64(rep, nb, db, gq, wq);
+            const double ws = sqrt(d), gs = fast_sqrt_f64(d);
+            if (__double_as_longlong(ws) != __double_as_longlong(gs)) record64(rep, db, 0, gs, ws);
+            n += 2;
+        }
+    atomicAdd(&rep->tested, n);
+}
+// does v_div_scale_f64 leave operands of the window alone (no scaling, VCC clear)?  every exponent pair x 128 mantissas
+__global__ void check_div_scale_identity(Report* rep, int nexp, int dlo, int dhi) {
+    const unsigned pat = threadIdx.x;
+    unsigned long long n = 0;
+    for (int ne = -nexp + static_cast<int>(blockIdx.x); ne <= nexp; ne += static_cast<int>(gridDim.x))
+        for (int de = dlo; de <= dhi; ++de) {
+            const double a = __longlong_as_double(f64_bits(ne, pattern64(pat), 0)), d = __longlong_as_double(f64_bits(de, pattern64(127 - pat), 0));
+            bool         f1 = false, f2 = false;
+            const double sd = __builtin_amdgcn_div_scale(a, d, false, &f1);  // scaled denominator
+            const double sn = __builtin_amdgcn_div_scale(a, d, true, &f2);   // scaled numerator
+            if (__double_as_longlong(sd) != __double_as_longlong(d) || __double_as_longlong(sn) != __double_as_longlong(a) || f1 || f2)
+                record64(rep, __double_as_longlong(a), __double_as_longlong(d), sd, sn);
+            ++n;
+        }
+    atomicAdd(&rep->tested, n);
+}
+
 static void show(const char* what, Report* dev) {
     Report r;
     CHECK(hipDeviceSynchronize());
@@ -160,5 +252,17 @@ int main() {
     }
     hipLaunchKernelGGL(check_div_random, dim3(4096), dim3(256), 0, 0, rep, 60, 120, 4096u, 99ull);
     show("div random |n| 2^+-60, d 2^+-120 (outside guard)", rep);
+
+    // ---- fp64 (window: |n| in {+0} U 2^+-100, d = r2^2 in 2^[-200, 406], sqrt argument in 2^[-100, 203]) ----
+    hipLaunchKernelGGL(check_div_scale_identity, dim3(201), dim3(128), 0, 0, rep, 100, -200, 406);
+    show("fp64 v_div_scale is the identity in the window", rep);
+    hipLaunchKernelGGL(check_f64_structured, dim3(128), dim3(128), 0, 0, rep, 100, -200, 406);
+    show("fp64 div+sqrt structured mantissas", rep);
+    for (int round = 0; round < 4; ++round) {
+        hipLaunchKernelGGL(check_f64_random, dim3(4096), dim3(256), 0, 0, rep, 100, -200, 406, -100, 203, 2048u, 0xabcdefull + round);
+        show("fp64 div+sqrt random, in window", rep);
+    }
+    hipLaunchKernelGGL(check_f64_random, dim3(4096), dim3(256), 0, 0, rep, 400, -900, 900, -1000, 1000, 1024u, 7ull);
+    show("fp64 div+sqrt random, far outside the window", rep);
     return 0;
 }
