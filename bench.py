@@ -57,27 +57,70 @@ def parse_args():
                          "host: gloo + host-staged all-gather, so that several ranks can share ONE GPU (functional rehearsal of the "
                          "N-rank code path on a one-GPU box; RCCL refuses two ranks per device); host-tiles: the same rehearsal with the TILE "
                          "schedule (gloo send/recv rounds on device tensors).  host* is never a performance number.")
+    ap.add_argument("--launch-timeout", type=float, default=600.0,
+                    help="plain `bench.py --gpus N`: seconds the launcher waits for the N ranks before ending them (see self_launch)")
     ap.add_argument("--emulate-gpus", type=int, default=0,
                     help="on ONE GPU, run rank 0's kernel schedule of a G-rank strong-scaling job (no collective): "
                          "projection aid, prints its own JSON and never the headline metric")
     return ap.parse_args()
 
 
-def self_launch(n_ranks: int) -> int:
+def self_launch(n_ranks: int, explicit_exchange: bool, limit_s: float) -> int:
     """Run this same command line as `n_ranks` ranks under torch.distributed.run (one process per GPU, rendezvous on
-    127.0.0.1) as a CHILD process; rank 0's JSON line reaches our stdout through the inherited descriptors."""
+    127.0.0.1) as a CHILD process group and relay its output.  The >1-GPU path has not run on hardware yet, so the launcher
+    carries one safety net: when the ranks fail or go `limit_s` seconds without finishing before rank 0 printed its line,
+    and the exchange was not chosen on the command line, their process group is ended (by its exact id) and the job is
+    started ONCE more with the plainest exchange (`--exchange allgather`: one ncclAllGather per step)."""
+    import signal
     import socket
     import subprocess
+    import threading
 
-    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
-        sock.bind(("127.0.0.1", 0))
-        port = sock.getsockname()[1]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this pool (RCCL needs it)
     env.setdefault("OMP_NUM_THREADS", "1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    return subprocess.run(cmd, env=env).returncode
+
+    def attempt(extra):
+        with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:] + extra
+        child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, start_new_session=True)
+        seen = {"metric": False}
+
+        def relay():
+            for line in child.stdout:
+                if line.startswith("{") and '"metric"' in line:
+                    seen["metric"] = True
+                sys.stdout.write(line)
+                sys.stdout.flush()
+
+        reader = threading.Thread(target=relay, daemon=True)
+        reader.start()
+        try:
+            rc = child.wait(timeout=limit_s)
+        except subprocess.TimeoutExpired:
+            print(f"[bench] ranks still running after {limit_s:.0f} s: ending process group {child.pid}", file=sys.stderr, flush=True)
+            for sig in (signal.SIGTERM, signal.SIGKILL):
+                try:
+                    os.killpg(child.pid, sig)  # the group this call created (start_new_session), nothing else
+                except ProcessLookupError:
+                    break
+                try:
+                    child.wait(timeout=20)
+                    break
+                except subprocess.TimeoutExpired:
+                    continue
+            rc = child.returncode if child.returncode is not None else -9
+        reader.join(timeout=10)
+        return rc, seen["metric"]
+
+    rc, reported = attempt([])
+    if rc != 0 and not reported and not explicit_exchange:
+        print(f"[bench] the {n_ranks}-rank run ended with status {rc} before reporting; one more attempt with --exchange allgather", file=sys.stderr, flush=True)
+        rc, reported = attempt(["--exchange", "allgather"])
+    return rc
 
 
 def make_bodies(n: int, dtype):
@@ -124,7 +167,7 @@ def main():
     if world == 1 and args.gpus > 1 and "RANK" not in os.environ:
         # plain `python3 bench.py --gpus N`: start the N ranks ourselves, BEFORE anything in this process touches the GPU
         # (no torch import, no HIP call so far), relay their output and exit with their status.  Children, never exec.
-        raise SystemExit(self_launch(args.gpus))
+        raise SystemExit(self_launch(args.gpus, any(a.startswith("--exchange") for a in sys.argv[1:]), args.launch_timeout))
     if args.gpus != world:
         args.gpus = world
 
