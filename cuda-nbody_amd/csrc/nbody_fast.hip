@@ -10,21 +10,26 @@
 //     in PAIRS, one pair per 64-bit VGPR pair: an interaction pair is 3 v_pk_add + 6 v_pk_fma + 2-3 v_pk_mul + 2 v_rsq_f32,
 //     the j body's x/y/z/m being broadcast into both halves with op_sel, not moved.
 //     fp64 has no packed form: one body per "vector"; m*d2^(-3/2) from the v_rsq_f64 seed by a 2-term series (Lane<double>::coupling).
-//   * Wave-stream layout (large shards): each lane register-tiles R vectors (I = R*W bodies i, W = 2 fp32 / 1 fp64), so
-//     one broadcast ds_read_b128 of a body j feeds I interactions.  The S waves of a workgroup own the SAME 64*I bodies i
-//     and split the bodies j: wave w streams chunks w, w+S, w+2S, ... of CH = 64*LPT consecutive bodies, each through its
-//     OWN double-buffered LDS ring (coalesced 16 B/lane global_load_dwordx4 -> registers -> ds_write_b128 -> broadcast
-//     ds_read_b128).  Because a wave reads only what it wrote itself there is NO workgroup barrier in the main loop: the
-//     waves of a SIMD drift apart freely and keep its VALU issuing (a per-tile s_barrier cost 3-4 % at 4 waves/SIMD,
-//     where one wave alone can only issue every 8th cycle).  The S partial sums are folded through LDS in a fixed
-//     order at the end (deterministic).
-//   * Mass factorisation: sums are accumulated in units of m_ref (the mass of the first body j of the range): the ring
-//     holds m_j/m_ref, and a chunk whose 64*LPT bodies ALL have mass m_ref -- every chunk of an equal-mass system such
-//     as the reference's start-up configurations -- takes a loop without the mass multiply (one v_pk_mul fewer of 12,
-//     and no mass moves: -8 % loop time).  With m_ref = 1 both forms are bit-identical to the plain one.
+//   * Wave-stream layout (large shards): each lane register-tiles R vectors (I = R*W bodies i, W = 2 fp32 / 1 fp64).  The
+//     S waves of a workgroup own the SAME 64*I bodies i and split the bodies j: wave w streams chunks w, w+S, w+2S, ...
+//     of CH = 64*LPT consecutive bodies.  Every lane of a wave meets the same body j, so a body j is wave-UNIFORM data:
+//     the wave reads its chunk with SCALAR loads (s_load_dwordx16 = 4 bodies, through the constant address space and the
+//     scalar cache, one group ahead of the one being computed) into scalar registers, and x/y/z/m enter the packed
+//     subtractions as scalar operands, broadcast into both halves by op_sel.  Rounds 1-2 staged the chunk in a per-wave
+//     LDS ring and read it back with broadcast ds_read_b128: same VALU count, but the loop also carried the LDS
+//     instructions and 4 more vector-register reads per body j -- measured in isolation 65.4 -> 61.8 cycles per
+//     interaction pair (profiles/round2_loop_microbench.txt), in the kernel +2.9 % fp32 / +2.7 % fp64 on the same box
+//     (profiles/round2_scalar_stream_ab.txt).  No workgroup barrier, no LDS traffic at all in the main loop; the waves
+//     of a SIMD drift apart freely and keep its VALU issuing.  The S partial sums are folded through LDS in a fixed
+//     order at the end (deterministic).  The LDS-tile form lives on in the wave-split layout below, where the bodies j
+//     differ from lane to lane.
+//   * Mass factorisation: sums are accumulated in units of m_ref (the mass of the first body j of the range), and a
+//     chunk whose bodies ALL have mass m_ref -- every chunk of an equal-mass system such as the reference's start-up
+//     configurations -- takes a loop without the mass multiply (11 packed ops + 2 v_rsq per interaction pair instead of
+//     12 + 2, plus one packed op per body j for m_j/m_ref).  With m_ref = 1 both forms are bit-identical to the plain one.
 //   * Wave-split layout (small shards, fewer bodies i than lanes on the chip): a wave owns the bodies i, its 64
 //     lanes split j, wavefront-64 butterfly fold at the end (integrate_bodies_wavesplit below).
-//   * softening^2 lives in VGPRs: a VALU op with an SGPR source issues ~35 % slower on this chip.
+//   * softening^2 stays in a vector register pair: as a scalar operand of the v_pk_fma it changes nothing (same microbenchmark).
 //   * The shard form (i-range x j-range, optional partial sums in/out) is the same kernel; the single-GPU
 //     step is the shard i = j = [0,N) with finalize.
 //
@@ -50,6 +55,8 @@ template <typename T> struct Lane;
 
 template <> struct Lane<float> {
     using vec4                 = float4;
+    typedef float raw4 __attribute__((ext_vector_type(4)));  // a body as the scalar unit loads it
+    using bits                 = unsigned;
     using vec                  = v2f;  // two bodies i per vector -> v_pk_*_f32
     static constexpr int W     = 2;
     static __device__ __forceinline__ vec  splat(float a) { return vec{a, a}; }
@@ -71,6 +78,13 @@ template <> struct Lane<float> {
         asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(s) : "v"(zm), "v"(inv3));
         return s;
     }
+    // the same with the body's relative mass already a vector (wave-stream kernel: body j arrives in scalar registers)
+    template <bool UNIT> static __device__ __forceinline__ vec coupling_rel(vec mrel, vec d2, const Consts&) {
+        const vec inv  = vec{__builtin_amdgcn_rsqf(d2.x), __builtin_amdgcn_rsqf(d2.y)};
+        const vec inv2 = inv * inv;
+        const vec inv3 = inv * inv2;
+        if constexpr (UNIT) return inv3; else return mrel * inv3;
+    }
     static __device__ __forceinline__ vec z_and_mass(const vec4& b) { return vec{b.z, b.w}; }
     static __device__ __forceinline__ float get(vec a, int w) { return w == 0 ? a.x : a.y; }
     static __device__ __forceinline__ void  set(vec& a, int w, float v) {
@@ -81,6 +95,8 @@ template <> struct Lane<float> {
 
 template <> struct Lane<double> {
     using vec4                 = double4;
+    typedef double raw4 __attribute__((ext_vector_type(4)));
+    using bits                 = unsigned long long;
     using vec                  = double;
     static constexpr int W     = 1;
     static __device__ __forceinline__ vec splat(double a) { return a; }
@@ -110,6 +126,7 @@ template <> struct Lane<double> {
         const double w  = r * __builtin_fma(r, c1875, c15);
         return __builtin_fma(mc, w, mc);
     }
+    template <bool UNIT> static __device__ __forceinline__ vec coupling_rel(vec mrel, vec d2, const Consts& k) { return coupling<UNIT>(mrel, d2, k); }
     static __device__ __forceinline__ double get(vec a, int) { return a; }
     static __device__ __forceinline__ void   set(vec& a, int, double v) { a = v; }
     static __device__ __forceinline__ void   keep_in_vgpr(vec& a) { asm volatile("" : "+v"(a)); }
@@ -148,24 +165,40 @@ __device__ __forceinline__ void interact(const typename Lane<T>::vec4 bj, const 
     if constexpr (!UNIT && sizeof(T) == 4) asm volatile("" : : "v"(bj.z), "v"(bj.w));
 }
 
+// The same for a body j held in SCALAR registers (every lane of the wave meets the same body): its coordinates enter the
+// subtractions as scalar operands, broadcast to both halves of a packed pair by op_sel.  `mrel`: relative mass, a vector.
+template <typename T, int R, bool UNIT>
+__device__ __forceinline__ void interact_uniform(const typename Lane<T>::raw4 bj, const typename Lane<T>::vec mrel, const typename Lane<T>::vec (&px)[R], const typename Lane<T>::vec (&py)[R], const typename Lane<T>::vec (&pz)[R],
+                                                 typename Lane<T>::vec (&ax)[R], typename Lane<T>::vec (&ay)[R], typename Lane<T>::vec (&az)[R], const typename Lane<T>::vec eps2, const typename Lane<T>::Consts& consts) {
+    using L   = Lane<T>;
+    using vec = typename L::vec;
+    const vec bx = L::splat(bj.x), by = L::splat(bj.y), bz = L::splat(bj.z);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const vec dx = bx - px[r];
+        const vec dy = by - py[r];
+        const vec dz = bz - pz[r];
+        vec       d2 = L::fma(dx, dx, eps2);
+        d2           = L::fma(dy, dy, d2);
+        d2           = L::fma(dz, dz, d2);
+        const vec s  = L::template coupling_rel<UNIT>(mrel, d2, consts);
+        ax[r]        = L::fma(dx, s, ax[r]);
+        ay[r]        = L::fma(dy, s, ay[r]);
+        az[r]        = L::fma(dz, s, az[r]);
+    }
+}
+
 // The mass every sum of a j range is expressed in units of: the first body's, when 1/m is a well-behaved number
 // (then an equal-mass range never multiplies by a mass inside the loop), otherwise 1.
-template <typename T> __device__ __forceinline__ T reference_mass(const Shard<T>& s) {
+template <typename T, typename Stream> __device__ __forceinline__ T reference_mass(const Shard<T>& s, Stream bodies) {
     if (s.j_count == 0) return T(1);
-    const T m = s.old_pos[4 * static_cast<size_t>(s.j_begin) + 3];
+    const T m = bodies[s.j_begin].w;  // (a scalar load: the value is compared with scalar registers)
     const T a = m < 0 ? -m : m;
     return (a >= T(0x1p-60) && a <= T(0x1p60)) ? m : T(1);  // false for NaN too
 }
 
-// A wave's LDS traffic is ordered (one queue per CU, in issue order), so data a wave writes for ITSELF needs no
-// s_barrier: wait for the writes to land and keep the compiler from moving LDS accesses across this point.
-__device__ __forceinline__ void wave_lds_sync() {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
-}
-
 // T: float|double   R: vectors per lane (I = R*W bodies i)   S: waves splitting j   LPT: vec4 loads per lane per chunk
-template <typename T, int R, int S, int LPT> __global__ __launch_bounds__(block_threads_for(S), 4) void integrate_bodies_fast(Shard<T> s) {
+template <typename T, int R, int S, int LPT> __global__ __launch_bounds__(block_threads_for(S)) __attribute__((amdgpu_waves_per_eu(4, 4))) void integrate_bodies_fast(Shard<T> s) {
     using LT            = Lane<T>;
     using vec4          = typename LT::vec4;
     using vec           = typename LT::vec;
@@ -176,16 +209,18 @@ template <typename T, int R, int S, int LPT> __global__ __launch_bounds__(block_
     // j bodies in flight per lane: 8 independent interaction chains (R vectors x U bodies j) hide the VALU latency.
     // Every geometry is capped at 128 VGPRs (4 waves/SIMD: 16 waves per CU in 1, 2 or 4 workgroups), so with R >= 2 the
     // loop unrolls less instead of spilling (an R = 4 body at U = 8 spilled 1.2 KB/lane to scratch: 1.2 GB of HBM writes per launch).
-    constexpr int U = R >= 2 ? 8 / R : 8;
+    constexpr int U = sizeof(T) == 8 && R == 1 ? 4 : (R >= 2 ? 8 / R : 8);  // (fp64 bodies take 8 scalar registers each)
     static_assert(CH % U == 0, "inner loop is unrolled by U");
 
     extern __shared__ __attribute__((aligned(32))) unsigned char smem_raw[];
 
+    using raw4 = typename LT::raw4;
+    typedef const raw4 __attribute__((address_space(4)))* stream_ptr;  // read-only for the whole launch -> s_load_dwordx4/x8/x16
     const vec4* __restrict__ old_pos = reinterpret_cast<const vec4*>(s.old_pos);
+    const stream_ptr         bodies  = reinterpret_cast<stream_ptr>(reinterpret_cast<unsigned long long>(s.old_pos));
     const int tid  = threadIdx.x;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
-    vec4* ring = reinterpret_cast<vec4*>(smem_raw) + wave * (2 * CH);  // this wave's [2][CH]
 
     // bodies i of this lane: block_base + k*64 + lane, k = r*W + w  (coalesced across the lanes of a wave)
     const unsigned block_base = blockIdx.x * BODIES_PER_BLOCK;
@@ -202,7 +237,7 @@ template <typename T, int R, int S, int LPT> __global__ __launch_bounds__(block_
         LT::set(py[k / W], k % W, p.y);
         LT::set(pz[k / W], k % W, p.z);
     }
-    const T m_ref    = reference_mass(s);
+    const T m_ref    = reference_mass(s, bodies);
     const T inv_mref = T(1) / m_ref;
 #pragma unroll
     for (int r = 0; r < R; ++r) ax[r] = ay[r] = az[r] = LT::splat(0);
@@ -217,47 +252,17 @@ template <typename T, int R, int S, int LPT> __global__ __launch_bounds__(block_
     }
     vec eps2 = LT::splat(s.eps2);
     LT::keep_in_vgpr(eps2);
+    vec inv_mref_v = LT::splat(inv_mref);
+    LT::keep_in_vgpr(inv_mref_v);
     const typename LT::Consts consts = LT::make_consts();
+    const typename LT::bits   unit_bits = __builtin_bit_cast(typename LT::bits, m_ref);
 
     const unsigned j_end    = s.j_begin + s.j_count;
     const unsigned n_chunks = (s.j_count + CH - 1) / CH;
 
-    // Out-of-range slots become zero-mass bodies at the origin: they add exactly 0 (eps2 > 0).
-    auto load_chunk = [&](unsigned c, vec4 (&regs)[LPT]) {
-#pragma unroll
-        for (int r = 0; r < LPT; ++r) {
-            const unsigned j = s.j_begin + c * CH + r * 64 + lane;
-            vec4           v;
-            v.x = v.y = v.z = v.w = 0;
-            if (j < j_end) v = old_pos[j];
-            regs[r] = v;
-        }
-    };
-    // Stores the chunk with masses relative to m_ref; returns whether EVERY body of it has the reference mass
-    // (wave-uniform; a chunk with out-of-range slots is a mixed one).
-    auto store_chunk = [&](int buf, const vec4 (&regs)[LPT]) -> bool {
-        bool same = true;
-#pragma unroll
-        for (int r = 0; r < LPT; ++r) {
-            vec4 v = regs[r];
-            same   = same && (v.w == m_ref);
-            v.w    = v.w * inv_mref;
-            ring[buf * CH + r * 64 + lane] = v;
-        }
-        return __builtin_amdgcn_ballot_w64(!same) == 0;
-    };
-
 #ifdef NB_STAMPS  // diagnostic build only (tools/stamp_probe.py): when does each wave start / finish streaming?
     const unsigned long long stamp_t0 = __builtin_amdgcn_s_memtime();
 #endif
-    vec4     regs[LPT];
-    unsigned c    = wave;  // wave w streams chunks w, w+S, w+2S, ...
-    bool     unit = false;
-    if (c < n_chunks) {
-        load_chunk(c, regs);
-        unit = store_chunk(0, regs);
-    }
-    wave_lds_sync();
 
     // The SIMD arbiter is strictly oldest-first: left alone, the four waves that share a SIMD finish equal shares of work
     // at 30 % / 53 % / 76 % / 100 % of the workgroup's time (profiles/round2_wave_finish_times.txt), and for the last
@@ -268,9 +273,8 @@ template <typename T, int R, int S, int LPT> __global__ __launch_bounds__(block_
     // finish within 0.5 % of each other; with four (S = 16) the two youngest still trail (a starved wave cannot re-evaluate
     // itself; graded levels made it worse), which is why S = 8 is the default.  The chunk -> wave assignment stays static, so the summation order (and every result bit) is the same
     // from run to run.  (Putting the leaders to sleep instead equalises too, but costs 15 %: a SIMD needs 3-4 runnable waves.)
-    constexpr size_t kRingBytes = static_cast<size_t>(S) * 2 * CH * sizeof(vec4);
     constexpr size_t kFoldBytes = static_cast<size_t>(S - 1) * 3 * I * 64 * sizeof(T);
-    unsigned* const   balance    = reinterpret_cast<unsigned*>(smem_raw + (kRingBytes > kFoldBytes ? kRingBytes : kFoldBytes));
+    unsigned* const   balance    = reinterpret_cast<unsigned*>(smem_raw + kFoldBytes);
     unsigned* const   simd_count = balance;                                     // [4] waves of this workgroup per SIMD
     volatile unsigned* progress  = reinterpret_cast<volatile unsigned*>(balance + 4);  // [4][8] chunks done, by SIMD and slot
     if (tid < 36) balance[tid] = tid < 4 ? 0u : 0xffffffffu;
@@ -304,10 +308,100 @@ template <typename T, int R, int S, int LPT> __global__ __launch_bounds__(block_
         for (int r = 0; r < R; ++r) ax[r] = ay[r] = az[r] = LT::splat(0);
     };
 
-    int cur = 0;
+    // Every lane of a wave meets the same body j, so the bodies j are not staged anywhere: the wave reads them U at a time with
+    // scalar loads (through the constant address space: `old_pos` is read-only for the whole launch) straight into scalar
+    // registers, one group ahead of the one it is computing, and they enter the packed subtractions as scalar operands.
+    // Against a per-wave LDS ring read back with ds_read_b128 (rounds 1-2) the loop loses its LDS instructions and 4
+    // vector-register reads per body j.
+    // Whether a chunk takes the loop without the mass multiply (every mass == m_ref) is found one chunk ahead: each lane
+    // looks at the masses of two bodies of the wave's next chunk with an ordinary vector load.
+    auto chunk_is_unit = [&](unsigned c) -> bool {  // (masses of chunk c, one or more per lane; wave-uniform answer)
+        bool same = true;
+#pragma unroll
+        for (int r = 0; r < LPT; ++r) {
+            const unsigned j = s.j_begin + c * CH + r * 64 + lane;
+            same             = same && j < j_end && (__builtin_bit_cast(typename LT::bits, s.old_pos[4 * static_cast<size_t>(j < j_end ? j : s.j_begin) + 3]) == unit_bits);
+        }
+        return __builtin_amdgcn_ballot_w64(!same) == 0;
+    };
+    auto group = [&](stream_ptr from, raw4 (&b)[U]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) b[u] = from[u];
+    };
+
+    // U bodies j against the R vectors of bodies i, written stage by stage (all differences, all squared distances, all
+    // reciprocal square roots, ...): U*R independent chains in flight whatever the instruction scheduler makes of it
+    auto compute = [&]<bool UNIT>(const raw4 (&b)[U]) {
+        constexpr int UB = (4 / R > 0 ? 4 / R : 1) < U ? (4 / R > 0 ? 4 / R : 1) : U;  // bodies j per stage block: >= 4 chains
+#pragma unroll
+        for (int h = 0; h < U; h += UB) {
+            vec dx[UB][R], dy[UB][R], dz[UB][R], w[UB][R];
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                const vec bx = LT::splat(b[h + u].x), by = LT::splat(b[h + u].y), bz = LT::splat(b[h + u].z);
+#pragma unroll
+                for (int r = 0; r < R; ++r) dx[u][r] = bx - px[r], dy[u][r] = by - py[r], dz[u][r] = bz - pz[r];
+            }
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) w[u][r] = LT::fma(dx[u][r], dx[u][r], eps2);
+            }
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) w[u][r] = LT::fma(dy[u][r], dy[u][r], w[u][r]);
+            }
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) w[u][r] = LT::fma(dz[u][r], dz[u][r], w[u][r]);
+            }
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                vec mrel = inv_mref_v;
+                if constexpr (!UNIT) mrel = LT::splat(b[h + u].w) * inv_mref_v;
+#pragma unroll
+                for (int r = 0; r < R; ++r) w[u][r] = LT::template coupling_rel<UNIT>(mrel, w[u][r], consts);
+            }
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    ax[r] = LT::fma(dx[u][r], w[u][r], ax[r]);
+                    ay[r] = LT::fma(dy[u][r], w[u][r], ay[r]);
+                    az[r] = LT::fma(dz[u][r], w[u][r], az[r]);
+                }
+            }
+        }
+    };
+    auto arrived = [](const raw4 (&b)[U]) { asm volatile("" : : "s"(b[0]) : "memory"); };  // first use of the set: what follows is issued after its wait
+    // b0 holds (or is loading) group 0 of the chunk; on return it is loading the first group at `next` (the wave's next chunk)
+    auto stream = [&]<bool UNIT>(stream_ptr chunk, unsigned groups, stream_ptr next, raw4 (&b0)[U], raw4 (&b1)[U]) {
+        unsigned g = 0;
+#pragma unroll 1
+        for (; g + 2 <= groups; g += 2) {
+            arrived(b0);
+            group(chunk + (g + 1) * U, b1);
+            __builtin_amdgcn_sched_barrier(0);  // (the load stays ahead of the compute it overlaps)
+            compute.template operator()<UNIT>(b0);
+            arrived(b1);
+            group(g + 2 < groups ? chunk + (g + 2) * U : next, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            compute.template operator()<UNIT>(b1);
+        }
+        if (g < groups) {  // (odd count: the ragged last chunk of the range, nothing follows it)
+            compute.template operator()<UNIT>(b0);
+        }
+    };
+
+    unsigned c    = wave;  // wave w streams chunks w, w+S, w+2S, ...
+    bool     unit = c < n_chunks && chunk_is_unit(c);
+    raw4     b0[U], b1[U];  // two register sets: while one group is computed the next one is in flight.  (Scalar loads return in
+                            // any order, so a wait is for everything outstanding: a set is loaded only once the other has been waited for.)
+    if (c < n_chunks && j_end - (s.j_begin + c * CH) >= static_cast<unsigned>(U)) group(bodies + (s.j_begin + c * CH), b0);
     for (; c < n_chunks; c += S) {
-        const bool have_next = (c + S) < n_chunks;
-        if (have_next) load_chunk(c + S, regs);  // global loads in flight across the compute below
+        const bool next_unit = (c + S) < n_chunks && chunk_is_unit(c + S);  // (its loads are in flight across the compute below)
 #ifndef NB_NO_BALANCE  // (diagnostic builds switch it off: tools/stamp_probe.py)
         // a wave that is not ahead of any wave of its SIMD (same workgroup) runs at priority 3, the others at 0
         {
@@ -321,30 +415,30 @@ template <typename T, int R, int S, int LPT> __global__ __launch_bounds__(block_
             }
         }
 #endif
-
-        const vec4* __restrict__ chunk = ring + cur * CH;
-        if (unit) {
-#pragma unroll 1
-            for (int jj = 0; jj < CH; jj += U) {
-#pragma unroll
-                for (int u = 0; u < U; ++u) interact<T, R, true>(chunk[jj + u], px, py, pz, ax, ay, az, eps2, consts);
-            }
-        } else {
-#pragma unroll 1
-            for (int jj = 0; jj < CH; jj += U) {
-#pragma unroll
-                for (int u = 0; u < U; ++u) interact<T, R, false>(chunk[jj + u], px, py, pz, ax, ay, az, eps2, consts);
+        const unsigned   first  = s.j_begin + c * CH;
+        const unsigned   count  = min(static_cast<unsigned>(CH), j_end - first);
+        const unsigned   groups = count / U;
+        const stream_ptr chunk  = bodies + first;
+        // the wave's next chunk, when it has a whole group (else anything readable: the set is not used again)
+        const stream_ptr next = ((c + S) < n_chunks && j_end - (first + S * CH) >= static_cast<unsigned>(U)) ? chunk + S * CH : chunk;
+        if (groups > 0) {
+            if (unit) {
+                stream.template operator()<true>(chunk, groups, next, b0, b1);
+            } else {
+                stream.template operator()<false>(chunk, groups, next, b0, b1);
             }
         }
-
-        if (have_next) unit = store_chunk(cur ^ 1, regs);
+#pragma unroll 1
+        for (unsigned jj = groups * U; jj < count; ++jj) {  // ragged end of the range
+            const raw4 b = chunk[jj];
+            interact_uniform<T, R, false>(b, LT::splat(b.w) * inv_mref_v, px, py, pz, ax, ay, az, eps2, consts);
+        }
+        unit = next_unit;
         ++done;
         if constexpr (kTwoLevel) {
             if (done % kFlush == 0) flush();
         }
         if (lane == 0) mine[slot] = done;
-        wave_lds_sync();
-        cur ^= 1;
     }
     if (lane == 0) mine[slot] = 0xffffffffu;  // finished: never the one the others defer to
     __builtin_amdgcn_s_setprio(0);
@@ -364,8 +458,7 @@ template <typename T, int R, int S, int LPT> __global__ __launch_bounds__(block_
 #endif
 
     // fold the S partial sums (waves 1..S-1 -> wave 0) through LDS, fixed order
-    T* red = reinterpret_cast<T*>(smem_raw);  // [(S-1)][3][I][64]; overlays the rings, hence the barrier: every wave is done streaming
-    __syncthreads();
+    T* red = reinterpret_cast<T*>(smem_raw);  // [(S-1)][3][I][64]
     if (wave > 0) {
 #pragma unroll
         for (int k = 0; k < I; ++k) {
@@ -388,8 +481,13 @@ template <typename T, int R, int S, int LPT> __global__ __launch_bounds__(block_
 
 #pragma unroll
     for (int k = 0; k < I; ++k) {
-        if (!active[k]) continue;
-        const unsigned i  = idx[k];
+        // (index and activity are worked out again from a lane number the compiler cannot tie to the one above: held across
+        // the streaming loop they cost I registers that the loop's stage blocks need)
+        unsigned lane_again = lane;
+        asm volatile("" : "+v"(lane_again));
+        const unsigned local = block_base + k * 64 + lane_again;
+        if (local >= s.i_count) continue;
+        const unsigned i  = s.i_begin + local;
         const T        fx = LT::get(ax[k / W], k % W) * m_ref, fy = LT::get(ay[k / W], k % W) * m_ref, fz = LT::get(az[k / W], k % W) * m_ref;
         if (s.finalize) {
             // integrateBodies, bodysystemcuda.cu:166-183
@@ -597,10 +695,11 @@ template <typename T, int R> hipError_t dispatch_s(const Shard<T>& s, const Plan
 //     has one workgroup per CU (65 536 bodies at I = 4) still runs near full rate.  S = 16 (one 1024-thread workgroup per
 //     CU) is 1-2 % slower: its four waves per SIMD cannot be kept level (see the kernel), S = 4 is 8 % slower.
 //   * I (bodies i per lane, a multiple of W: fp32 bodies travel in packed pairs; at most 4, what fits 128 VGPRs):
-//     register tiling amortises the LDS broadcast, but what matters more is how the resulting workgroup count divides
-//     over the 256 CUs.
-//   * 128 bodies j per wave and chunk (tile = S * 128 = 1024 bodies staged per workgroup and round, 2 x 16 KiB fp32 /
-//     2 x 32 KiB fp64 of LDS rings).
+//     register tiling amortises the per-body scalar work, but what matters more is how the resulting workgroup count
+//     divides over the 256 CUs.
+//   * 128 bodies j per wave and chunk (`tile_bodies` = S * 128 = the bodies j a workgroup takes per round): a chunk is the
+//     unit of the unit-mass decision, of the priority balancing and of the fp32 two-level sums; nothing is staged, so
+//     the only LDS is the fold buffer, the progress words and the second-level sums.
 template <typename T> Plan plan_fast(unsigned i_count, unsigned j_count, int cu_count, int ovr_i, int ovr_s, int ovr_tile) {
     constexpr int W     = Lane<T>::W;
     constexpr int kMaxI = 4;  // fp32: 2 packed pairs, fp64: 4 bodies -- the most a 1024-thread workgroup holds in 128 VGPRs without spilling
@@ -653,9 +752,8 @@ template <typename T> Plan plan_fast(unsigned i_count, unsigned j_count, int cu_
     p.block_threads   = block;
     const unsigned bodies_per_block = static_cast<unsigned>(block / S * I);
     p.grid_blocks     = (i_count + bodies_per_block - 1) / bodies_per_block;
-    const size_t tile_bytes = 2ull * tile * 4 * sizeof(T);
-    const size_t red_bytes  = static_cast<size_t>(S - 1) * 3 * I * (block / S) * sizeof(T);
-    p.lds_bytes             = static_cast<unsigned>(std::max(tile_bytes, red_bytes)) + 256u;  // + the waves' progress words
+    const size_t red_bytes  = static_cast<size_t>(S - 1) * 3 * I * (block / S) * sizeof(T);       // the fold of the S partial sums
+    p.lds_bytes             = static_cast<unsigned>(red_bytes) + 256u;                            // + the waves' progress words
     if (sizeof(T) == 4) p.lds_bytes += static_cast<unsigned>(S) * 3 * I * 64 * sizeof(T);       // + fp32: the lanes' second-level sums
     return p;
 }

@@ -1,21 +1,27 @@
 #!/usr/bin/env python3
-"""tools/loop_microbench_gen.py -- generates tools/loop_microbench.hip: the FAST kernel's compiled inner loop (taken verbatim
-from csrc/nbody_fast.s, with the registers hipcc allocated) run in isolation under s_memtime, plus edited variants, to
-see where the 7.6 % of non-VALU-active cycles of the real kernel come from (profiles/round1_n262144_f32_pmc_summary.json)
-and what an edited loop body would buy BEFORE touching the kernel.
+"""tools/loop_microbench_gen.py -- generates tools/loop_microbench.hip: an inner loop of the FAST kernel as hipcc compiled it
+(instruction for instruction, with the registers hipcc allocated) run in isolation under s_memtime, plus edited variants, to
+see what an edited loop body would buy BEFORE touching the kernel.
 
-    python3 tools/loop_microbench_gen.py cuda-nbody_amd/csrc/nbody_fast.s > tools/loop_microbench.hip
+    python3 tools/loop_microbench_gen.py [listing.s] > tools/loop_microbench.hip
     hipcc -O3 --offload-arch=gfx950 tools/loop_microbench.hip -o tools/loop_microbench
 
-Each kernel: 1024-thread workgroups (16 waves = 4 per SIMD, as the production geometry), one per CU; every wave runs
-OUTER x 32 iterations of the loop (32 = one 128-body slice of an LDS tile) reading a 64 KiB LDS buffer; true cycles
-from s_memtime (shader clock), so DVFS does not blur the result.  Reports cycles per packed interaction pair per SIMD.
+The default listing is tools/data/round2_lds_ring_kernel_f32_R2_S8.s: the round-2 kernel that staged the bodies j in a
+per-wave LDS ring (git history: the commit before "FAST: bodies j through scalar loads"), hipcc's own output for
+integrate_bodies_fast<float,2,8,2>.  The variants "body j as SGPR operands" of that loop are what motivated the present
+kernel (65.4 -> 61.8 cycles per interaction pair).
+
+Each kernel: 1024-thread workgroups (16 waves = 4 per SIMD), one per CU; every wave runs OUTER x 32 iterations of the
+loop reading a 64 KiB LDS buffer; true cycles from s_memtime (shader clock), so DVFS does not blur the result.  Reports
+cycles per packed interaction pair per SIMD.
 """
 import re
 import sys
 
-src = open(sys.argv[1]).read().split("\n")
-KERNEL = "_ZN2nb12_GLOBAL__N_121integrate_bodies_fastIfLi2ELi16ELi2EEEvNS_5ShardIT_EE"
+import os
+
+src = open(sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "round2_lds_ring_kernel_f32_R2_S8.s")).read().split("\n")
+KERNEL = "_ZN2nb12_GLOBAL__N_121integrate_bodies_fastIfLi2ELi8ELi2EEEvNS_5ShardIT_EE"  # the production geometry at 262 144 bodies
 start = next(i for i, l in enumerate(src) if l.startswith(KERNEL + ":"))
 # every depth-2 inner loop of the kernel (round 2: a generic-mass loop and a unit-mass loop), loop control stripped:
 # the harness supplies its own counter
@@ -73,6 +79,23 @@ if len(loops) > 1:
     variant("unit loop, static prio 3,2,1,0 by wave>>2", unit, prologue=by_slot(3, 2, 1, 0))
     variant("unit loop, all prio 3", unit, prologue=["s_setprio 3"])
 
+
+# ---- body j from SGPRs: every lane of a wave reads the same body j, so its coordinates could be scalar operands (s_load through the
+# scalar cache instead of an LDS ring); here only the operand form is timed -- no loads at all -- against "unit loop, VALU only"
+if len(loops) > 1:
+    unit = loops[1][1]
+    lo = int(re.search(r"ds_read_b128 v\[(\d+):", next(l for l in unit if l.startswith("ds_read_b128"))).group(1))
+    valu = [l for l in unit if not l.startswith("ds_read") and not l.startswith("s_waitcnt")]
+    sets = ["s_mov_b32 s60, 0x3f800000", "s_mov_b32 s61, 0x40000000", "s_mov_b32 s62, 0x40400000", "s_mov_b32 s63, 0x3f800000", "s_mov_b32 s64, 0x3c23d70a", "s_mov_b32 s65, 0x3c23d70a"]
+    def j_from_sgprs(l):
+        if not l.startswith("v_pk_add_f32"):
+            return l
+        return re.sub(rf"^(v_pk_add_f32 v\[\d+:\d+\], )v\[{lo}:{lo + 1}\]", r"\1s[60:61]", re.sub(rf"^(v_pk_add_f32 v\[\d+:\d+\], )v\[{lo + 2}:{lo + 3}\]", r"\1s[62:63]", l))
+    sg = [j_from_sgprs(l) for l in valu]
+    variant("unit loop, VALU only, body j as SGPR operands", sg, prologue=sets)
+    eps = next(re.search(r"(v\[\d+:\d+\])$", l).group(1) for l in valu if l.startswith("v_pk_fma_f32") and re.search(r"(v\[\d+:\d+\]), \1, v\[\d+:\d+\]$", l))
+    variant("unit loop, VALU only, body j and softening as SGPR operands", [l.replace(", " + eps, ", s[64:65]") if l.startswith("v_pk_fma_f32") and l.endswith(eps) and re.search(r"(v\[\d+:\d+\]), \1, ", l) else l for l in sg], prologue=sets)
+    variant("unit loop, VALU only (again, for drift)", valu)
 
 # ---- pipe-overlap probes: do packed fp32, plain fp32 and transcendental ops share one issue pipe? (32 instr per iteration) ----
 def acc(k):
@@ -142,7 +165,7 @@ for idx, (name, lines, _, prologue) in enumerate(variants):
     print('        "s_memtime %1\\n\\t"')
     print('        "s_memrealtime %3\\n\\t"')
     print('        "s_waitcnt lgkmcnt(0)\\n\\t"')
-    print(f'        : "=&s"(t0), "=&s"(t1), "=&s"(r0), "=&s"(r1) : "v"(tid) : {clob}, "s26", "s40", "scc", "vcc", "memory");')
+    print(f'        : "=&s"(t0), "=&s"(t1), "=&s"(r0), "=&s"(r1) : "v"(tid) : {clob}, "s26", "s40", "s41", "s60", "s61", "s62", "s63", "s64", "s65", "scc", "vcc", "memory");')
     print("    if ((threadIdx.x & 63) == 0) {")
     print("        unsigned long long* o = out + (blockIdx.x * 16 + (threadIdx.x >> 6)) * 4;")
     print("        o[0] = t0, o[1] = t1, o[2] = r0, o[3] = r1;")
