@@ -115,6 +115,16 @@ variant("probe: 8 v_rsq + 24 v_pk_fma interleaved", [RSQ(k) if k % 4 == 0 else P
 variant("probe: 8 v_rsq + 24 v_fma_f32 interleaved", [RSQ(k) if k % 4 == 0 else FMA(k) for k in range(32)], pairs_per_iter=32)
 variant("probe: 32 v_rsq_f32", [RSQ(k) for k in range(32)], pairs_per_iter=32)
 variant("probe: 32 v_mul_f32", [MUL(k) for k in range(32)], pairs_per_iter=32)
+# packed ops with ONE scalar source, by operand position (s[60:65] are set by the prologue)
+SETS = ["s_mov_b32 s60, 0x3f800000", "s_mov_b32 s61, 0x40000000", "s_mov_b32 s62, 0x40400000", "s_mov_b32 s63, 0x3f800000", "s_mov_b32 s64, 0x3c23d70a", "s_mov_b32 s65, 0x3c23d70a"]
+variant("probe: 32 v_pk_add_f32 v,v", [f"v_pk_add_f32 v[{acc(k)}:{acc(k)+1}], v[100:101], v[{acc(k)}:{acc(k)+1}]" for k in range(32)], pairs_per_iter=32)
+variant("probe: 32 v_pk_add_f32 s,v (src0 scalar)", [f"v_pk_add_f32 v[{acc(k)}:{acc(k)+1}], s[60:61], v[{acc(k)}:{acc(k)+1}]" for k in range(32)], pairs_per_iter=32, prologue=SETS)
+variant("probe: 32 v_pk_mul_f32 s,v (src0 scalar)", [f"v_pk_mul_f32 v[{acc(k)}:{acc(k)+1}], s[60:61], v[{acc(k)}:{acc(k)+1}]" for k in range(32)], pairs_per_iter=32, prologue=SETS)
+variant("probe: 32 v_pk_fma_f32 v,v,s (src2 scalar)", [f"v_pk_fma_f32 v[{acc(k)}:{acc(k)+1}], v[100:101], v[{acc(k)}:{acc(k)+1}], s[64:65]" for k in range(32)], pairs_per_iter=32, prologue=SETS)
+variant("probe: 32 v_pk_fma_f32 s,v,v (src0 scalar)", [f"v_pk_fma_f32 v[{acc(k)}:{acc(k)+1}], s[64:65], v[100:101], v[{acc(k)}:{acc(k)+1}]" for k in range(32)], pairs_per_iter=32, prologue=SETS)
+variant("probe: 32 v_pk_fma_f32 v,v,v three distinct pairs", [f"v_pk_fma_f32 v[{acc(k)}:{acc(k)+1}], v[100:101], v[102:103], v[{acc(k)}:{acc(k)+1}]" for k in range(32)], pairs_per_iter=32)
+variant("probe: 32 v_pk_fma_f32 v,v,0.5 (inline constant src2)", [f"v_pk_fma_f32 v[{acc(k)}:{acc(k)+1}], v[100:101], v[{acc(k)}:{acc(k)+1}], 0.5 op_sel_hi:[1,1,0]" for k in range(32)], pairs_per_iter=32)
+variant("probe: 16 s_mov_b32 + 32 v_pk_fma_f32 (scalar moves interleaved)", [x for k in range(32) for x in ([PK(k)] + ([f"s_mov_b32 s{66 + (k % 8)}, s60"] if k % 2 == 0 else []))], pairs_per_iter=32, prologue=SETS)
 
 
 # ---- s_setprio semantics: the two older waves of every SIMD (wave < 8) at level a, the two younger ones at level b -------
@@ -165,7 +175,7 @@ for idx, (name, lines, _, prologue) in enumerate(variants):
     print('        "s_memtime %1\\n\\t"')
     print('        "s_memrealtime %3\\n\\t"')
     print('        "s_waitcnt lgkmcnt(0)\\n\\t"')
-    print(f'        : "=&s"(t0), "=&s"(t1), "=&s"(r0), "=&s"(r1) : "v"(tid) : {clob}, "s26", "s40", "s41", "s60", "s61", "s62", "s63", "s64", "s65", "scc", "vcc", "memory");')
+    print(f'        : "=&s"(t0), "=&s"(t1), "=&s"(r0), "=&s"(r1) : "v"(tid) : {clob}, "s26", "s40", "s41", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "scc", "vcc", "memory");')
     print("    if ((threadIdx.x & 63) == 0) {")
     print("        unsigned long long* o = out + (blockIdx.x * 16 + (threadIdx.x >> 6)) * 4;")
     print("        o[0] = t0, o[1] = t1, o[2] = r0, o[3] = r1;")
