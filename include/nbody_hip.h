@@ -201,7 +201,7 @@ typedef struct nb_launch_plan {
     int bodies_per_lane;   /* I  : i-bodies register-tiled per lane                  */
     int lanes_per_body;    /* S  : wave groups of one workgroup that split the j range; 64 = wave-split layout
                               (small shards): the 64 lanes of a wave split j and bodies_per_lane counts per WAVE */
-    int tile_bodies;       /* LDS tile, bodies                                       */
+    int tile_bodies;       /* bodies j a workgroup takes per round (S chunks; an LDS tile in the wave-split layout) */
     int block_threads;
     unsigned grid_blocks;
     unsigned lds_bytes;
