@@ -9,6 +9,7 @@
 #include "rand_stream_guard.h"
 
 #include <atomic>
+#include <utility>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
@@ -73,6 +74,22 @@ int integrate_shard(T* new_pos, const T* old_pos, T* vel, T* acc, unsigned i_beg
     if ((acc_in || !finalize) && !acc) return NB_ERR_INVALID_ARGUMENT;
     if (!aligned_vec4<T>(old_pos) || !aligned_vec4<T>(new_pos) || !aligned_vec4<T>(vel) || !aligned_vec4<T>(acc)) return NB_ERR_INVALID_ARGUMENT;
     if (static_cast<unsigned long long>(i_begin) + i_count > 0xFFFFFFFFull || static_cast<unsigned long long>(j_begin) + j_count > 0xFFFFFFFFull) return NB_ERR_INVALID_ARGUMENT;
+    {
+        // old_pos is read-only for the whole launch (the kernels read it through the scalar cache and the constant address
+        // space): nothing the launch WRITES -- bodies [i_begin, i_begin+i_count) of new_pos, vel, acc -- may overlap what it
+        // READS of old_pos -- the bodies i and the bodies j.
+        const auto span = [](const T* base, unsigned first, unsigned count) {
+            const auto lo = reinterpret_cast<std::uintptr_t>(base) + static_cast<std::uintptr_t>(first) * 4 * sizeof(T);
+            return std::pair<std::uintptr_t, std::uintptr_t>(lo, lo + static_cast<std::uintptr_t>(count) * 4 * sizeof(T));
+        };
+        const auto overlaps = [](std::pair<std::uintptr_t, std::uintptr_t> a, std::pair<std::uintptr_t, std::uintptr_t> b) { return a.first < b.second && b.first < a.second; };
+        const auto read_i = span(old_pos, i_begin, i_count), read_j = span(old_pos, j_begin, j_count);
+        for (const T* written : {static_cast<const T*>(finalize ? new_pos : nullptr), static_cast<const T*>(finalize ? vel : nullptr), static_cast<const T*>(finalize ? nullptr : acc)}) {
+            if (written == nullptr) continue;
+            const auto w = span(written, i_begin, i_count);
+            if (overlaps(w, read_i) || overlaps(w, read_j)) return NB_ERR_INVALID_ARGUMENT;
+        }
+    }
 
     nb::Shard<T> s;
     s.new_pos = new_pos, s.old_pos = old_pos, s.vel = vel, s.acc = acc;

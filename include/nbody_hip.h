@@ -136,7 +136,10 @@ NB_API int nb_integrate_f64(double* new_positions, const double* old_positions, 
  *  of old_positions (all arrays are full-size and indexed by global body id).  acc is T[4*N] scratch
  *  holding partial accelerations between calls (flags: NB_SHARD_ACC_IN / NB_SHARD_FINALIZE).
  *  nb_integrate_* == one shard call with i = j = [0,N), flags = NB_SHARD_FINALIZE.
- *  In STRICT mode chunks must be issued in ascending j order to keep the CPU path's summation order. */
+ *  In STRICT mode chunks must be issued in ascending j order to keep the CPU path's summation order.
+ *  old_positions is read-only for the whole launch (the kernels read it through the scalar cache): the bodies a call
+ *  writes -- [i_begin, i_begin+i_count) of new_positions and velocities, or of acc -- must not overlap the bodies i and j
+ *  it reads of old_positions (NB_ERR_INVALID_ARGUMENT otherwise). */
 NB_API int nb_integrate_shard_f32(float* new_positions, const float* old_positions, float* velocities, float* acc,
                                   unsigned i_begin, unsigned i_count, unsigned j_begin, unsigned j_count,
                                   unsigned flags, float delta_time, float damping, int block_size, int mode,

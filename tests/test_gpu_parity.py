@@ -279,9 +279,18 @@ def test_errors_are_reported_not_swallowed(gpu):
     assert lib.nb_integrate_f32(other.ptr, buf.ptr, buf.ptr, 0.016, 1.0, 64, 100, gpu.NB_MODE_STRICT, None) == 10001
     # misaligned float4 pointer
     assert lib.nb_integrate_f32(ctypes.c_void_p(other.ptr.value + 4), buf.ptr, buf.ptr, 0.016, 1.0, 64, 256, gpu.NB_MODE_FAST, None) == 10001
+    # what a launch writes may not overlap what it reads of old_positions (read through the scalar cache): velocities on the
+    # positions, new positions shifted by one body inside the old array, a shard's acc on the bodies j it reads
+    third = gpu.DeviceBuffer(4096)
+    assert lib.nb_integrate_f32(other.ptr, buf.ptr, buf.ptr, 0.016, 1.0, 64, 256, gpu.NB_MODE_FAST, None) == 10001
+    assert lib.nb_integrate_f32(ctypes.c_void_p(buf.ptr.value + 16), buf.ptr, third.ptr, 0.016, 1.0, 64, 256, gpu.NB_MODE_FAST, None) == 10001
+    assert lib.nb_integrate_shard_f32(other.ptr, buf.ptr, third.ptr, buf.ptr, 0, 32, 32, 32, 0, 0.016, 1.0, 256, gpu.NB_MODE_FAST, None) == 10001
+    # ... while disjoint parts of ONE allocation are fine: bodies 0..31 read, partial sums written behind them
+    assert lib.nb_integrate_shard_f32(None, buf.ptr, None, ctypes.c_void_p(buf.ptr.value + 64 * 16), 0, 32, 0, 32, 0, 0.016, 1.0, 256, gpu.NB_MODE_FAST, None) == 0
+    assert lib.nb_device_synchronize() == 0
     with pytest.raises(gpu.NBodyHipError):
         gpu.check(10001, "x")
-    buf.free(), other.free()
+    buf.free(), other.free(), third.free()
 
 
 def test_device_is_gfx950(gpu):
