@@ -21,11 +21,15 @@
 //     on operands outside a window that is checked up front -- all coordinates |c| <= 2^18, softening^2 in
 //     [2^-39, 2^38], masses +0 or 2^-40 <= |m| <= 2^40 -- per wave (bodies i) and per 64-body chunk (bodies j), and any
 //     chunk outside it takes the generic form.  Inside the window r2 is in [2^-39, 2^40], r2^2 in [2^-78, 2^80], and
-//       sqrt : r = rsq(x); s = x*r; h = r/2; e = fma(-h,s,1/2); h = fma(h,e,h); s = fma(s,e,s); d = fma(-s,s,x); s = fma(d,h,s)
-//              == sqrtf(x) for EVERY float in [2^-100, 2^127)   (exhaustive: tools/strict_fastpath_check.hip)
+//       sqrt : r = rsq(x); s = x*r; h = r/2; d = fma(-s,s,x); s = fma(d,h,s)
+//              == sqrtf(x) for EVERY float in [2^-100, 2^127)   (exhaustive: tools/strict_unit_mass_check.hip; so is LLVM's
+//              longer form with the extra e = fma(-h,s,1/2); h = fma(h,e,h); s = fma(s,e,s) step, which rounds 1-3 used)
 //       div  : r = rcp(d); e = fma(-d,r,1); r = fma(e,r,r); q = n*r; e = fma(-d,q,n); q = fma(e,r,q); e = fma(-d,q,n); q = fma(e,r,q)
 //              is hipcc's own sequence with the identity scalings removed; == n/d on 1.7e10 random + structured pairs
-//     (profiles/round2_strict_fastpath_check.txt).  28 packed ops + 6 adds + 4 transcendentals per two interactions.
+//     (profiles/round2_strict_fastpath_check.txt).  25 packed ops + 6 adds + 4 transcendentals per two interactions.
+//       unit : a chunk whose masses are all exactly 1.0f (every start-up configuration of the reference) needs 1/d, not m/d:
+//              r = rcp(d); e = fma(-d,r,1); r = fma(e,r,r) == 1.0f/d for EVERY float d in [2^-100, 2^101) (exhaustive, same
+//              tool, profiles/round2_strict_unit_mass_check.txt): 20 packed ops + 6 adds + 4 transcendentals.
 //   * fast (fp64): one interaction at a time (no packed fp64), the same scaling-free divide and sqrt with its own window.
 #include "nbody_kernels.h"
 
@@ -71,7 +75,8 @@ __device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_el
 // 2*U interactions: the lane's body i against U pairs {j, j+1} of consecutive bodies, fast form; valid inside the operand
 // window only.  Written stage by stage over the U independent pairs so that their dependent chains interleave (the
 // divide and sqrt chains are ~20 dependent operations long); the running sums take the 2*U results in j order.
-template <int U>
+// UNIT: every mass of the pairs is exactly 1.0f (bm is not read).
+template <int U, bool UNIT>
 __device__ __forceinline__ void interact_jpairs_fast(const v2f (&bx)[U], const v2f (&by)[U], const v2f (&bz)[U], const v2f (&bm)[U], float pix, float piy, float piz, float& ax, float& ay, float& az, v2f eps2) {
     const v2f half = {0.5f, 0.5f}, one = {1.0f, 1.0f};
     v2f dx[U], dy[U], dz[U], x[U], r[U], mr3[U];
@@ -84,19 +89,12 @@ __device__ __forceinline__ void interact_jpairs_fast(const v2f (&bx)[U], const v
 #pragma unroll
     for (int u = 0; u < U; ++u) x[u] = ((eps2 + dx[u] * dx[u]) + dy[u] * dy[u]) + dz[u] * dz[u];  // r2
     {   // r = sqrt(r2), correctly rounded
-        v2f s[U], h[U], e[U], dd[U];
+        v2f s[U], h[U], dd[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const v2f rs = v2f{__builtin_amdgcn_rsqf(x[u].x), __builtin_amdgcn_rsqf(x[u].y)};
             s[u]         = x[u] * rs;
             h[u]         = rs * half;
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) e[u] = pk_fma(-h[u], s[u], half);
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            h[u] = pk_fma(h[u], e[u], h[u]);
-            s[u] = pk_fma(s[u], e[u], s[u]);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) dd[u] = pk_fma(-s[u], s[u], x[u]);
@@ -114,16 +112,21 @@ __device__ __forceinline__ void interact_jpairs_fast(const v2f (&bx)[U], const v
         for (int u = 0; u < U; ++u) e[u] = pk_fma(-d[u], rc[u], one);
 #pragma unroll
         for (int u = 0; u < U; ++u) rc[u] = pk_fma(e[u], rc[u], rc[u]);
+        if constexpr (UNIT) {  // 1/d: the Newton step above already gave the correctly rounded reciprocal
 #pragma unroll
-        for (int u = 0; u < U; ++u) q[u] = bm[u] * rc[u];
+            for (int u = 0; u < U; ++u) mr3[u] = rc[u] * r[u];
+        } else {
 #pragma unroll
-        for (int u = 0; u < U; ++u) e[u] = pk_fma(-d[u], q[u], bm[u]);
+            for (int u = 0; u < U; ++u) q[u] = bm[u] * rc[u];
 #pragma unroll
-        for (int u = 0; u < U; ++u) q[u] = pk_fma(e[u], rc[u], q[u]);
+            for (int u = 0; u < U; ++u) e[u] = pk_fma(-d[u], q[u], bm[u]);
 #pragma unroll
-        for (int u = 0; u < U; ++u) e[u] = pk_fma(-d[u], q[u], bm[u]);
+            for (int u = 0; u < U; ++u) q[u] = pk_fma(e[u], rc[u], q[u]);
 #pragma unroll
-        for (int u = 0; u < U; ++u) mr3[u] = pk_fma(e[u], rc[u], q[u]) * r[u];
+            for (int u = 0; u < U; ++u) e[u] = pk_fma(-d[u], q[u], bm[u]);
+#pragma unroll
+            for (int u = 0; u < U; ++u) mr3[u] = pk_fma(e[u], rc[u], q[u]) * r[u];
+        }
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -251,18 +254,21 @@ template <typename T> __global__ __launch_bounds__(512, 4) void integrate_bodies
         return v;
     };
     // ... and per chunk for the bodies j (slots past the end of the range hold zeros and are never visited)
-    auto store_chunk = [&](int buf, const vec4 v) -> bool {
+    // (returns 0: outside the window, 1: inside, 2: inside and every mass of the chunk is exactly 1)
+    auto store_chunk = [&](int buf, unsigned c, const vec4 v) -> int {
         T* dst = ring + buf * (4 * kChunk) + lane;
         dst[0 * kChunk] = v.x, dst[1 * kChunk] = v.y, dst[2 * kChunk] = v.z, dst[3 * kChunk] = v.w;
-        const bool ok = coord_in_window(v.x) && coord_in_window(v.y) && coord_in_window(v.z) && mass_in_window(v.w);
-        return __builtin_amdgcn_ballot_w64(!ok) == 0;
+        const bool ok   = coord_in_window(v.x) && coord_in_window(v.y) && coord_in_window(v.z) && mass_in_window(v.w);
+        const bool unit = v.w == T(1) || c * kChunk + lane >= s.j_count;
+        if (__builtin_amdgcn_ballot_w64(!ok) != 0) return 0;
+        return __builtin_amdgcn_ballot_w64(!unit) == 0 ? 2 : 1;
     };
 
-    bool chunk_in_window = false;
+    int  chunk_form = 0;
     vec4 next;
     if (n_chunks > 0) {
-        next            = load_chunk(0);
-        chunk_in_window = store_chunk(0, next);
+        next       = load_chunk(0);
+        chunk_form = store_chunk(0, 0, next);
     }
     wave_lds_sync();
 
@@ -288,29 +294,42 @@ template <typename T> __global__ __launch_bounds__(512, 4) void integrate_bodies
 
         unsigned k = 0;
         if constexpr (sizeof(T) == 4) {
-            if (wave_in_window && chunk_in_window) {
+            if (wave_in_window && chunk_form != 0) {
                 const v2f e2 = {eps2, eps2};
                 constexpr int U = 4;  // pairs in flight
+                if (chunk_form == 2) {  // unit masses: the reciprocal form, the masses are not even read
 #pragma unroll 1
-                for (; k + 2 * U <= cnt; k += 2 * U) {
-                    v2f bx[U], by[U], bz[U], bm[U];
+                    for (; k + 2 * U <= cnt; k += 2 * U) {
+                        v2f bx[U], by[U], bz[U], bm[U];
 #pragma unroll
-                    for (int u = 0; u < U; ++u) {
-                        bx[u] = *reinterpret_cast<const v2f*>(cx + k + 2 * u), by[u] = *reinterpret_cast<const v2f*>(cy + k + 2 * u);
-                        bz[u] = *reinterpret_cast<const v2f*>(cz + k + 2 * u), bm[u] = *reinterpret_cast<const v2f*>(cm + k + 2 * u);
+                        for (int u = 0; u < U; ++u) {
+                            bx[u] = *reinterpret_cast<const v2f*>(cx + k + 2 * u), by[u] = *reinterpret_cast<const v2f*>(cy + k + 2 * u);
+                            bz[u] = *reinterpret_cast<const v2f*>(cz + k + 2 * u), bm[u] = v2f{1.0f, 1.0f};
+                        }
+                        interact_jpairs_fast<U, true>(bx, by, bz, bm, pi.x, pi.y, pi.z, ax, ay, az, e2);
                     }
-                    interact_jpairs_fast<U>(bx, by, bz, bm, pi.x, pi.y, pi.z, ax, ay, az, e2);
+                } else {
+#pragma unroll 1
+                    for (; k + 2 * U <= cnt; k += 2 * U) {
+                        v2f bx[U], by[U], bz[U], bm[U];
+#pragma unroll
+                        for (int u = 0; u < U; ++u) {
+                            bx[u] = *reinterpret_cast<const v2f*>(cx + k + 2 * u), by[u] = *reinterpret_cast<const v2f*>(cy + k + 2 * u);
+                            bz[u] = *reinterpret_cast<const v2f*>(cz + k + 2 * u), bm[u] = *reinterpret_cast<const v2f*>(cm + k + 2 * u);
+                        }
+                        interact_jpairs_fast<U, false>(bx, by, bz, bm, pi.x, pi.y, pi.z, ax, ay, az, e2);
+                    }
                 }
 #pragma unroll 1
                 for (; k + 2 <= cnt; k += 2) {  // ragged chunk: pair by pair
                     const v2f bx[1] = {*reinterpret_cast<const v2f*>(cx + k)}, by[1] = {*reinterpret_cast<const v2f*>(cy + k)};
                     const v2f bz[1] = {*reinterpret_cast<const v2f*>(cz + k)}, bm[1] = {*reinterpret_cast<const v2f*>(cm + k)};
-                    interact_jpairs_fast<1>(bx, by, bz, bm, pi.x, pi.y, pi.z, ax, ay, az, e2);
+                    interact_jpairs_fast<1, false>(bx, by, bz, bm, pi.x, pi.y, pi.z, ax, ay, az, e2);
                 }
             }
         }
         if constexpr (sizeof(T) == 8) {
-            if (wave_in_window && chunk_in_window) {
+            if (wave_in_window && chunk_form != 0) {
 #pragma unroll 4
                 for (; k < cnt; ++k) {
                     vec4 bj;
@@ -327,7 +346,7 @@ template <typename T> __global__ __launch_bounds__(512, 4) void integrate_bodies
             interact_generic<T>(bj, pi.x, pi.y, pi.z, ax, ay, az, eps2);
         }
 
-        if (have_next) chunk_in_window = store_chunk(cur ^ 1, next);
+        if (have_next) chunk_form = store_chunk(cur ^ 1, c + 1, next);
         if (lane == 0) mine[slot] = c + 1;
         wave_lds_sync();
         cur ^= 1;

@@ -509,7 +509,7 @@ def test_strict_fast_form_window_edges_bitwise(gpu, oracle, dtype):
     window (fp32: |coordinate| <= 2^18, 2^-40 <= |mass| <= 2^40 or +0, softening^2 in [2^-39, 2^38]; fp64: 2^100, 2^+-100,
     [2^-100, 2^100]) and fall back to the generic IEEE expansions per 64-body chunk otherwise.  Systems that sit ON the
     window's edges, mix in-window and out-of-window chunks, produce denormal products (tiny separations) and carry -0 /
-    zero masses must all stay 0 ulp."""
+    zero masses must all stay 0 ulp; so must the fp32 unit-mass form (chunks of masses exactly 1.0: a 2-op reciprocal)."""
     rng = np.random.default_rng(7)
     n = 64 * 9 + 17  # ragged last chunk
     f32 = dtype == np.float32
@@ -549,6 +549,21 @@ def test_strict_fast_form_window_edges_bitwise(gpu, oracle, dtype):
     pos, vel = system(10.0, -2, 2)
     cases.append(("softening below window", pos, vel, 2.0 ** -21 if f32 else 2.0 ** -60))
     cases.append(("softening above window", pos, vel, 2.0 ** 19.5 if f32 else 2.0 ** 60))
+    # (e) the unit-mass form (fp32: chunks whose masses are all exactly 1 take 1/d instead of m/d): unit chunks next to
+    #     chunks with one odd mass (1 + ulp, 1 - ulp/2, 2, -1), coordinates on the edge, and tiny separations
+    pos, vel = system(2.0 ** min(cexp, 18), 0, 0)
+    pos[:, 3] = 1
+    pos[0, :3], pos[1, :3] = 2.0 ** min(cexp, 18), -(2.0 ** min(cexp, 18))
+    pos[64 * 1 + 63, 3] = dtype(1) + dtype(ulp)
+    pos[64 * 3 + 0, 3] = dtype(1) - dtype(ulp / 2)
+    pos[64 * 5 + 31, 3] = 2
+    pos[64 * 7 + 7, 3] = -1
+    cases.append(("unit-mass chunks among others", pos, vel, 0.1))
+    pos, vel = system(1.0, 0, 0)
+    pos[:, 3] = 1
+    pos[1::2, :3] = pos[0::2, :3][: pos[1::2].shape[0]] + dtype(2.0 ** -70)
+    cases.append(("unit masses, tiny separations", pos, vel, float(np.sqrt(np.float32(soft_lo))) if f32 else 2.0 ** -50))
+    cases.append(("unit masses, softening at the upper edge", pos, vel, float(np.sqrt(np.float32(soft_hi))) * 0.999 if f32 else 2.0 ** 49))
     for name, pos, vel, softening in cases:
         pos0, vel0 = pos.reshape(-1).copy(), vel.reshape(-1).copy()
         params = gpu.NBodyParams(softening=softening, damping=0.999)

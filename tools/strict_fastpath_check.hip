@@ -25,13 +25,10 @@
 // The two sequences under test -- keep in sync with csrc/nbody_strict.hip (fast_sqrt / fast_div).
 __device__ __forceinline__ float fast_sqrt(float x) {
     const float r = __builtin_amdgcn_rsqf(x);
-    float       s = x * r;
-    float       h = r * 0.5f;
-    const float e = __builtin_fmaf(-h, s, 0.5f);
-    h             = __builtin_fmaf(h, e, h);
-    s             = __builtin_fmaf(s, e, s);
+    const float s = x * r;
+    const float h = r * 0.5f;
     const float d = __builtin_fmaf(-s, s, x);
-    return __builtin_fmaf(d, h, s);
+    return __builtin_fmaf(d, h, s);  // (rounds 1-3 refined s and h once more first; both forms are exact: strict_unit_mass_check.hip)
 }
 __device__ __forceinline__ float fast_div(float n, float d) {
     float       r  = __builtin_amdgcn_rcpf(d);
