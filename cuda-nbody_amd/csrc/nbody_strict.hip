@@ -165,13 +165,14 @@ __device__ __forceinline__ double fast_div_f64(double n, double d) {
     e              = __builtin_fma(-d, q, n);
     return __builtin_fma(e, r, q);
 }
-__device__ __forceinline__ void interact_fast_f64(const double4 bj, double pix, double piy, double piz, double& ax, double& ay, double& az, double eps2) {
+// UNIT: the body's mass is exactly 1.0 -- the same sequence with n = 1, where q = n*r is r itself (bj.w is not read)
+template <bool UNIT> __device__ __forceinline__ void interact_fast_f64(const double4 bj, double pix, double piy, double piz, double& ax, double& ay, double& az, double eps2) {
     const double dx  = bj.x - pix;
     const double dy  = bj.y - piy;
     const double dz  = bj.z - piz;
     const double r2  = r2_T(dx * dx, dy * dy, dz * dz, eps2);
     const double r   = fast_sqrt_f64(r2);
-    const double mr4 = fast_div_f64(bj.w, r2 * r2);
+    const double mr4 = fast_div_f64(UNIT ? 1.0 : bj.w, r2 * r2);
     const double mr3 = mr4 * r;
     ax               = ax + mr3 * dx;
     ay               = ay + mr3 * dy;
@@ -329,12 +330,19 @@ template <typename T> __global__ __launch_bounds__(512, 4) void integrate_bodies
             }
         }
         if constexpr (sizeof(T) == 8) {
-            if (wave_in_window && chunk_form != 0) {
+            if (wave_in_window && chunk_form == 2) {
+#pragma unroll 4
+                for (; k < cnt; ++k) {
+                    vec4 bj;
+                    bj.x = cx[k], bj.y = cy[k], bj.z = cz[k], bj.w = 1;
+                    interact_fast_f64<true>(bj, pi.x, pi.y, pi.z, ax, ay, az, eps2);
+                }
+            } else if (wave_in_window && chunk_form != 0) {
 #pragma unroll 4
                 for (; k < cnt; ++k) {
                     vec4 bj;
                     bj.x = cx[k], bj.y = cy[k], bj.z = cz[k], bj.w = cm[k];
-                    interact_fast_f64(bj, pi.x, pi.y, pi.z, ax, ay, az, eps2);
+                    interact_fast_f64<false>(bj, pi.x, pi.y, pi.z, ax, ay, az, eps2);
                 }
             }
         }
