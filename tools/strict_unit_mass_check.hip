@@ -65,6 +65,36 @@ __device__ __forceinline__ float div7_one(float d) {
     return __builtin_fmaf(e3, r, q);
 }
 
+// 1 / RN(x*x) for the r2 window WITHOUT v_rcp_f32: the seed comes from the v_rsq_f32 the sqrt needs anyway (rs^4 ~ 1/x^2)
+template <int NEWTON> __device__ __forceinline__ float cand_rcp_of_square_from_rsq(float x) {
+    const float rs = __builtin_amdgcn_rsqf(x);
+    const float d  = x * x;
+    const float y  = rs * rs;
+    float       q  = y * y;
+#pragma unroll
+    for (int k = 0; k < NEWTON; ++k) {
+        const float e = __builtin_fmaf(-d, q, 1.0f);
+        q             = __builtin_fmaf(e, q, q);
+    }
+    return q;
+}
+// the unit-mass chain as the kernel runs it: r = sqrt(x) (4-op form), q = 1/RN(x*x) (rcp + 1 Newton), mr3 = q*r
+__device__ __forceinline__ float chain_kernel(float x) {
+    const float rs = __builtin_amdgcn_rsqf(x);
+    const float s = x * rs, h = rs * 0.5f;
+    const float r = __builtin_fmaf(__builtin_fmaf(-s, s, x), h, s);
+    const float d = x * x;
+    float       q = __builtin_amdgcn_rcpf(d);
+    q             = __builtin_fmaf(__builtin_fmaf(-d, q, 1.0f), q, q);
+    return q * r;
+}
+template <int NEWTON> __device__ __forceinline__ float chain_from_rsq(float x) {
+    const float rs = __builtin_amdgcn_rsqf(x);
+    const float s = x * rs, h = rs * 0.5f;
+    const float r = __builtin_fmaf(__builtin_fmaf(-s, s, x), h, s);
+    return cand_rcp_of_square_from_rsq<NEWTON>(x) * r;
+}
+
 struct Report {
     unsigned long long mismatches, tested;
     uint32_t           first[8], got[8], want[8];
@@ -112,6 +142,14 @@ int main() {
     run("1/d: rcp + 1 Newton step (2 ops)", -100, 101, [] __device__(float d) { return cand_rcp<2>(d); }, ref_rcp);
     run("1/d: rcp + 2 Newton steps (4 ops)", -100, 101, [] __device__(float d) { return cand_rcp<4>(d); }, ref_rcp);
     run("1/d: rcp + 3 Newton steps (6 ops)", -100, 101, [] __device__(float d) { return cand_rcp<6>(d); }, ref_rcp);
+    // the whole unit-mass chain as a function of r2 alone, over the kernel's r2 window [2^-39, 2^40] (and a margin)
+    auto ref_chain = [] __device__(float x) { return (1.0f / (x * x)) * sqrtf(x); };
+    auto ref_rsq   = [] __device__(float x) { return 1.0f / (x * x); };
+    run("chain mr3(r2) = (1/(r2*r2))*sqrt(r2): kernel form", -45, 46, [] __device__(float x) { return chain_kernel(x); }, ref_chain);
+    run("1/(r2*r2): seed rs^4 from the sqrt's v_rsq, 1 Newton step (no v_rcp)", -45, 46, [] __device__(float x) { return cand_rcp_of_square_from_rsq<1>(x); }, ref_rsq);
+    run("1/(r2*r2): seed rs^4 from the sqrt's v_rsq, 2 Newton steps (no v_rcp)", -45, 46, [] __device__(float x) { return cand_rcp_of_square_from_rsq<2>(x); }, ref_rsq);
+    run("chain with the rs^4 seed, 1 Newton step", -45, 46, [] __device__(float x) { return chain_from_rsq<1>(x); }, ref_chain);
+    run("chain with the rs^4 seed, 2 Newton steps", -45, 46, [] __device__(float x) { return chain_from_rsq<2>(x); }, ref_chain);
     // negative denominators cannot occur (d = r2*r2 > 0)
     return 0;
 }
