@@ -51,9 +51,11 @@ def parse_args():
     ap.add_argument("--cpu-sample-bodies", type=int, default=0, help="bodies i in the CPU sample (0 = auto, ~10 s)")
     ap.add_argument("--sweep", action="store_true", help="time every fast-kernel geometry (tuning aid), N=1 only")
     ap.add_argument("--plan", type=str, default="", help="I,S,TILE override for the fast kernel, e.g. 2,1,1024")
-    ap.add_argument("--exchange", choices=["rccl", "allgather", "host", "host-tiles"], default="rccl",
+    ap.add_argument("--exchange", choices=["rccl", "allgather", "staged", "host", "host-tiles"], default="rccl",
                     help="rccl: the position all-gather issued as its G-1 tiles (one grouped RCCL send/recv pair per round, the kernel "
                          "of tile k waiting only on round k); allgather: one all_gather_into_tensor per step; "
+                         "staged: no RCCL at all -- gloo, the slices gathered through host memory, each rank on its OWN GPU (the launcher's "
+                         "last resort: a real N-GPU number of the kernels with a slow exchange); "
                          "host: gloo + host-staged all-gather, so that several ranks can share ONE GPU (functional rehearsal of the "
                          "N-rank code path on a one-GPU box; RCCL refuses two ranks per device); host-tiles: the same rehearsal with the TILE "
                          "schedule (gloo send/recv rounds on device tensors).  host* is never a performance number.")
@@ -70,7 +72,8 @@ def self_launch(n_ranks: int, explicit_exchange: bool, limit_s: float) -> int:
     127.0.0.1) as a CHILD process group and relay its output.  The >1-GPU path has not run on hardware yet, so the launcher
     carries one safety net: when the ranks fail or go `limit_s` seconds without finishing before rank 0 printed its line,
     and the exchange was not chosen on the command line, their process group is ended (by its exact id) and the job is
-    started ONCE more with the plainest exchange (`--exchange allgather`: one ncclAllGather per step)."""
+    started again with a plainer exchange: `--exchange allgather` (one ncclAllGather per step), then `--exchange staged`
+    (gloo through host memory, no RCCL) -- at most those two further attempts."""
     import signal
     import socket
     import subprocess
@@ -117,9 +120,11 @@ def self_launch(n_ranks: int, explicit_exchange: bool, limit_s: float) -> int:
         return rc, seen["metric"]
 
     rc, reported = attempt([])
-    if rc != 0 and not reported and not explicit_exchange:
-        print(f"[bench] the {n_ranks}-rank run ended with status {rc} before reporting; one more attempt with --exchange allgather", file=sys.stderr, flush=True)
-        rc, reported = attempt(["--exchange", "allgather"])
+    for fallback in ("allgather", "staged"):  # plainer and plainer: one ncclAllGather per step, then no RCCL at all
+        if rc == 0 or reported or explicit_exchange:
+            break
+        print(f"[bench] the {n_ranks}-rank run ended with status {rc} before reporting; one more attempt with --exchange {fallback}", file=sys.stderr, flush=True)
+        rc, reported = attempt(["--exchange", fallback])
     return rc
 
 
@@ -188,6 +193,7 @@ def main():
 
     if args.exchange.startswith("host"):
         local_rank = 0  # every rank on the one GPU
+    over_gloo = args.exchange.startswith("host") or args.exchange == "staged"
     torch.cuda.set_device(local_rank)
     pkg.check(lib.nb_set_device(local_rank), "nb_set_device")
     dev = torch.device("cuda", local_rank)
@@ -200,7 +206,7 @@ def main():
         # RCCL's all-gather kernel competes with the force kernel for CUs (a 1024-thread workgroup fills a CU's VGPRs):
         # a high-priority stream lets its few workgroups dispatch first, so the exchange overlaps the own-slice chunk
         # instead of queueing behind it.
-        if args.exchange.startswith("host"):
+        if over_gloo:
             dist.init_process_group("gloo")
         else:
             try:
@@ -236,7 +242,7 @@ def main():
     if distributed:
         sharded = entry.load_package_module("sharded")
         host_gather = None
-        if args.exchange == "host":
+        if args.exchange in ("host", "staged"):
             class _Done:
                 def wait(self):
                     pass
@@ -405,7 +411,7 @@ def main():
     launches = kernel_launches[0] - launches_before
 
     if distributed:
-        t = torch.tensor([elapsed], device="cpu" if args.exchange.startswith("host") else dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device="cpu" if over_gloo else dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -457,6 +463,7 @@ def main():
                 "bodies_per_gpu": n // world,
                 "exchange": "none" if world == 1 else (
                     "REHEARSAL: gloo, host-staged gather, ranks share one GPU" if args.exchange == "host" else
+                    "FALLBACK (no RCCL): gloo all-gather of the slices through host memory, one GPU per rank" if args.exchange == "staged" else
                     "REHEARSAL: gloo send/recv rounds (tile schedule) on device tensors, ranks share one GPU" if args.exchange == "host-tiles" else
                     "RCCL all-gather of the new positions per step, issued as G-1 position tiles (grouped send/recv rounds on RCCL's stream); "
                     "the kernel of tile k waits only on round k, the own-slice chunk runs first" if system.exchange == "tiles" else

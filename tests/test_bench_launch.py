@@ -17,8 +17,9 @@ def run_bench(*flags, timeout=600):
     return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *flags], capture_output=True, text=True, env=env, timeout=timeout)
 
 
-def test_launcher_retries_once_with_the_plain_all_gather_and_reports_failure():
-    """No GPU here: both attempts must fail, the second one must be the all-gather form, and the status must say so."""
+def test_launcher_falls_back_twice_and_reports_failure():
+    """No GPU here: every attempt must fail; the second one must be the all-gather form, the third the RCCL-free one, and the
+    status must say so."""
     import torch
 
     if torch.cuda.is_available():
@@ -26,6 +27,7 @@ def test_launcher_retries_once_with_the_plain_all_gather_and_reports_failure():
     out = run_bench("--gpus", "2", "--steps", "1", "--warmup", "0", "--bodies", "1024", "--no-cpu-baseline", "--launch-timeout", "240")
     assert out.returncode != 0
     assert out.stderr.count("one more attempt with --exchange allgather") == 1, out.stderr[-2000:]
+    assert out.stderr.count("one more attempt with --exchange staged") == 1, out.stderr[-2000:]
     assert '"metric"' not in out.stdout
 
 
