@@ -315,14 +315,24 @@ template <typename T, int R, int S, int LPT> __global__ __launch_bounds__(block_
     // vector-register reads per body j.
     // Whether a chunk takes the loop without the mass multiply (every mass == m_ref) is found one chunk ahead: each lane
     // looks at the masses of two bodies of the wave's next chunk with an ordinary vector load.
-    auto chunk_is_unit = [&](unsigned c) -> bool {  // (masses of chunk c, one or more per lane; wave-uniform answer)
+    // The masses of chunk c, one or more per lane; wave-uniform answer.  kUnit: every mass is m_ref.  kUniform: the bodies of
+    // the chunk all have the SAME mass (a species of a galaxy file) -- the chunk then runs the loop without the mass
+    // multiply into sums of its own, which join the running sums scaled by that mass.  kMixed: the mass-multiplying loop.
+    // (A ragged chunk -- the last of the range -- is only judged by the bodies it has; its odd bodies go one by one anyway.)
+    enum : int { kMixed = 0, kUnit = 1, kUniform = 2 };
+    auto chunk_form = [&](unsigned c, T& common_mass) -> int {
+        const unsigned first_j = s.j_begin + c * CH;
+        using bits = typename LT::bits;
+        const bits first_bits = __builtin_bit_cast(bits, s.old_pos[4 * static_cast<size_t>(first_j) + 3]);  // (uniform address)
         bool same = true;
 #pragma unroll
         for (int r = 0; r < LPT; ++r) {
-            const unsigned j = s.j_begin + c * CH + r * 64 + lane;
-            same             = same && j < j_end && (__builtin_bit_cast(typename LT::bits, s.old_pos[4 * static_cast<size_t>(j < j_end ? j : s.j_begin) + 3]) == unit_bits);
+            const unsigned j = first_j + r * 64 + lane;
+            same             = same && (j >= j_end || __builtin_bit_cast(bits, s.old_pos[4 * static_cast<size_t>(j < j_end ? j : first_j) + 3]) == first_bits);
         }
-        return __builtin_amdgcn_ballot_w64(!same) == 0;
+        common_mass = __builtin_bit_cast(T, first_bits);
+        if (__builtin_amdgcn_ballot_w64(!same) != 0 || !(common_mass == common_mass)) return kMixed;  // (NaN masses take the plain loop)
+        return first_bits == unit_bits ? kUnit : kUniform;
     };
     auto group = [&](stream_ptr from, raw4 (&b)[U]) {
 #pragma unroll
@@ -331,7 +341,7 @@ template <typename T, int R, int S, int LPT> __global__ __launch_bounds__(block_
 
     // U bodies j against the R vectors of bodies i, written stage by stage (all differences, all squared distances, all
     // reciprocal square roots, ...): U*R independent chains in flight whatever the instruction scheduler makes of it
-    auto compute = [&]<bool UNIT>(const raw4 (&b)[U]) {
+    auto compute = [&]<bool UNIT>(const raw4 (&b)[U], vec (&ax)[R], vec (&ay)[R], vec (&az)[R]) {
         constexpr int UB = (4 / R > 0 ? 4 / R : 1) < U ? (4 / R > 0 ? 4 / R : 1) : U;  // bodies j per stage block: >= 4 chains
 #pragma unroll
         for (int h = 0; h < U; h += UB) {
@@ -377,31 +387,32 @@ template <typename T, int R, int S, int LPT> __global__ __launch_bounds__(block_
     };
     auto arrived = [](const raw4 (&b)[U]) { asm volatile("" : : "s"(b[0]) : "memory"); };  // first use of the set: what follows is issued after its wait
     // b0 holds (or is loading) group 0 of the chunk; on return it is loading the first group at `next` (the wave's next chunk)
-    auto stream = [&]<bool UNIT>(stream_ptr chunk, unsigned groups, stream_ptr next, raw4 (&b0)[U], raw4 (&b1)[U]) {
+    auto stream = [&]<bool UNIT>(stream_ptr chunk, unsigned groups, stream_ptr next, raw4 (&b0)[U], raw4 (&b1)[U], vec (&sx)[R], vec (&sy)[R], vec (&sz)[R]) {
         unsigned g = 0;
 #pragma unroll 1
         for (; g + 2 <= groups; g += 2) {
             arrived(b0);
             group(chunk + (g + 1) * U, b1);
             __builtin_amdgcn_sched_barrier(0);  // (the load stays ahead of the compute it overlaps)
-            compute.template operator()<UNIT>(b0);
+            compute.template operator()<UNIT>(b0, sx, sy, sz);
             arrived(b1);
             group(g + 2 < groups ? chunk + (g + 2) * U : next, b0);
             __builtin_amdgcn_sched_barrier(0);
-            compute.template operator()<UNIT>(b1);
+            compute.template operator()<UNIT>(b1, sx, sy, sz);
         }
         if (g < groups) {  // (odd count: the ragged last chunk of the range, nothing follows it)
-            compute.template operator()<UNIT>(b0);
+            compute.template operator()<UNIT>(b0, sx, sy, sz);
         }
     };
 
     unsigned c    = wave;  // wave w streams chunks w, w+S, w+2S, ...
-    bool     unit = c < n_chunks && chunk_is_unit(c);
+    T        common_mass = 0, next_mass = 0;
+    int      form = c < n_chunks ? chunk_form(c, common_mass) : kMixed;
     raw4     b0[U], b1[U];  // two register sets: while one group is computed the next one is in flight.  (Scalar loads return in
                             // any order, so a wait is for everything outstanding: a set is loaded only once the other has been waited for.)
     if (c < n_chunks && j_end - (s.j_begin + c * CH) >= static_cast<unsigned>(U)) group(bodies + (s.j_begin + c * CH), b0);
     for (; c < n_chunks; c += S) {
-        const bool next_unit = (c + S) < n_chunks && chunk_is_unit(c + S);  // (its loads are in flight across the compute below)
+        const int next_form = (c + S) < n_chunks ? chunk_form(c + S, next_mass) : kMixed;  // (its loads are in flight across the compute below)
 #ifndef NB_NO_BALANCE  // (diagnostic builds switch it off: tools/stamp_probe.py)
         // a wave that is not ahead of any wave of its SIMD (same workgroup) runs at priority 3, the others at 0
         {
@@ -422,10 +433,18 @@ template <typename T, int R, int S, int LPT> __global__ __launch_bounds__(block_
         // the wave's next chunk, when it has a whole group (else anything readable: the set is not used again)
         const stream_ptr next = ((c + S) < n_chunks && j_end - (first + S * CH) >= static_cast<unsigned>(U)) ? chunk + S * CH : chunk;
         if (groups > 0) {
-            if (unit) {
-                stream.template operator()<true>(chunk, groups, next, b0, b1);
+            if (form == kUnit) {
+                stream.template operator()<true>(chunk, groups, next, b0, b1, ax, ay, az);
+            } else if (form == kUniform) {
+                vec cx[R], cy[R], cz[R];
+#pragma unroll
+                for (int r = 0; r < R; ++r) cx[r] = cy[r] = cz[r] = LT::splat(0);
+                stream.template operator()<true>(chunk, groups, next, b0, b1, cx, cy, cz);
+                const vec scale = LT::splat(common_mass) * inv_mref_v;
+#pragma unroll
+                for (int r = 0; r < R; ++r) ax[r] = LT::fma(cx[r], scale, ax[r]), ay[r] = LT::fma(cy[r], scale, ay[r]), az[r] = LT::fma(cz[r], scale, az[r]);
             } else {
-                stream.template operator()<false>(chunk, groups, next, b0, b1);
+                stream.template operator()<false>(chunk, groups, next, b0, b1, ax, ay, az);
             }
         }
 #pragma unroll 1
@@ -433,7 +452,7 @@ template <typename T, int R, int S, int LPT> __global__ __launch_bounds__(block_
             const raw4 b = chunk[jj];
             interact_uniform<T, R, false>(b, LT::splat(b.w) * inv_mref_v, px, py, pz, ax, ay, az, eps2, consts);
         }
-        unit = next_unit;
+        form = next_form, common_mass = next_mass;
         ++done;
         if constexpr (kTwoLevel) {
             if (done % kFlush == 0) flush();

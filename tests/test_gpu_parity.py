@@ -162,6 +162,61 @@ def test_fast_force_error_every_geometry(gpu, oracle, plan):
     assert np.all(acc.reshape(n, 4)[:, 3] == 0)
 
 
+def direct_sum_f64(pos, i0, ni, j0, nj, softening_sq):
+    """accelerations of bodies [i0, i0+ni) from bodies [j0, j0+nj), numpy float64 (yardstick for FAST; small n only)"""
+    p = pos.astype(np.longdouble)  # (x86 80-bit: the yardstick's own rounding stays below fp64 FAST's)
+    eps2 = np.longdouble(softening_sq)
+    out, size = np.zeros((ni, 3), np.longdouble), np.zeros(ni, np.longdouble)
+    for a in range(0, ni, 256):
+        pi = p[i0 + a:i0 + min(a + 256, ni), None, :3]
+        d = p[None, j0:j0 + nj, :3] - pi
+        r2 = (d * d).sum(axis=2) + eps2
+        terms = d * (p[None, j0:j0 + nj, 3] / (r2 * np.sqrt(r2)))[:, :, None]
+        out[a:a + pi.shape[0]] = terms.sum(axis=1)
+        size[a:a + pi.shape[0]] = np.linalg.norm(terms, axis=2).sum(axis=1)  # what a sum's rounding error scales with
+    return out.astype(np.float64), size.astype(np.float64)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("plan", [(2, 8, 512), (4, 8, 1024), (4, 16, 2048)])
+def test_fast_chunk_forms_by_mass(gpu, oracle, dtype, plan):
+    """The wave-stream kernel picks a loop per chunk of bodies j by its masses: all equal to the first body's (no mass
+    multiply), all equal to each other (a species: no multiply, the chunk's own sums scaled once), mixed.  A system of species
+    whose boundaries do not fall on chunk boundaries, with zero-mass, negative, huge and NaN-free odd bodies sprinkled in,
+    against an fp64 direct sum -- and a system whose first body is the odd one."""
+    n = 128 * 37 + 41
+    rng = np.random.default_rng(11)
+    tol = 5e-6 if dtype == np.float32 else 2e-14
+    eps2 = dtype(np.float32(0.1) * np.float32(0.1))
+    gpu.set_softening_squared(eps2)
+    for variant in range(3):
+        pos = np.zeros((n, 4), dtype)
+        pos[:, :3] = rng.standard_normal((n, 3)).astype(dtype)
+        species = np.array([1.0, 0.25, 3.0, 1.0, 1e-3, 7.5])
+        edges = np.sort(rng.choice(np.arange(1, n), size=len(species) - 1, replace=False))
+        pos[:, 3] = np.repeat(species, np.diff(np.concatenate(([0], edges, [n])))).astype(dtype)
+        if variant >= 1:  # odd bodies inside otherwise uniform chunks
+            odd = rng.choice(n, size=23, replace=False)
+            pos[odd, 3] = rng.choice(np.array([0.0, -2.0, 1e6, 1.0, 0.5]), size=23).astype(dtype)
+        if variant == 2:  # the reference mass (first body of the range) is itself an odd one
+            pos[0, 3] = 0.125
+        flat = pos.reshape(-1).copy()
+        gpu.set_plan_override(*plan)
+        try:
+            acc = gpu_accel(gpu, flat, dtype, 0, n, 0, n, gpu.NB_MODE_FAST)
+            part = gpu_accel(gpu, flat, dtype, 100, 2000, 300, n - 517, gpu.NB_MODE_FAST)  # a j range starting mid-chunk, mid-species
+        finally:
+            gpu.set_plan_override(0, 0, 0)
+        # (masses of both signs and of very different size cancel: the error is measured against the sum of the terms' sizes)
+        ref, size = direct_sum_f64(pos, 0, n, 0, n, eps2)
+        err = np.linalg.norm(xyz(acc) - ref, axis=1) / size
+        assert err.max() < tol, (variant, err.max())
+        ref_part, size_part = direct_sum_f64(pos, 100, 2000, 300, n - 517, eps2)
+        got_part = xyz(part)[100:2100]
+        err = np.linalg.norm(got_part - ref_part, axis=1) / size_part
+        assert err.max() < tol, (variant, "partial", err.max())
+
+
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 @pytest.mark.parametrize("mode_name", ["strict", "fast"])
 def test_shard_chunks_compose(gpu, oracle, dtype, mode_name):

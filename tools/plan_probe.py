@@ -22,7 +22,8 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--mode", choices=["fast", "strict"], default="fast")
     ap.add_argument("--data", choices=["normal", "shell", "zeros"], default="normal", help="positions: standard normal / the reference's SHELL start-up / all bodies at the origin")
-    ap.add_argument("--masses", choices=["equal", "varied"], default="equal", help="varied: every chunk takes the generic (mass-multiplying) loop")
+    ap.add_argument("--masses", choices=["equal", "varied", "species"], default="equal",
+                    help="varied: every chunk takes the generic (mass-multiplying) loop; species: three contiguous blocks of equal masses (1, 0.3, 2.5)")
     ap.add_argument("plans", nargs="*", default=["0,0,0"])
     args = ap.parse_args()
     pkg = entry.load_package()
@@ -47,6 +48,10 @@ def main():
     if args.masses == "varied":
         pos = pos.copy()
         pos[:, 3] = (0.5 + rng.random(n)).astype(dtype)
+    if args.masses == "species":
+        pos = pos.copy()
+        pos[n // 3:, 3] = 0.3
+        pos[2 * n // 3:, 3] = 2.5
     mode = pkg.NB_MODE_FAST if args.mode == "fast" else pkg.NB_MODE_STRICT
     system = pkg.BodySystemHIP(n, 256, pkg.NBodyParams(), dtype, pos.ravel(), vel.ravel(), mode=mode)
     flops = 30 if args.fp64 else 20
