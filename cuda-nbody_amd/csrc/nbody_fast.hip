@@ -26,7 +26,8 @@
 //   * Mass factorisation: sums are accumulated in units of m_ref (the mass of the first body j of the range), and a
 //     chunk whose bodies ALL have mass m_ref -- every chunk of an equal-mass system such as the reference's start-up
 //     configurations -- takes a loop without the mass multiply (11 packed ops + 2 v_rsq per interaction pair instead of
-//     12 + 2, plus one packed op per body j for m_j/m_ref).  With m_ref = 1 both forms are bit-identical to the plain one.
+//     12 + 2, plus one packed op per body j for m_j/m_ref).  So does a chunk whose bodies all share ANOTHER mass (a species of
+//     a galaxy file): into sums of its own, which join the running sums once, scaled by that mass.
 //   * Wave-split layout (small shards, fewer bodies i than lanes on the chip): a wave owns the bodies i, its 64
 //     lanes split j, wavefront-64 butterfly fold at the end (integrate_bodies_wavesplit below).
 //   * softening^2 stays in a vector register pair: as a scalar operand of the v_pk_fma it changes nothing (same microbenchmark).
