@@ -262,7 +262,7 @@ template <typename T, int R, int S, int LPT> __global__ __launch_bounds__(block_
     const unsigned n_chunks = (s.j_count + CH - 1) / CH;
 
 #ifdef NB_STAMPS  // diagnostic build only (tools/stamp_probe.py): when does each wave start / finish streaming?
-    const unsigned long long stamp_t0 = __builtin_amdgcn_s_memtime();
+    const unsigned long long stamp_t0 = __builtin_amdgcn_s_memrealtime();  // (100 MHz, one clock for the whole chip)
 #endif
 
     // The SIMD arbiter is strictly oldest-first: left alone, the four waves that share a SIMD finish equal shares of work
@@ -272,7 +272,8 @@ template <typename T, int R, int S, int LPT> __global__ __launch_bounds__(block_
     // chunks it has done; a wave that is level with the slowest wave of ITS SIMD (HW_ID.SIMD_ID) runs at priority 3, one that is ahead
     // at 0.  With two waves per SIMD and workgroup (S = 8, the production geometry: two 512-thread workgroups per CU) they
     // finish within 0.5 % of each other; with four (S = 16) the two youngest still trail (a starved wave cannot re-evaluate
-    // itself; graded levels made it worse), which is why S = 8 is the default.  The chunk -> wave assignment stays static, so the summation order (and every result bit) is the same
+    // itself; graded levels made it worse, and letting a yielding wave look again every 8 bodies cost 1 % at S = 8 and 27 % on
+    // one-workgroup-per-CU shards), which is why S = 8 is the default.  The chunk -> wave assignment stays static, so the summation order (and every result bit) is the same
     // from run to run.  (Putting the leaders to sleep instead equalises too, but costs 15 %: a SIMD needs 3-4 runnable waves.)
     constexpr size_t kFoldBytes = static_cast<size_t>(S - 1) * 3 * I * 64 * sizeof(T);
     unsigned* const   balance    = reinterpret_cast<unsigned*>(smem_raw + kFoldBytes);
@@ -473,7 +474,7 @@ template <typename T, int R, int S, int LPT> __global__ __launch_bounds__(block_
 #ifdef NB_STAMPS
     if (lane == 0 && s.acc != nullptr && s.finalize && !s.acc_in) {
         unsigned long long* stamps = reinterpret_cast<unsigned long long*>(s.acc) + (static_cast<size_t>(blockIdx.x) * S + wave) * 2;
-        stamps[0] = stamp_t0, stamps[1] = __builtin_amdgcn_s_memtime();
+        stamps[0] = stamp_t0, stamps[1] = __builtin_amdgcn_s_memrealtime();
     }
 #endif
 
