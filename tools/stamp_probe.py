@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """tools/stamp_probe.py -- with a diagnostic build of the library (make -C cuda-nbody_amd/csrc EXP=-DNB_STAMPS OUT=...),
-record when each wave of each workgroup of the FAST kernel starts and stops streaming (s_memtime), and print how the
+record when each wave of each workgroup of the FAST kernel starts and stops streaming (s_memrealtime, 10 ns ticks), and print how the
 waves of a workgroup spread out: the under-filled tail of a workgroup is (last finish - mean finish).
 
     NBODY_HIP_LIB=/path/libnbody_hip_stamps.so python3 tools/stamp_probe.py [--bodies N] [--plan I,S,TILE]
@@ -42,7 +42,7 @@ st = raw[:plan.grid_blocks * waves * 2].reshape(plan.grid_blocks, waves, 2).asty
 t0 = st[:, :, 0].min(axis=1, keepdims=True)
 dur = st[:, :, 1] - t0                       # per wave: finish time since the workgroup's first start
 span = dur.max(axis=1)                       # workgroup busy span
-print(f"plan {args.plan}: {plan.grid_blocks} workgroups x {waves} waves; median workgroup span {np.median(span):.0f} cycles")
+print(f"plan {args.plan}: {plan.grid_blocks} workgroups x {waves} waves; median workgroup span {np.median(span) * 0.01:.1f} us")
 rel = np.sort(dur / span[:, None], axis=1)   # sorted finish times relative to the span
 print("finish time of the k-th wave / workgroup span, median over workgroups:")
 print("  " + " ".join(f"{x:.3f}" for x in np.median(rel, axis=0)))
