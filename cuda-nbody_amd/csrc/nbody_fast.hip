@@ -26,7 +26,7 @@
 //   * Mass factorisation: sums are accumulated in units of m_ref (the mass of the first body j of the range), and a
 //     chunk whose bodies ALL have mass m_ref -- every chunk of an equal-mass system such as the reference's start-up
 //     configurations -- takes a loop without the mass multiply (11 packed ops + 2 v_rsq per interaction pair instead of
-//     12 + 2, plus one packed op per body j for m_j/m_ref).  So does a chunk whose bodies all share ANOTHER mass (a species of
+//     12 + 2; a chunk of mixed masses multiplies by the raw mass in the loop and by 1/m_ref once, when its sums join the others).  So does a chunk whose bodies all share ANOTHER mass (a species of
 //     a galaxy file): into sums of its own, which join the running sums once, scaled by that mass.
 //   * Wave-split layout (small shards, fewer bodies i than lanes on the chip): a wave owns the bodies i, its 64
 //     lanes split j, wavefront-64 butterfly fold at the end (integrate_bodies_wavesplit below).
@@ -372,7 +372,7 @@ template <typename T, int R, int S, int LPT> __global__ __launch_bounds__(block_
 #pragma unroll
             for (int u = 0; u < UB; ++u) {
                 vec mrel = inv_mref_v;
-                if constexpr (!UNIT) mrel = LT::splat(b[h + u].w) * inv_mref_v;
+                if constexpr (!UNIT) mrel = LT::splat(b[h + u].w);  // (the raw mass, a scalar operand; the chunk's sums are scaled once)
 #pragma unroll
                 for (int r = 0; r < R; ++r) w[u][r] = LT::template coupling_rel<UNIT>(mrel, w[u][r], consts);
             }
@@ -445,8 +445,13 @@ template <typename T, int R, int S, int LPT> __global__ __launch_bounds__(block_
                 const vec scale = LT::splat(common_mass) * inv_mref_v;
 #pragma unroll
                 for (int r = 0; r < R; ++r) ax[r] = LT::fma(cx[r], scale, ax[r]), ay[r] = LT::fma(cy[r], scale, ay[r]), az[r] = LT::fma(cz[r], scale, az[r]);
-            } else {
-                stream.template operator()<false>(chunk, groups, next, b0, b1, ax, ay, az);
+            } else {  // mixed masses: the raw mass multiplies inside the loop, 1/m_ref once per chunk
+                vec cx[R], cy[R], cz[R];
+#pragma unroll
+                for (int r = 0; r < R; ++r) cx[r] = cy[r] = cz[r] = LT::splat(0);
+                stream.template operator()<false>(chunk, groups, next, b0, b1, cx, cy, cz);
+#pragma unroll
+                for (int r = 0; r < R; ++r) ax[r] = LT::fma(cx[r], inv_mref_v, ax[r]), ay[r] = LT::fma(cy[r], inv_mref_v, ay[r]), az[r] = LT::fma(cz[r], inv_mref_v, az[r]);
             }
         }
 #pragma unroll 1
