@@ -217,6 +217,39 @@ def test_fast_chunk_forms_by_mass(gpu, oracle, dtype, plan):
         assert err.max() < tol, (variant, "partial", err.max())
 
 
+def test_fast_sees_positions_rewritten_between_launches(gpu):
+    """The FAST kernel reads the bodies j through the scalar cache as launch-constant data.  Constant for ONE launch: the same
+    device array rewritten by the host, by a device-to-device copy and by a previous launch must be seen fresh by the next."""
+    n = 128 * 9
+    rng = np.random.default_rng(5)
+    eps2 = np.float32(0.1) * np.float32(0.1)
+    gpu.set_softening_squared(eps2)
+    lib = gpu.lib()
+    d_pos, d_other, d_acc = gpu.DeviceBuffer(16 * n), gpu.DeviceBuffer(16 * n), gpu.DeviceBuffer(16 * n)
+
+    def check(pos, what):
+        gpu.check(lib.nb_integrate_shard_f32(None, d_pos.ptr, None, d_acc.ptr, 0, n, 0, n, 0, np.float32(DT), np.float32(1), 256, gpu.NB_MODE_FAST, None))
+        acc = d_acc.download(np.zeros(4 * n, np.float32))
+        ref, size = direct_sum_f64(pos, 0, n, 0, n, eps2)
+        assert (np.linalg.norm(xyz(acc) - ref, axis=1) / size).max() < 5e-6, what
+
+    gpu.set_plan_override(2, 8, 512)  # the wave-stream layout at this small size
+    try:
+        first = np.concatenate([rng.standard_normal((n, 3)), np.ones((n, 1))], axis=1).astype(np.float32)
+        d_pos.upload(first.reshape(-1))
+        check(first, "first upload")
+        second = np.concatenate([rng.standard_normal((n, 3)) * 3 + 1, rng.uniform(0.5, 2, (n, 1))], axis=1).astype(np.float32)
+        d_pos.upload(second.reshape(-1))  # host rewrite of the same array
+        check(second, "after a host rewrite")
+        third = np.concatenate([rng.standard_normal((n, 3)) * 0.5, np.full((n, 1), 2.0)], axis=1).astype(np.float32)
+        d_other.upload(third.reshape(-1))
+        gpu.check(lib.nb_d2d(d_pos.ptr, d_other.ptr, 16 * n, None))
+        check(third, "after a device copy")
+    finally:
+        gpu.set_plan_override(0, 0, 0)
+        d_pos.free(), d_other.free(), d_acc.free()
+
+
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 @pytest.mark.parametrize("mode_name", ["strict", "fast"])
 def test_shard_chunks_compose(gpu, oracle, dtype, mode_name):
