@@ -233,6 +233,22 @@ def test_cli_strict_run_reproduces_golden(tmp_path, n, tag, dtype, flags):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("flags", [[], ["--fp64"]])
+def test_cli_fast_hostmem_equals_device_memory_bitwise(tmp_path, flags):
+    """FAST at a size that takes the wave-stream kernel (bodies j through scalar loads): with the positions in mapped host
+    memory (--hostmem) the run must produce the same bits as with device arrays -- same kernel, same data, and FAST is
+    deterministic from run to run."""
+    dumps = []
+    for extra in ([], ["--hostmem"]):
+        dump = tmp_path / ("state" + "_".join(extra) + ".bin")
+        r = run_cli("--numbodies=32768", "--steps=3", f"--dump={dump}", *flags, *extra)
+        assert r.returncode == 0, r.stderr
+        dumps.append(np.fromfile(dump, dtype=np.uint8))
+    assert dumps[0].size == 32768 * 8 * (8 if flags else 4)
+    assert dumps[0].tobytes() == dumps[1].tobytes()
+
+
+@pytest.mark.gpu
 def test_cli_tipsy_and_other_configs(host, tmp_path, oracle):
     n = 700
     oracle.srand(9)
