@@ -249,6 +249,36 @@ def test_cli_fast_hostmem_equals_device_memory_bitwise(tmp_path, flags):
 
 
 @pytest.mark.gpu
+def test_cli_fast_on_a_three_species_galaxy_file(host, tmp_path, oracle):
+    """A tipsy model with three species of different masses in contiguous blocks (what galaxy files look like), large enough
+    for the wave-stream kernel: FAST (chunks of one species take the loop without the mass multiply, chunks straddling a
+    boundary the mixed one) against STRICT -- the CPU path's bits -- after 3 steps."""
+    n, nd = 40960, 21111
+    oracle.srand(21)
+    pos, vel = oracle.randomise(0, n, 1.54, 8.0, np.float64)
+    mass = np.empty(n, np.float32)
+    mass[:nd], mass[nd:nd + 12345], mass[nd + 12345:] = 2.5, 0.75, 1.0  # (dark first, then stars: the writer's order)
+    pos[3::4] = mass
+    vel[3::4] = np.float32(0.01)
+    path = tmp_path / "galaxy.tipsy"
+    dp = ctypes.POINTER(ctypes.c_double)
+    assert host.nbh_write_tipsy(str(path).encode(), pos.ctypes.data_as(dp), vel.ctypes.data_as(dp), n, nd) == 0
+    out = {}
+    for mode in ("fast", "strict"):
+        dump = tmp_path / f"{mode}.bin"
+        r = run_cli(f"--tipsy={path}", f"--mode={mode}", "--steps=3", f"--dump={dump}")
+        assert r.returncode == 0, r.stderr
+        out[mode] = np.fromfile(dump, dtype=np.float32)
+    assert out["fast"].size == out["strict"].size == 8 * n
+    p_fast, p_strict = out["fast"][:4 * n].reshape(n, 4), out["strict"][:4 * n].reshape(n, 4)
+    assert np.array_equal(p_fast[:, 3], p_strict[:, 3])  # masses untouched
+    scale = np.abs(p_strict[:, :3]).max()
+    assert np.abs(p_fast[:, :3] - p_strict[:, :3]).max() / scale < 2e-6
+    v_fast, v_strict = out["fast"][4 * n:].reshape(n, 4), out["strict"][4 * n:].reshape(n, 4)
+    assert np.abs(v_fast[:, :3] - v_strict[:, :3]).max() / np.abs(v_strict[:, :3]).max() < 2e-5
+
+
+@pytest.mark.gpu
 def test_cli_tipsy_and_other_configs(host, tmp_path, oracle):
     n = 700
     oracle.srand(9)
