@@ -115,6 +115,16 @@ variant("probe: 8 v_rsq + 24 v_pk_fma interleaved", [RSQ(k) if k % 4 == 0 else P
 variant("probe: 8 v_rsq + 24 v_fma_f32 interleaved", [RSQ(k) if k % 4 == 0 else FMA(k) for k in range(32)], pairs_per_iter=32)
 variant("probe: 32 v_rsq_f32", [RSQ(k) for k in range(32)], pairs_per_iter=32)
 variant("probe: 32 v_mul_f32", [MUL(k) for k in range(32)], pairs_per_iter=32)
+# fp64 issue costs (what the FAST fp64 loop is made of): v[100:103] hold finite doubles made of the float patterns, results go nowhere useful
+D = lambda k: 2 + 2 * (k % 24)
+variant("probe: 32 v_fma_f64", [f"v_fma_f64 v[{D(k)}:{D(k)+1}], v[100:101], v[102:103], v[{D(k)}:{D(k)+1}]" for k in range(32)], pairs_per_iter=32)
+variant("probe: 32 v_mul_f64", [f"v_mul_f64 v[{D(k)}:{D(k)+1}], v[100:101], v[{D(k)}:{D(k)+1}]" for k in range(32)], pairs_per_iter=32)
+variant("probe: 32 v_add_f64", [f"v_add_f64 v[{D(k)}:{D(k)+1}], v[100:101], v[{D(k)}:{D(k)+1}]" for k in range(32)], pairs_per_iter=32)
+variant("probe: 32 v_rsq_f64", [f"v_rsq_f64 v[{D(k)}:{D(k)+1}], v[100:101]" for k in range(32)], pairs_per_iter=32)
+variant("probe: 32 v_rcp_f64", [f"v_rcp_f64 v[{D(k)}:{D(k)+1}], v[100:101]" for k in range(32)], pairs_per_iter=32)
+variant("probe: 32 v_cvt_f32_f64", [f"v_cvt_f32_f64 v{D(k)}, v[100:101]" for k in range(32)], pairs_per_iter=32)
+variant("probe: 32 v_cvt_f64_f32", [f"v_cvt_f64_f32 v[{D(k)}:{D(k)+1}], v100" for k in range(32)], pairs_per_iter=32)
+variant("probe: 8 v_rsq_f64 + 24 v_fma_f64 interleaved", [f"v_rsq_f64 v[{D(k)}:{D(k)+1}], v[100:101]" if k % 4 == 0 else f"v_fma_f64 v[{D(k)}:{D(k)+1}], v[100:101], v[102:103], v[{D(k)}:{D(k)+1}]" for k in range(32)], pairs_per_iter=32)
 # packed ops with ONE scalar source, by operand position (s[60:65] are set by the prologue)
 SETS = ["s_mov_b32 s60, 0x3f800000", "s_mov_b32 s61, 0x40000000", "s_mov_b32 s62, 0x40400000", "s_mov_b32 s63, 0x3f800000", "s_mov_b32 s64, 0x3c23d70a", "s_mov_b32 s65, 0x3c23d70a"]
 variant("probe: 32 v_pk_add_f32 v,v", [f"v_pk_add_f32 v[{acc(k)}:{acc(k)+1}], v[100:101], v[{acc(k)}:{acc(k)+1}]" for k in range(32)], pairs_per_iter=32)
