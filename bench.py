@@ -162,6 +162,8 @@ def make_bodies(n: int, dtype):
 # with 3-4 runnable waves (11 v_pk_* at ~4 cycles + 2 v_rsq_f32 at ~8.3); at the nominal 2.4 GHz that is
 # 1024 SIMDs x 128 interactions / 61.5 cycles = 5.115e12 interactions/s = 65.0 % of the 157.3 TFLOP/s "20 flop" roofline.
 FP32_ISSUE_CEILING_INTERACTIONS_PER_S = 1024 * 128 * 2.4e9 / 61.5
+# fp64 (profiles/round2_fp64_issue_probes.txt): 14 add/mul/fma at 4.41 cycles + one v_rsq_f64 at 16.3 = 78 cycles per interaction and wave
+FP64_ISSUE_CEILING_INTERACTIONS_PER_S = 1024 * 64 * 2.4e9 / 78.0
 
 
 def main():
@@ -484,8 +486,8 @@ def main():
                 "traffic_source": traffic_src,
                 # achieved / what this instruction mix can issue at best on the chip (see FP32_ISSUE_CEILING_...): how close
                 # the kernel is to ITS ceiling; `frac` above is against the nominal "20 flop" peak
-                "issue_ceiling_frac": (value / world / FP32_ISSUE_CEILING_INTERACTIONS_PER_S) if not args.fp64 else None,
-                "issue_ceiling_interactions_per_s": FP32_ISSUE_CEILING_INTERACTIONS_PER_S if not args.fp64 else None,
+                "issue_ceiling_frac": value / world / (FP64_ISSUE_CEILING_INTERACTIONS_PER_S if args.fp64 else FP32_ISSUE_CEILING_INTERACTIONS_PER_S),
+                "issue_ceiling_interactions_per_s": FP64_ISSUE_CEILING_INTERACTIONS_PER_S if args.fp64 else FP32_ISSUE_CEILING_INTERACTIONS_PER_S,
                 "kernel_ms": ms_per_launch,
                 "algorithmic_flops_per_launch": flops_per * per_launch_interactions,
                 "algorithmic_hbm_bytes_per_launch": (128 if args.fp64 else 64) * (n // world),
