@@ -24,9 +24,12 @@
 //       sqrt : r = rsq(x); s = x*r; h = r/2; d = fma(-s,s,x); s = fma(d,h,s)
 //              == sqrtf(x) for EVERY float in [2^-100, 2^127)   (exhaustive: tools/strict_unit_mass_check.hip; so is LLVM's
 //              longer form with the extra e = fma(-h,s,1/2); h = fma(h,e,h); s = fma(s,e,s) step, which rounds 1-3 used)
-//       div  : r = rcp(d); e = fma(-d,r,1); r = fma(e,r,r); q = n*r; e = fma(-d,q,n); q = fma(e,r,q); e = fma(-d,q,n); q = fma(e,r,q)
-//              is hipcc's own sequence with the identity scalings removed; == n/d on 1.7e10 random + structured pairs
-//     (profiles/round2_strict_fastpath_check.txt).  25 packed ops + 6 adds + 4 transcendentals per two interactions.
+//       div  : r = rcp(d); e = fma(-d,r,1); r = fma(e,r,r); q = n*r; e = fma(-d,q,n); q = fma(e,r,q)
+//              == n/d for EVERY pair of significands (2^46 quotients, tools/strict_divide_exhaustive.hip,
+//              profiles/round2_strict_divide_exhaustive.txt; every step scales exactly with the operands' exponents inside the
+//              window, v_rcp_f32 included, so that covers all operands).  hipcc's own sequence corrects the quotient a second
+//              time (e = fma(-d,q,n); q = fma(e,r,q) again): also exact, never needed.
+//     23 packed ops + 6 adds + 4 transcendentals per two interactions.
 //       unit : a chunk whose masses are all exactly 1.0f (every start-up configuration of the reference) needs 1/d, not m/d:
 //              r = rcp(d); e = fma(-d,r,1); r = fma(e,r,r) == 1.0f/d for EVERY float d in [2^-100, 2^101) (exhaustive, same
 //              tool, profiles/round2_strict_unit_mass_check.txt): 20 packed ops + 6 adds + 4 transcendentals.
@@ -118,10 +121,6 @@ __device__ __forceinline__ void interact_jpairs_fast(const v2f (&bx)[U], const v
         } else {
 #pragma unroll
             for (int u = 0; u < U; ++u) q[u] = bm[u] * rc[u];
-#pragma unroll
-            for (int u = 0; u < U; ++u) e[u] = pk_fma(-d[u], q[u], bm[u]);
-#pragma unroll
-            for (int u = 0; u < U; ++u) q[u] = pk_fma(e[u], rc[u], q[u]);
 #pragma unroll
             for (int u = 0; u < U; ++u) e[u] = pk_fma(-d[u], q[u], bm[u]);
 #pragma unroll

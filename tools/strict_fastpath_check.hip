@@ -34,11 +34,9 @@ __device__ __forceinline__ float fast_div(float n, float d) {
     float       r  = __builtin_amdgcn_rcpf(d);
     const float e  = __builtin_fmaf(-d, r, 1.0f);
     r              = __builtin_fmaf(e, r, r);
-    float       q  = n * r;
+    const float q  = n * r;
     const float e2 = __builtin_fmaf(-d, q, n);
-    q              = __builtin_fmaf(e2, r, q);
-    const float e3 = __builtin_fmaf(-d, q, n);
-    return __builtin_fmaf(e3, r, q);
+    return __builtin_fmaf(e2, r, q);  // (one correction: exact for every pair of significands, strict_divide_exhaustive.hip)
 }
 
 __device__ __forceinline__ double fast_sqrt_f64(double x) {
