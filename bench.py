@@ -486,8 +486,9 @@ def main():
                 "traffic_source": traffic_src,
                 # achieved / what this instruction mix can issue at best on the chip (see FP32_ISSUE_CEILING_...): how close
                 # the kernel is to ITS ceiling; `frac` above is against the nominal "20 flop" peak
-                "issue_ceiling_frac": value / world / (FP64_ISSUE_CEILING_INTERACTIONS_PER_S if args.fp64 else FP32_ISSUE_CEILING_INTERACTIONS_PER_S),
-                "issue_ceiling_interactions_per_s": FP64_ISSUE_CEILING_INTERACTIONS_PER_S if args.fp64 else FP32_ISSUE_CEILING_INTERACTIONS_PER_S,
+                # (the ceilings are those of the FAST instruction mix; STRICT executes other, exactly rounded, operations)
+                "issue_ceiling_frac": None if args.mode != "fast" else value / world / (FP64_ISSUE_CEILING_INTERACTIONS_PER_S if args.fp64 else FP32_ISSUE_CEILING_INTERACTIONS_PER_S),
+                "issue_ceiling_interactions_per_s": None if args.mode != "fast" else (FP64_ISSUE_CEILING_INTERACTIONS_PER_S if args.fp64 else FP32_ISSUE_CEILING_INTERACTIONS_PER_S),
                 "kernel_ms": ms_per_launch,
                 "algorithmic_flops_per_launch": flops_per * per_launch_interactions,
                 "algorithmic_hbm_bytes_per_launch": (128 if args.fp64 else 64) * (n // world),
