@@ -595,11 +595,11 @@ def test_strict_bitwise_on_extreme_values(gpu, oracle, dtype):
 def test_strict_fast_form_window_edges_bitwise(gpu, oracle, dtype):
     """The STRICT kernels run divide and sqrt without scaling/fix-up steps while every operand sits inside a checked
     window (fp32: |coordinate| <= 2^18, 2^-40 <= |mass| <= 2^40 or +0, softening^2 in [2^-39, 2^38]; fp64: 2^100, 2^+-100,
-    [2^-100, 2^100]) and fall back to the generic IEEE expansions per 64-body chunk otherwise.  Systems that sit ON the
+    [2^-100, 2^100]) and fall back to the generic IEEE expansions per 128-body chunk otherwise.  Systems that sit ON the
     window's edges, mix in-window and out-of-window chunks, produce denormal products (tiny separations) and carry -0 /
     zero masses must all stay 0 ulp; so must the fp32 unit-mass form (chunks of masses exactly 1.0: a 2-op reciprocal)."""
     rng = np.random.default_rng(7)
-    n = 64 * 9 + 17  # ragged last chunk
+    n = 128 * 9 + 17  # ragged last chunk
     f32 = dtype == np.float32
     cexp, mexp = (18, 40) if f32 else (100, 100)
     ulp = 2.0 ** -23 if f32 else 2.0 ** -52
@@ -622,11 +622,11 @@ def test_strict_fast_form_window_edges_bitwise(gpu, oracle, dtype):
     cases.append(("edges", pos, vel, 0.1))
     # (b) single chunks just outside (coordinate one ulp above the edge, mass 2^(mexp+1), mass -0.0), the others inside
     pos, vel = system(100.0, -3, 3)
-    pos[64 * 2 + 5, 0] = dtype(2.0 ** cexp) * dtype(1 + ulp)
-    pos[64 * 4 + 1, 3] = 2.0 ** (mexp + 1)
-    pos[64 * 6 + 9, 3] = -0.0
-    pos[64 * 7 + 2, 3] = 0.0
-    pos[64 * 8 + 3, 3] = -1.5  # negative masses are in the window too
+    pos[128 * 2 + 5, 0] = dtype(2.0 ** cexp) * dtype(1 + ulp)
+    pos[128 * 4 + 1, 3] = 2.0 ** (mexp + 1)
+    pos[128 * 6 + 9, 3] = -0.0
+    pos[128 * 7 + 2, 3] = 0.0
+    pos[128 * 8 + 3, 3] = -1.5  # negative masses are in the window too
     cases.append(("mixed chunks", pos, vel, 0.1))
     # (c) tiny separations: dx^2 underflows / goes denormal (fp32), softening at the window's lower edge
     pos, vel = system(1.0, -2, 2)
@@ -642,10 +642,10 @@ def test_strict_fast_form_window_edges_bitwise(gpu, oracle, dtype):
     pos, vel = system(2.0 ** min(cexp, 18), 0, 0)
     pos[:, 3] = 1
     pos[0, :3], pos[1, :3] = 2.0 ** min(cexp, 18), -(2.0 ** min(cexp, 18))
-    pos[64 * 1 + 63, 3] = dtype(1) + dtype(ulp)
-    pos[64 * 3 + 0, 3] = dtype(1) - dtype(ulp / 2)
-    pos[64 * 5 + 31, 3] = 2
-    pos[64 * 7 + 7, 3] = -1
+    pos[128 * 1 + 63, 3] = dtype(1) + dtype(ulp)
+    pos[128 * 3 + 0, 3] = dtype(1) - dtype(ulp / 2)
+    pos[128 * 5 + 31, 3] = 2
+    pos[128 * 7 + 7, 3] = -1
     cases.append(("unit-mass chunks among others", pos, vel, 0.1))
     pos, vel = system(1.0, 0, 0)
     pos[:, 3] = 1
