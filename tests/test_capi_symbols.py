@@ -108,3 +108,40 @@ def test_inline_asm_never_consumes_a_transcendental_result_directly():
                 t = re.match(r"v_(rsq|rcp|sqrt|exp|log|sin|cos)_f32(_e32|_e64)? v(\d+),", prev)
                 assert not (t and int(t.group(3)) in sources), (i, prev, line)
     assert inline > 0  # the instruction is there (otherwise this test checks nothing)
+
+
+def test_production_inner_loops_keep_their_instruction_mix():
+    """A guard against a silent regression of the code generator: the headline kernel (fp32, 4 bodies i per lane, 8 waves per
+    workgroup) must keep streaming loops of exactly 11 (unit / one-species chunks) and 12 (mixed masses) packed ops + 2 v_rsq per
+    interaction pair, with the bodies j in scalar registers (s_load, no ds_* and no v_mov in the loop, no hazard s_nop), <= 128
+    VGPRs and no scratch; and no FAST kernel at all may use scratch."""
+    import subprocess
+
+    csrc = os.path.join(ROOT, "cuda-nbody_amd", "csrc")
+    subprocess.run(["make", "-s", "-C", csrc, "asm"], check=True, capture_output=True)
+    lines = open(os.path.join(csrc, "nbody_fast.s")).read().split("\n")
+    kernel = "_ZN2nb12_GLOBAL__N_121integrate_bodies_fastIfLi2ELi8ELi2EEEvNS_5ShardIT_EE"
+    start = next(i for i, l in enumerate(lines) if l.startswith(kernel + ":"))
+    end = next(i for i in range(start, len(lines)) if lines[i].startswith(".Lfunc_end"))
+    mixes = []
+    for i in range(start, end):
+        if "Inner Loop Header" not in lines[i]:
+            continue
+        label = lines[i - 1].split(":")[0].strip()
+        stop = next((k for k in range(i, end) if ("s_cbranch" in lines[k] or "s_branch" in lines[k]) and label in lines[k]), None)
+        if stop is None:
+            continue
+        body = [l.strip() for l in lines[i + 1:stop]]
+        count = lambda prefix: sum(1 for l in body if l.startswith(prefix))
+        if count("v_rsq_f32") == 32:  # a streaming loop: two groups of 4 bodies j x 2 packed pairs of bodies i
+            mixes.append((count("v_pk_"), count("ds_"), count("v_mov"), count("s_nop"), count("s_load"),
+                          sum(1 for l in body if l.startswith("v_") and not l.startswith(("v_pk_", "v_rsq_f32")))))
+    assert sorted(m[0] for m in mixes) == [176, 176, 192], mixes  # unit, one-species, mixed
+    for packed, lds, moves, nops, loads, other_valu in mixes:
+        assert lds == 0 and moves == 0 and nops == 0 and other_valu == 0 and loads >= 2, mixes
+    tail = "\n".join(lines[end:end + 60])
+    assert int(re.search(r"; NumVgprs: (\d+)", tail).group(1)) <= 128
+    assert int(re.search(r"; ScratchSize: (\d+)", tail).group(1)) == 0
+    # no FAST kernel spills to scratch
+    sizes = [int(m) for m in re.findall(r"; ScratchSize: (\d+)", "\n".join(lines))]
+    assert sizes and max(sizes) == 0, max(sizes)
