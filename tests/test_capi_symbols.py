@@ -145,3 +145,32 @@ def test_production_inner_loops_keep_their_instruction_mix():
     # no FAST kernel spills to scratch
     sizes = [int(m) for m in re.findall(r"; ScratchSize: (\d+)", "\n".join(lines))]
     assert sizes and max(sizes) == 0, max(sizes)
+
+
+def test_strict_fast_form_loops_keep_their_instruction_mix():
+    """The same guard for the bit-reproducing kernel: per four packed pairs of bodies j the fp32 fast form issues 80 packed ops
+    (unit masses) or 92 (any masses) + 16 transcendentals + 24 adds -- the exhaustively verified sqrt / reciprocal / divide
+    sequences and nothing else -- without scratch."""
+    import subprocess
+
+    csrc = os.path.join(ROOT, "cuda-nbody_amd", "csrc")
+    subprocess.run(["make", "-s", "-C", csrc, "asm"], check=True, capture_output=True)
+    lines = open(os.path.join(csrc, "nbody_strict.s")).read().split("\n")
+    kernel = "_ZN2nb12_GLOBAL__N_123integrate_bodies_strictIfEEvNS_5ShardIT_EE"
+    start = next(i for i, l in enumerate(lines) if l.startswith(kernel + ":"))
+    end = next(i for i in range(start, len(lines)) if lines[i].startswith(".Lfunc_end"))
+    packed = []
+    for i in range(start, end):
+        if "Inner Loop Header" not in lines[i]:
+            continue
+        label = lines[i - 1].split(":")[0].strip()
+        stop = next((k for k in range(i, end) if ("s_cbranch" in lines[k] or "s_branch" in lines[k]) and label in lines[k]), None)
+        if stop is None:
+            continue
+        body = [l.strip() for l in lines[i + 1:stop]]
+        count = lambda prefix: sum(1 for l in body if l.startswith(prefix))
+        if count("v_rsq_f32") == 8 and count("v_rcp_f32") == 8:  # the U = 4 pair loops
+            assert count("v_add_f32") == 24 and count("v_mov") == 0 and count("scratch_") == 0, body
+            packed.append(count("v_pk_"))
+    assert sorted(packed) == [80, 92], packed
+    assert int(re.search(r"; ScratchSize: (\d+)", "\n".join(lines[end:end + 60])).group(1)) == 0
