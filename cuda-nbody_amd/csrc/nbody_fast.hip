@@ -548,11 +548,11 @@ template <typename F> __device__ __forceinline__ F wave64_sum(F v) {
     return v;
 }
 
-template <typename T, int R, int LPT> __global__ __launch_bounds__(256) void integrate_bodies_wavesplit(Shard<T> s) {
+template <typename T, int R, int LPT, int BLOCK> __global__ __launch_bounds__(BLOCK) void integrate_bodies_wavesplit(Shard<T> s) {
     using LT            = Lane<T>;
     using vec4          = typename LT::vec4;
     using vec           = typename LT::vec;
-    constexpr int kBlock = 256;
+    constexpr int kBlock = BLOCK;  // (every workgroup stages ALL bodies j through its LDS: the more waves share a tile, the less L2 traffic)
     constexpr int WAVES = kBlock / 64;
     constexpr int W     = LT::W;
     constexpr int I     = R * W;          // bodies i per WAVE
@@ -657,16 +657,19 @@ template <typename T, int R, int LPT> __global__ __launch_bounds__(256) void int
     }
 }
 
-template <typename T, int R, int LPT> hipError_t launch_wavesplit(const Shard<T>& s, const Plan& p, hipStream_t stream, bool prepare_only) {
+template <typename T, int R, int LPT, int BLOCK> hipError_t launch_wavesplit(const Shard<T>& s, const Plan& p, hipStream_t stream, bool prepare_only) {
     if (prepare_only) return hipSuccess;
-    hipLaunchKernelGGL((integrate_bodies_wavesplit<T, R, LPT>), dim3(p.grid_blocks), dim3(256), p.lds_bytes, stream, s);
+    hipLaunchKernelGGL((integrate_bodies_wavesplit<T, R, LPT, BLOCK>), dim3(p.grid_blocks), dim3(BLOCK), p.lds_bytes, stream, s);
     return hipGetLastError();
 }
 
 template <typename T, int R> hipError_t dispatch_wavesplit(const Shard<T>& s, const Plan& p, hipStream_t stream, bool prepare_only) {
-    switch (p.tile_bodies / 256) {
-        case 2: return launch_wavesplit<T, R, 2>(s, p, stream, prepare_only);
-        case 4: return launch_wavesplit<T, R, 4>(s, p, stream, prepare_only);
+    switch (p.block_threads * 16 + p.tile_bodies / p.block_threads) {  // (workgroup size, vec4 loads per lane and tile)
+        case 256 * 16 + 2: return launch_wavesplit<T, R, 2, 256>(s, p, stream, prepare_only);
+        case 256 * 16 + 4: return launch_wavesplit<T, R, 4, 256>(s, p, stream, prepare_only);
+        case 512 * 16 + 1: return launch_wavesplit<T, R, 1, 512>(s, p, stream, prepare_only);
+        case 512 * 16 + 2: return launch_wavesplit<T, R, 2, 512>(s, p, stream, prepare_only);
+        case 1024 * 16 + 1: return launch_wavesplit<T, R, 1, 1024>(s, p, stream, prepare_only);
         default: return hipErrorInvalidValue;
     }
 }
@@ -760,8 +763,16 @@ template <typename T> Plan plan_fast(unsigned i_count, unsigned j_count, int cu_
         p.bodies_per_lane = I;  // per WAVE in this layout
         p.lanes_per_body  = kWaveSplit;
         p.tile_bodies     = (ovr_tile == 512 || ovr_tile == 1024) ? ovr_tile : (j_count > 512 ? 1024 : 512);
-        p.block_threads   = 256;
-        const unsigned bodies_per_block = 4u * static_cast<unsigned>(I);
+        // the largest workgroup that still leaves one per CU: a tile is staged once per workgroup whatever its size, so bigger
+        // workgroups mean less L2 traffic (-4 ... -8 % at 4 096 ... 16 384 bodies, profiles/round2_wavesplit_experiments.txt)
+        p.block_threads = 256;
+        for (int cand : {1024, 512}) {
+            if (p.tile_bodies % cand == 0 && (static_cast<long>(i_count) + cand / 64 * I - 1) / (cand / 64 * I) >= cu_count) {
+                p.block_threads = cand;
+                break;
+            }
+        }
+        const unsigned bodies_per_block = static_cast<unsigned>(p.block_threads / 64 * I);
         p.grid_blocks     = (i_count + bodies_per_block - 1) / bodies_per_block;
         p.lds_bytes       = static_cast<unsigned>(2ull * p.tile_bodies * 4 * sizeof(T));
         return p;
