@@ -70,9 +70,10 @@ def test_launch_plan_heuristics_without_gpu(pkg):
     assert plan(131072, 262144)[:2] + plan(131072, 262144)[4:] == (4, 16, 512)
     assert plan(65536, 262144)[:2] + plan(65536, 262144)[4:] == (4, 16, 256)
     assert plan(32768, 262144)[:2] + plan(32768, 262144)[4:] == (2, 16, 256)
-    # small or awkward sizes: wave-split layout (lanes_per_body == 64), 256-thread workgroups
-    for n in (1, 1024, 4096, 16384, 40960):
-        assert plan(n, n)[1] == 64 and plan(n, n)[3] == 256, n
+    # small or awkward sizes: wave-split layout (lanes_per_body == 64); the largest workgroup that still leaves one per CU
+    for n, block in ((1, 256), (1024, 256), (2048, 256), (4096, 512), (8192, 1024), (16384, 1024), (40960, 1024)):
+        assert plan(n, n)[1] == 64 and plan(n, n)[3] == block, (n, plan(n, n))
+        assert plan(n, n)[4] == -(-n // (plan(n, n)[0] * block // 64))
     # fp64: one body per vector, up to 4 per lane
     assert plan(262144, 262144, np.float64) == (4, 8, 1024, 512, 1024)
     assert plan(1024, 1024, np.float64)[1] == 64
