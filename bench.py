@@ -8,7 +8,11 @@
 A "step" is one pass of the hot path (integrateNbodySystem: N^2 interactions + leapfrog update) over the
 synthetic SHELL system the reference itself starts from.  Workload at any N GPUs: BASELINE.json configs[2],
 262 144 bodies fp32 (the configuration the metric is quoted on), total size fixed => "scaling": "strong";
-bodies shard across ranks with one RCCL all-gather of the new positions per step (cuda-nbody_amd/sharded.py).
+bodies shard across ranks with one RCCL all-gather of the new positions per step, issued as position tiles by the product's own
+multi-GPU entry points (nb_comm_init_rank + nb_sharded_step_*, csrc/nbody_comm.hip); torch.distributed (gloo) only does the
+rendezvous, the barriers and the time reduction.  cuda-nbody_amd/sharded.py, the same schedule over torch.distributed, stays as
+`--exchange torch` for A/B and as the fallback.  At N=1 the line also carries "configs": the other BASELINE configs and STRICT,
+timed after the headline measurement.
 
 Metric conventions are the reference's (src/nbody/compute.cpp:16-18,105-121): interactions/step = N^2
 (self-interaction counted), 20 flop per fp32 interaction, 30 per fp64.  Timing protocol: W untimed warm-up
@@ -51,14 +55,19 @@ def parse_args():
     ap.add_argument("--cpu-sample-bodies", type=int, default=0, help="bodies i in the CPU sample (0 = auto, ~10 s)")
     ap.add_argument("--sweep", action="store_true", help="time every fast-kernel geometry (tuning aid), N=1 only")
     ap.add_argument("--plan", type=str, default="", help="I,S,TILE override for the fast kernel, e.g. 2,1,1024")
-    ap.add_argument("--exchange", choices=["rccl", "allgather", "staged", "host", "host-tiles"], default="rccl",
-                    help="rccl: the position all-gather issued as its G-1 tiles (one grouped RCCL send/recv pair per round, the kernel "
-                         "of tile k waiting only on round k); allgather: one all_gather_into_tensor per step; "
-                         "staged: no RCCL at all -- gloo, the slices gathered through host memory, each rank on its OWN GPU (the launcher's "
-                         "last resort: a real N-GPU number of the kernels with a slow exchange); "
+    ap.add_argument("--exchange", choices=["rccl", "torch", "allgather", "staged", "host", "host-tiles"], default="rccl",
+                    help="rccl: the PRODUCT's multi-GPU path -- nb_comm_init_rank + nb_sharded_step_* of the C-ABI (csrc/nbody_comm.hip): the "
+                         "position all-gather issued as its G-1 tiles, one grouped RCCL send/recv pair per round on the communicator's side "
+                         "stream, the kernel of tile k waiting only on round k; torch.distributed then only does rendezvous, barrier and the "
+                         "time reduction (gloo).  torch: the same tile schedule re-implemented over torch.distributed "
+                         "(cuda-nbody_amd/sharded.py, batch_isend_irecv) -- A/B and first fallback; allgather: one all_gather_into_tensor per "
+                         "step (sharded.py); staged: no RCCL at all -- gloo, the slices gathered through host memory, each rank on its OWN GPU "
+                         "(the last resort: a real N-GPU number of the kernels with a slow exchange); "
                          "host: gloo + host-staged all-gather, so that several ranks can share ONE GPU (functional rehearsal of the "
                          "N-rank code path on a one-GPU box; RCCL refuses two ranks per device); host-tiles: the same rehearsal with the TILE "
-                         "schedule (gloo send/recv rounds on device tensors).  host* is never a performance number.")
+                         "schedule (gloo send/recv rounds staged through host memory).  host* is never a performance number.")
+    ap.add_argument("--dump-state", type=str, default="", help="rank 0 writes its final positions (.npy) here (tests)")
+    ap.add_argument("--no-configs", action="store_true", help="skip the extra BASELINE configs timed after the headline measurement (N=1)")
     ap.add_argument("--launch-timeout", type=float, default=600.0,
                     help="plain `bench.py --gpus N`: seconds the launcher waits for the N ranks before ending them (see self_launch)")
     ap.add_argument("--emulate-gpus", type=int, default=0,
@@ -72,8 +81,9 @@ def self_launch(n_ranks: int, explicit_exchange: bool, limit_s: float) -> int:
     127.0.0.1) as a CHILD process group and relay its output.  The >1-GPU path has not run on hardware yet, so the launcher
     carries one safety net: when the ranks fail or go `limit_s` seconds without finishing before rank 0 printed its line,
     and the exchange was not chosen on the command line, their process group is ended (by its exact id) and the job is
-    started again with a plainer exchange: `--exchange allgather` (one ncclAllGather per step), then `--exchange staged`
-    (gloo through host memory, no RCCL) -- at most those two further attempts."""
+    started again with a plainer exchange: `--exchange torch` (the tile schedule over torch.distributed), `--exchange allgather`
+    (one all-gather per step), then `--exchange staged` (gloo through host memory, no RCCL) -- at most those three further
+    attempts, each marked "exchange_fallback": true in its JSON line."""
     import signal
     import socket
     import subprocess
@@ -120,7 +130,10 @@ def self_launch(n_ranks: int, explicit_exchange: bool, limit_s: float) -> int:
         return rc, seen["metric"]
 
     rc, reported = attempt([])
-    for fallback in ("allgather", "staged"):  # plainer and plainer: one ncclAllGather per step, then no RCCL at all
+    # plainer and plainer: the tile schedule over torch.distributed, one all-gather per step, then no RCCL at all.  A line
+    # produced by a retry says so at its top level ("exchange_fallback": true), not only in config.exchange.
+    env["NBODY_BENCH_EXCHANGE_FALLBACK"] = "1"
+    for fallback in ("torch", "allgather", "staged"):
         if rc == 0 or reported or explicit_exchange:
             break
         print(f"[bench] the {n_ranks}-rank run ended with status {rc} before reporting; one more attempt with --exchange {fallback}", file=sys.stderr, flush=True)
@@ -166,6 +179,47 @@ FP32_ISSUE_CEILING_INTERACTIONS_PER_S = 1024 * 128 * 2.4e9 / 61.5
 FP64_ISSUE_CEILING_INTERACTIONS_PER_S = 1024 * 64 * 2.4e9 / 78.0
 
 
+def other_configs(pkg, lib, headline):
+    """BASELINE.json configs besides the headline one, plus STRICT (the parity-exact mode), each as
+    {workload, bodies, dtype, mode, steps, ms_per_step, interactions_per_s, frac}: 1 warm-up step, then K steps between two
+    HIP events on the launch stream (the reference's GPU protocol, compute_cuda.cpp:183-195); frac against the same
+    vector-FMA peaks as the headline (20 flop per fp32 interaction, 30 per fp64: compute.cpp:16-18)."""
+    cases = [
+        ("configs[1]: 65 536 bodies, fp32, 1 GPU", 65536, False, "fast", 200),
+        ("configs[2]: 262 144 bodies, fp32, 1 GPU", 262144, False, "fast", 20),
+        ("configs[4]: 262 144 bodies, fp64, 1 GPU", 262144, True, "fast", 5),
+        ("configs[3]'s system on ONE GPU: 1 048 576 bodies, fp32", 1048576, False, "fast", 3),
+        ("STRICT (bit-identical to the CPU BodySystem path): 262 144 bodies, fp32", 262144, False, "strict", 5),
+        ("STRICT: 262 144 bodies, fp64", 262144, True, "strict", 3),
+        ("configs[0]'s system on the GPU: 1 024 bodies, fp32, 100 steps", 1024, False, "fast", 100),
+        ("configs[0]'s system on the GPU, STRICT: 1 024 bodies, fp32, 100 steps", 1024, False, "strict", 100),
+        ("16 384 bodies, fp32 (small-system class)", 16384, False, "fast", 200),
+    ]
+    out = []
+    for what, n, fp64, mode_name, steps in cases:
+        if (n, fp64, mode_name) == headline:
+            continue
+        dtype = np.float64 if fp64 else np.float32
+        pos0, vel0 = make_bodies(n, dtype)
+        mode = pkg.NB_MODE_FAST if mode_name == "fast" else pkg.NB_MODE_STRICT
+        system = pkg.BodySystemHIP(n, 256, pkg.NBodyParams(), dtype, pos0, vel0, mode=mode)
+        dt = dtype(np.float32(0.016))
+        system.update(dt)
+        e0, e1 = pkg.Event(), pkg.Event()
+        system.synchronize()
+        e0.record(None)
+        for _ in range(steps):
+            system.update(dt)
+        e1.record(None)
+        e1.synchronize()
+        ms = e0.elapsed_ms(e1) / steps
+        system.free()
+        flops, peak = (30, FP64_VECTOR_PEAK_TFLOPS) if fp64 else (20, FP32_VECTOR_PEAK_TFLOPS)
+        out.append({"workload": what, "bodies": n, "dtype": "f64" if fp64 else "f32", "mode": mode_name, "steps": steps, "ms_per_step": ms,
+                    "interactions_per_s": float(n) * n / (ms * 1e-3), "frac": flops * float(n) * n / (ms * 1e-3) / (peak * 1e12)})
+    return out
+
+
 def main():
     args = parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -202,20 +256,27 @@ def main():
     # under torch.distributed.run (RANK set) the distributed path is taken even for one rank, so the 1-GPU line of a
     # scaling series is produced by the same code as the N-GPU lines
     distributed = world > 1 or "RANK" in os.environ
+    exchange_fallback = os.environ.get("NBODY_BENCH_EXCHANGE_FALLBACK") == "1"  # set by self_launch for its retries
+    rccl_group = None
     if distributed:
         import torch.distributed as dist
 
-        # RCCL's all-gather kernel competes with the force kernel for CUs (a 1024-thread workgroup fills a CU's VGPRs):
-        # a high-priority stream lets its few workgroups dispatch first, so the exchange overlaps the own-slice chunk
-        # instead of queueing behind it.
-        if over_gloo:
-            dist.init_process_group("gloo")
-        else:
+        # The default process group is gloo, always: rendezvous, barriers, the unique-id broadcast, collective decisions and
+        # the time reduction.  The data path is either the product's own RCCL communicator behind the C-ABI (--exchange rccl)
+        # or, for the torch.distributed re-implementation (--exchange torch|allgather), a separate "nccl" group.
+        dist.init_process_group("gloo")
+
+        def torch_rccl_group():
+            # RCCL's kernels compete with the force kernel for CUs (a 1024-thread workgroup fills a CU's VGPRs): a
+            # high-priority stream lets their few workgroups dispatch first, so the exchange overlaps the own-slice chunk
             try:
                 opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
-                dist.init_process_group("nccl", device_id=dev, pg_options=opts)
+                return dist.new_group(backend="nccl", pg_options=opts)
             except (AttributeError, TypeError):
-                dist.init_process_group("nccl", device_id=dev)
+                return dist.new_group(backend="nccl")
+
+        if args.exchange in ("torch", "allgather"):
+            rccl_group = torch_rccl_group()
     info = pkg.device_info(local_rank)
 
     pos0, vel0 = make_bodies(n, dtype)
@@ -241,37 +302,89 @@ def main():
         pkg.check(shard_fn(new_pos.data_ptr(), old_pos.data_ptr(), vel.data_ptr(), acc.data_ptr(), i0, ni, j0, nj, flags,
                            dt, damping, 256, mode, ctypes.c_void_p(stream.cuda_stream)), "nb_integrate_shard")
 
+    capi_rank = None  # --exchange rccl: this rank of the product's sharded system (nb_comm_init_rank + nb_sharded_step_*)
+    system = None     # every other exchange: cuda-nbody_amd/sharded.py over torch.distributed
     if distributed:
         sharded = entry.load_package_module("sharded")
-        host_gather = None
-        if args.exchange in ("host", "staged"):
-            class _Done:
-                def wait(self):
-                    pass
 
-            def host_gather(full, own):
-                staged = torch.empty(full.shape, dtype=full.dtype)
-                dist.all_gather_into_tensor(staged, own.cpu())
-                full.copy_(staged)
-                return _Done()
+        def everyone(ok: bool) -> bool:
+            """collective decision over gloo: true only if `ok` on EVERY rank (a rank deciding on its own would leave the
+            others inside mismatched collectives)"""
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            return bool(flag.item())
 
-        form = "tiles" if args.exchange in ("rccl", "host-tiles") else "allgather"
-        system = sharded.ShardedBodySystem(pos_t, vel_t, launch, ordered=(mode == pkg.NB_MODE_STRICT), gather=host_gather, exchange=form)
-        step = system.update
-        finish = system.finish
-        if world > 1:
-            # bring RCCL's all-gather path up (communicator, channels, first-call setup) outside any timed step, whatever
-            # --warmup says; every rank holds identical positions at this point, so gathering them is a no-op on the data
+        if args.exchange == "rccl":
+            bufs = [pos_t, pos_t.clone()]
+            acc_t = torch.zeros_like(pos_t)
+            problem = None
             try:
-                system.exchange_once(system.pos[0])
-            except RuntimeError as exc:  # the tile form could not be brought up: say so and use the single collective
-                if system.exchange != "tiles":
-                    raise
-                print(f"[bench rank {rank}] tile exchange failed at bring-up ({exc!r}); falling back to one all-gather per step", file=sys.stderr, flush=True)
-                system = sharded.ShardedBodySystem(pos_t, vel_t, launch, ordered=(mode == pkg.NB_MODE_STRICT), exchange="allgather")
-                step, finish = system.update, system.finish
-                system.exchange_once(system.pos[0])
-            torch.cuda.synchronize()
+                ids = [pkg.comm_unique_id() if (rank == 0 and world > 1) else None]
+            except pkg.NBodyHipError as exc:
+                ids, problem = [None], exc
+            dist.broadcast_object_list(ids, src=0)
+            if world > 1 and ids[0] is None:
+                problem = problem or RuntimeError("rank 0 could not create the RCCL unique id")
+            else:
+                try:
+                    capi_rank = pkg.ShardedRank(ids[0], world, rank, [b.data_ptr() for b in bufs], vel_t.data_ptr(), acc_t.data_ptr(), n, dtype, mode, 256,
+                                                ctypes.c_void_p(stream.cuda_stream))
+                    # bring the communicator up (channels, first-call set-up) outside any timed step, whatever --warmup says;
+                    # every rank holds identical positions at this point, so exchanging them changes nothing
+                    capi_rank.exchange_once(0)
+                    torch.cuda.synchronize()
+                except pkg.NBodyHipError as exc:
+                    problem = exc
+            if not everyone(problem is None):
+                print(f"[bench rank {rank}] the C-ABI RCCL path could not be brought up ({problem!r} on this rank); "
+                      "ALL ranks fall back to the tile schedule over torch.distributed", file=sys.stderr, flush=True)
+                if capi_rank is not None:
+                    capi_rank.destroy()
+                capi_rank, exchange_fallback = None, True
+                args.exchange = "torch"
+                rccl_group = torch_rccl_group()
+
+        if capi_rank is not None:
+            def step():
+                kernel_launches[0] += world  # one kernel per position tile
+                capi_rank.update(dt, damping)
+
+            finish = capi_rank.finish
+        else:
+            host_gather = None
+            if args.exchange in ("host", "staged"):
+                class _Done:
+                    def wait(self):
+                        pass
+
+                def host_gather(full, own):
+                    staged = torch.empty(full.shape, dtype=full.dtype)
+                    dist.all_gather_into_tensor(staged, own.cpu())
+                    full.copy_(staged)
+                    return _Done()
+
+            form = "tiles" if args.exchange in ("torch", "host-tiles") else "allgather"
+            system = sharded.ShardedBodySystem(pos_t, vel_t, launch, ordered=(mode == pkg.NB_MODE_STRICT), group=rccl_group, gather=host_gather, exchange=form)
+            step = system.update
+            finish = system.finish
+            if world > 1:
+                # bring the exchange up outside any timed step; if the tile form fails on ANY rank, ALL ranks take the single collective
+                problem = None
+                try:
+                    system.exchange_once(system.pos[0])
+                    torch.cuda.synchronize()
+                except RuntimeError as exc:
+                    problem = exc
+                if not everyone(problem is None):
+                    if system.exchange != "tiles":
+                        raise problem or RuntimeError("another rank failed to bring the exchange up")
+                    print(f"[bench rank {rank}] tile exchange failed at bring-up ({problem!r} on this rank); ALL ranks fall back to one all-gather per step",
+                          file=sys.stderr, flush=True)
+                    exchange_fallback = True
+                    system = sharded.ShardedBodySystem(pos_t, vel_t, launch, ordered=(mode == pkg.NB_MODE_STRICT), group=rccl_group, exchange="allgather")
+                    step, finish = system.update, system.finish
+                    system.exchange_once(system.pos[0])
+                    torch.cuda.synchronize()
     else:
         bufs = [pos_t, pos_t.clone()]
         acc_t = torch.zeros_like(pos_t)
@@ -289,7 +402,7 @@ def main():
         finish()
         torch.cuda.synchronize()
         if distributed:
-            dist.barrier()
+            dist.barrier()  # gloo: a host barrier between two device synchronisations
             torch.cuda.synchronize()
 
     if args.emulate_gpus > 1 and world == 1 and args.sweep:
@@ -413,7 +526,7 @@ def main():
     launches = kernel_launches[0] - launches_before
 
     if distributed:
-        t = torch.tensor([elapsed], device="cpu" if over_gloo else dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], dtype=torch.float64)  # gloo
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -455,6 +568,9 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
             "scaling": "strong",
+            # true when this line was NOT produced by the exchange asked for (the launcher's retries, or a collective in-rank
+            # fallback at bring-up): such a value must not pass for a number of the C-ABI RCCL path
+            "exchange_fallback": bool(exchange_fallback),
             "vs_baseline": None,
             "dtype": "f64" if args.fp64 else "f32",
             "data": "synthetic",
@@ -466,10 +582,13 @@ def main():
                 "exchange": "none" if world == 1 else (
                     "REHEARSAL: gloo, host-staged gather, ranks share one GPU" if args.exchange == "host" else
                     "FALLBACK (no RCCL): gloo all-gather of the slices through host memory, one GPU per rank" if args.exchange == "staged" else
-                    "REHEARSAL: gloo send/recv rounds (tile schedule) on device tensors, ranks share one GPU" if args.exchange == "host-tiles" else
-                    "RCCL all-gather of the new positions per step, issued as G-1 position tiles (grouped send/recv rounds on RCCL's stream); "
-                    "the kernel of tile k waits only on round k, the own-slice chunk runs first" if system.exchange == "tiles" else
-                    "RCCL all_gather_into_tensor of the new positions per step, overlapped with the own-slice j chunk"),
+                    "REHEARSAL: gloo send/recv rounds (tile schedule) staged through host memory, ranks share one GPU" if args.exchange == "host-tiles" else
+                    "C-ABI (nb_comm_init_rank + nb_sharded_step_*, csrc/nbody_comm.hip): RCCL all-gather of the new positions per step, issued as "
+                    "G-1 position tiles (grouped ncclSend/ncclRecv rounds on the communicator's high-priority stream); the kernel of tile k waits "
+                    "only on round k, the own-slice chunk runs first" if capi_rank is not None else
+                    "torch.distributed re-implementation (sharded.py) of the tile schedule: batch_isend_irecv rounds on RCCL's stream" if system.exchange == "tiles" else
+                    "torch.distributed (sharded.py): RCCL all_gather_into_tensor of the new positions per step, overlapped with the own-slice j chunk"),
+                "step_entry_point": "nb_integrate_shard_*" if not distributed else ("nb_sharded_step_*" if capi_rank is not None else "sharded.py -> nb_integrate_shard_*"),
                 "kernel_plan": plan_now,
                 "device": info.name.decode(),
                 "arch": info.arch.decode(),
@@ -522,7 +641,20 @@ def main():
                           f"1 thread is how the reference ships (OpenMP never enabled)",
                 "openmp": base["openmp"],
             }
+        if world == 1 and not args.no_configs and not args.plan:
+            # The other BASELINE configs and the parity-exact mode, timed AFTER the headline measurement (never inside it)
+            # so that one driver-run line carries them all.  A failure here costs only this list, never the headline.
+            try:
+                line["configs"] = other_configs(pkg, lib, (n, args.fp64, args.mode))
+            except Exception as exc:  # noqa: BLE001
+                line["configs"] = [{"error": repr(exc)}]
         print(json.dumps(line), flush=True)
+        if args.dump_state:
+            torch.cuda.synchronize()
+            final = capi_rank.pos[capi_rank.read] if capi_rank is not None else (system.positions().data_ptr() if system is not None else bufs[state["read"]].data_ptr())
+            host = np.zeros(4 * n, dtype)
+            pkg.check(lib.nb_d2h(host.ctypes.data_as(ctypes.c_void_p), final, host.nbytes, None), "nb_d2h")
+            np.save(args.dump_state, host)
 
     # Diagnostics for N > 1: the exchange alone and the kernels of one step alone (exposed exchange = step - kernels).
     # Taken after the timed region, never part of `value`, and printed to STDERR after the JSON line is already out,
@@ -530,27 +662,34 @@ def main():
     diagnostics = None
     if world > 1:
         try:
-            full = system.positions()
-            own = full[system.i0:system.i0 + system.ni]
             fence()
             t1 = time.perf_counter()
             for _ in range(10):
-                system.exchange_once(full)
+                if capi_rank is not None:
+                    capi_rank.exchange_once()
+                else:
+                    system.exchange_once(system.positions())
             torch.cuda.synchronize()
             exchange_ms = (time.perf_counter() - t1) / 10 * 1e3
             fence()
+            if capi_rank is not None:
+                cur, nxt, d_vel, d_acc = bufs[capi_rank.read], bufs[1 - capi_rank.read], vel_t, acc_t
+                i0, ni = sharded.slice_of(rank, world, n)
+                schedule = sharded.tile_schedule(rank, world, n, mode == pkg.NB_MODE_STRICT)
+            else:
+                cur, nxt, d_vel, d_acc = system.pos[system.read], system.pos[1 - system.read], system.vel, system.acc
+                i0, ni, schedule = system.i0, system.ni, system.schedule
             e0, e1 = pkg.Event(), pkg.Event()
             e0.record(ctypes.c_void_p(stream.cuda_stream))
             reps = max(2, min(args.steps, 10))
             for _ in range(reps):
-                cur, nxt = system.pos[system.read], system.pos[1 - system.read]
-                for k, (j0, nj, _) in enumerate(system.schedule):
-                    flags = (pkg.NB_SHARD_ACC_IN if k else 0) | (pkg.NB_SHARD_FINALIZE if k == len(system.schedule) - 1 else 0)
-                    launch(nxt, cur, system.vel, system.acc, system.i0, system.ni, j0, nj, flags)
+                for k, (j0, nj, _) in enumerate(schedule):
+                    flags = (pkg.NB_SHARD_ACC_IN if k else 0) | (pkg.NB_SHARD_FINALIZE if k == len(schedule) - 1 else 0)
+                    launch(nxt, cur, d_vel, d_acc, i0, ni, j0, nj, flags)
             e1.record(ctypes.c_void_p(stream.cuda_stream))
             e1.synchronize()
             diagnostics = {"exchange_alone_ms": exchange_ms, "kernels_alone_ms_per_step_rank0": e0.elapsed_ms(e1) / reps,
-                           "launches_per_step_rank0": len(system.schedule)}
+                           "launches_per_step_rank0": len(schedule)}
             fence()
         except Exception as exc:  # diagnostics must never cost the headline line
             diagnostics = {"error": repr(exc)}
@@ -558,6 +697,9 @@ def main():
     if diagnostics is not None and rank == 0:
         print("diagnostics: " + json.dumps(diagnostics), file=sys.stderr, flush=True)
 
+    if capi_rank is not None:
+        torch.cuda.synchronize()
+        capi_rank.destroy()
     if distributed:
         dist.destroy_process_group()
 

@@ -356,3 +356,58 @@ class Event:
                 lib().nb_event_destroy(self.h)
         except Exception:
             pass
+
+
+class ShardedRank:
+    """One rank of the body-sharded system THROUGH THE C-ABI: nb_comm_init_rank + nb_sharded_step_* (csrc/nbody_comm.hip),
+    i.e. the product's own multi-GPU path -- RCCL send/recv rounds of position tiles on the communicator's side stream,
+    the kernel of tile k waiting on round k.  One process (or thread) per GPU; `unique_id` is rank 0's
+    ``comm_unique_id()`` shipped to the other ranks by any means (bench.py: the torch.distributed store over gloo).
+
+    The caller owns the arrays, exactly as with nb_integrate_*: `positions` = the two full-size ping-pong arrays (device
+    addresses), `velocities`, `acc` (partial accelerations), all 4N T.  Python mirror of host/bodysystemhip_sharded.cpp's
+    use of the same entry points (that class drives all local devices from one thread through the *_all form)."""
+
+    def __init__(self, unique_id, world: int, rank: int, positions, velocities, acc, num_bodies: int, dtype=np.float32,
+                 mode: int = NB_MODE_FAST, block_size: int = 256, stream=None):
+        self.dtype = np.dtype(dtype)
+        self.world, self.rank, self.n = int(world), int(rank), int(num_bodies)
+        if self.n % self.world:
+            raise ValueError(f"{self.n} bodies do not shard evenly over {self.world} ranks; pad with zero-mass bodies")
+        self.pos, self.vel, self.acc = [int(positions[0]), int(positions[1])], int(velocities), int(acc)
+        self.mode, self.block_size, self.stream = mode, block_size, stream
+        self.read = 0
+        self.comm = _vp()
+        check(lib().nb_comm_init_rank(ctypes.byref(self.comm), unique_id, self.world, self.rank), "nb_comm_init_rank")
+        f32 = self.dtype == np.float32
+        self._step = lib().nb_sharded_step_f32 if f32 else lib().nb_sharded_step_f64
+        self._tiles = lib().nb_exchange_tiles_f32 if f32 else lib().nb_exchange_tiles_f64
+        self._scalar = np.float32 if f32 else float
+
+    def update(self, delta_time, damping) -> None:
+        """pos[1-read][own slice], vel[own slice] <- one step from pos[read]; then the tiles of pos[1-read] start moving."""
+        check(self._step(self.comm, self.pos[1 - self.read], self.pos[self.read], self.vel, self.acc, self.n, self._scalar(delta_time),
+                         self._scalar(damping), self.block_size, self.mode, self.stream), "nb_sharded_step")
+        self.read = 1 - self.read
+
+    def exchange_once(self, which: int | None = None) -> None:
+        """One exchange of a position array outside any step (bring-up / diagnostics); the stream waits for all its tiles."""
+        array = self.pos[self.read if which is None else which]
+        check(self._tiles(self.comm, array, self.n, self.stream), "nb_exchange_tiles")
+        self.finish()
+
+    def finish(self) -> None:
+        """Make the compute stream wait for every tile still in flight (asynchronous; synchronise the stream to block)."""
+        check(lib().nb_exchange_wait_all(self.comm, self.stream), "nb_exchange_wait_all")
+
+    def destroy(self) -> None:
+        if self.comm:
+            lib().nb_comm_destroy(self.comm)
+            self.comm = _vp()
+
+
+def comm_unique_id() -> bytes:
+    """nb_comm_unique_id: the 128 bytes rank 0 hands to every other rank."""
+    buf = ctypes.create_string_buffer(128)
+    check(lib().nb_comm_unique_id(buf), "nb_comm_unique_id")
+    return buf.raw

@@ -149,6 +149,21 @@ void free_resources(Comm* c) {
     if (c->stream) (void)hipStreamDestroy(c->stream);
 }
 
+// `locals` is a permutation of the local ranks of one communicator (and nothing else)
+bool same_group(const std::vector<Comm*>& locals) {
+    const std::vector<Comm*>& group = locals.front()->group;
+    if (locals.size() != group.size()) return false;
+    for (size_t k = 0; k < locals.size(); ++k) {
+        if (locals[k]->world != locals.front()->world) return false;
+        bool member = false;
+        for (Comm* g : group) member = member || g == locals[k];
+        if (!member) return false;
+        for (size_t m = 0; m < k; ++m)
+            if (locals[m] == locals[k]) return false;
+    }
+    return true;
+}
+
 // The G-1 rounds for every local rank of a communicator.  `bytes_per_body` = 4 * sizeof(T).
 int exchange_tiles(const std::vector<Comm*>& locals, void* const* positions, unsigned num_bodies, size_t bytes_per_body, int nccl_type, const hipStream_t* after) {
     Rccl* lib = rccl();
@@ -210,6 +225,9 @@ int sharded_step(nb_comm_t const* comms, int n_local, T* const* new_pos, const T
         locals[static_cast<size_t>(k)] = as_comm(comms[k]);
         if (locals[static_cast<size_t>(k)] == nullptr) return NB_ERR_INVALID_ARGUMENT;
     }
+    // The comms must be exactly the local ranks of ONE communicator (any order): a round is one RCCL group over all of
+    // them, and a group that misses a peer hangs inside RCCL instead of failing.
+    if (!same_group(locals)) return NB_ERR_INVALID_ARGUMENT;
     const int G = locals.front()->world;
     if (num_bodies == 0 || num_bodies % static_cast<unsigned>(G)) return NB_ERR_INVALID_ARGUMENT;  // pad with zero-mass bodies (as tipsy.cpp:111-119 does)
     const unsigned ni = num_bodies / static_cast<unsigned>(G);
@@ -255,10 +273,10 @@ int nb_comm_unique_id(void* id) {
 
 int nb_comm_init_rank(nb_comm_t* comm, const void* id, int world, int rank) {
     NB_KEEP_RAND_STREAM;
-    if (!comm || !id || world < 1 || rank < 0 || rank >= world) return NB_ERR_INVALID_ARGUMENT;
+    if (!comm || (!id && world > 1) || world < 1 || rank < 0 || rank >= world) return NB_ERR_INVALID_ARGUMENT;
     *comm     = nullptr;
-    Rccl* lib = rccl();
-    if (lib == nullptr) return NB_ERR_UNSUPPORTED;
+    Rccl* lib = world > 1 ? rccl() : nullptr;  // a world of one never exchanges anything: no RCCL needed, none loaded
+    if (world > 1 && lib == nullptr) return NB_ERR_UNSUPPORTED;
     auto* c  = new Comm;
     c->rank  = rank;
     c->world = world;
@@ -266,9 +284,12 @@ int nb_comm_init_rank(nb_comm_t* comm, const void* id, int world, int rank) {
         delete c;
         return static_cast<int>(err);
     }
-    ncclUniqueId uid;
-    std::memcpy(uid.internal, id, sizeof(uid.internal));
-    int rc = nccl_status(lib->CommInitRank(&c->nccl, world, uid, rank));
+    int rc = 0;
+    if (world > 1) {
+        ncclUniqueId uid;
+        std::memcpy(uid.internal, id, sizeof(uid.internal));
+        rc = nccl_status(lib->CommInitRank(&c->nccl, world, uid, rank));
+    }
     if (rc == 0) rc = make_resources(c);
     if (rc != 0) {
         if (c->nccl) (void)lib->CommDestroy(c->nccl);
@@ -284,12 +305,16 @@ int nb_comm_init_rank(nb_comm_t* comm, const void* id, int world, int rank) {
 int nb_comm_init_all(nb_comm_t* comms, int num_devices, const int* devices) {
     NB_KEEP_RAND_STREAM;
     if (!comms || num_devices < 1) return NB_ERR_INVALID_ARGUMENT;
-    Rccl* lib = rccl();
-    if (lib == nullptr) return NB_ERR_UNSUPPORTED;
+    Rccl* lib = num_devices > 1 ? rccl() : nullptr;  // one device: nothing to exchange, RCCL stays unloaded
+    if (num_devices > 1 && lib == nullptr) return NB_ERR_UNSUPPORTED;
     std::vector<int> devs(static_cast<size_t>(num_devices));
     for (int k = 0; k < num_devices; ++k) devs[static_cast<size_t>(k)] = devices ? devices[k] : k;
+    int visible = 0;
+    if (const auto err = hipGetDeviceCount(&visible); err != hipSuccess) return static_cast<int>(err);
+    for (int d : devs)
+        if (d < 0 || d >= visible) return NB_ERR_INVALID_ARGUMENT;
     std::vector<ncclComm_t> raw(static_cast<size_t>(num_devices), nullptr);
-    int                     rc = nccl_status(lib->CommInitAll(raw.data(), num_devices, devs.data()));
+    int                     rc = lib != nullptr ? nccl_status(lib->CommInitAll(raw.data(), num_devices, devs.data())) : 0;
     if (rc != 0) return rc;
     std::vector<Comm*> made;
     for (int k = 0; k < num_devices && rc == 0; ++k) {
@@ -302,7 +327,8 @@ int nb_comm_init_all(nb_comm_t* comms, int num_devices, const int* devices) {
         rc = make_resources(c);
     }
     if (rc != 0) {
-        for (size_t k = 0; k < raw.size(); ++k) (void)lib->CommDestroy(raw[k]);
+        for (size_t k = 0; k < raw.size(); ++k)
+            if (lib != nullptr && raw[k] != nullptr) (void)lib->CommDestroy(raw[k]);
         for (Comm* c : made) {
             free_resources(c);
             delete c;
@@ -318,12 +344,12 @@ int nb_comm_destroy(nb_comm_t comm) {
     NB_KEEP_RAND_STREAM;
     Comm* c = as_comm(comm);
     if (c == nullptr) return NB_ERR_INVALID_ARGUMENT;
-    Rccl* lib = rccl();
     {
         DeviceScope scope(c->device);
         (void)hipStreamSynchronize(c->stream);
     }
-    if (lib != nullptr && c->nccl != nullptr) (void)lib->CommDestroy(c->nccl);
+    if (c->nccl != nullptr)
+        if (Rccl* lib = rccl(); lib != nullptr) (void)lib->CommDestroy(c->nccl);
     free_resources(c);
     delete c;
     return 0;
@@ -372,10 +398,10 @@ int nb_exchange_wait_all(nb_comm_t comm, nb_stream_t stream) {
 static int allgather_one(nb_comm_t comm, void* positions, unsigned num_bodies, size_t bytes_per_body, int type, nb_stream_t after) {
     NB_KEEP_RAND_STREAM;
     Comm* c = as_comm(comm);
-    Rccl* lib = rccl();
-    if (lib == nullptr) return NB_ERR_UNSUPPORTED;
     if (c == nullptr || positions == nullptr || c->group.size() != 1 || num_bodies % static_cast<unsigned>(c->world)) return NB_ERR_INVALID_ARGUMENT;
     if (c->world == 1) return 0;
+    Rccl* lib = rccl();
+    if (lib == nullptr) return NB_ERR_UNSUPPORTED;
     DeviceScope  scope(c->device);
     const size_t slice = num_bodies / static_cast<unsigned>(c->world);
     auto         err   = hipEventRecord(c->ready, reinterpret_cast<hipStream_t>(after));

@@ -17,17 +17,18 @@ def run_bench(*flags, timeout=600):
     return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *flags], capture_output=True, text=True, env=env, timeout=timeout)
 
 
-def test_launcher_falls_back_twice_and_reports_failure():
-    """No GPU here: every attempt must fail; the second one must be the all-gather form, the third the RCCL-free one, and the
-    status must say so."""
+def test_launcher_falls_back_and_reports_failure():
+    """No GPU here: every attempt must fail; the retries must be, in this order, the tile schedule over torch.distributed, the
+    all-gather form and the RCCL-free one, and the status must say so."""
     import torch
 
     if torch.cuda.is_available():
         pytest.skip("needs a host without a GPU: on a GPU box the first attempt would go on to RCCL")
     out = run_bench("--gpus", "2", "--steps", "1", "--warmup", "0", "--bodies", "1024", "--no-cpu-baseline", "--launch-timeout", "240")
     assert out.returncode != 0
-    assert out.stderr.count("one more attempt with --exchange allgather") == 1, out.stderr[-2000:]
-    assert out.stderr.count("one more attempt with --exchange staged") == 1, out.stderr[-2000:]
+    order = [out.stderr.find(f"one more attempt with --exchange {name}") for name in ("torch", "allgather", "staged")]
+    assert all(at >= 0 for at in order) and order == sorted(order), out.stderr[-2000:]
+    assert out.stderr.count("one more attempt with --exchange") == 3
     assert '"metric"' not in out.stdout
 
 
@@ -52,3 +53,53 @@ def test_plain_shell_bench_starts_two_ranks_on_one_gpu():
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["steps"] == 3 and line["value"] > 0
     assert "REHEARSAL" in line["config"]["exchange"]
+
+
+def _metric_line(stdout):
+    lines = [l for l in stdout.splitlines() if l.startswith("{") and '"metric"' in l]
+    assert len(lines) == 1, stdout[-2000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_one_rank_under_torchrun_runs_the_capi_sharded_step_and_matches_the_plain_run(tmp_path):
+    """What the driver's scaling series does for N=1: `torch.distributed.run --nproc-per-node 1 bench.py --gpus 1`.  The step must be
+    the product's nb_sharded_step_* (communicator of one rank), no fallback, and the final positions must be the same bytes as
+    those of the plain `python bench.py` run (nb_integrate_shard_* directly)."""
+    import socket
+
+    import numpy as np
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    common = ["--gpus", "1", "--steps", "6", "--warmup", "2", "--bodies", "16384", "--no-cpu-baseline", "--no-configs"]
+    env = dict(os.environ)
+    for name in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(name, None)
+    a, b = tmp_path / "torchrun.npy", tmp_path / "plain.npy"
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                          os.path.join(ROOT, "bench.py"), *common, "--dump-state", str(a)], capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = _metric_line(out.stdout)
+    assert line["config"]["step_entry_point"] == "nb_sharded_step_*" and line["exchange_fallback"] is False and line["n_gpus"] == 1
+    plain = run_bench(*common, "--dump-state", str(b))
+    assert plain.returncode == 0, plain.stderr[-3000:]
+    pl = _metric_line(plain.stdout)
+    assert pl["config"]["step_entry_point"] == "nb_integrate_shard_*" and pl["exchange_fallback"] is False
+    assert np.load(a).tobytes() == np.load(b).tobytes()
+
+
+@pytest.mark.gpu
+def test_default_line_carries_every_baseline_config():
+    """`python bench.py` (what the driver runs): the one JSON line holds the headline AND, timed after it, the other BASELINE
+    configs and STRICT."""
+    out = run_bench("--steps", "5", "--warmup", "1", "--no-cpu-baseline")
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = _metric_line(out.stdout)
+    got = {(c["bodies"], c["dtype"], c["mode"]) for c in line["configs"]}
+    assert {(65536, "f32", "fast"), (262144, "f64", "fast"), (1048576, "f32", "fast"), (262144, "f32", "strict"), (262144, "f64", "strict"),
+            (1024, "f32", "fast"), (1024, "f32", "strict")} <= got
+    assert (262144, "f32", "fast") not in got  # that one IS the headline
+    for c in line["configs"]:
+        assert c["ms_per_step"] > 0 and 0 < c["frac"] < 1
