@@ -125,6 +125,7 @@ SIGNATURES = {
     "nb_plan_f32": (_ci, [_cu, _cu, _P(LaunchPlan)]),
     "nb_plan_f64": (_ci, [_cu, _cu, _P(LaunchPlan)]),
     "nb_set_plan_override": (_ci, [_ci, _ci, _ci]),
+    "nb_lds_optin_count": (_ci, [_P(_ci)]),
 }
 
 _lib = None

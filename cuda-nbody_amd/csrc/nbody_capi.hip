@@ -120,11 +120,16 @@ template <typename T> int graph_create(nb_graph_t* out, T* pos_a, T* pos_b, T* v
     NB_KEEP_RAND_STREAM;
     *out = nullptr;
     (void)current_device_ready();  // the one-time device warm-up allocates and copies: never inside a capture
-    if (mode == NB_MODE_FAST) {  // arm the >64 KiB dynamic-LDS attribute outside the capture
+    {  // arm the >64 KiB dynamic-LDS attribute outside the capture
         nb::Shard<T> probe{};
         probe.i_count = n, probe.j_count = n;
-        const nb::Plan p   = nb::plan_fast<T>(n, n, cu_count_cached(), g_ovr_i.load(), g_ovr_s.load(), g_ovr_tile.load());
-        const auto     err = nb::launch_fast<T>(probe, p, nullptr, /*prepare_only=*/true);
+        hipError_t err = hipSuccess;
+        if (mode == NB_MODE_FAST) {
+            const nb::Plan p = nb::plan_fast<T>(n, n, cu_count_cached(), g_ovr_i.load(), g_ovr_s.load(), g_ovr_tile.load());
+            err              = nb::launch_fast<T>(probe, p, nullptr, /*prepare_only=*/true);
+        } else if (mode == NB_MODE_STRICT) {
+            err = nb::launch_strict<T>(probe, block_size, cu_count_cached(), nullptr, /*prepare_only=*/true);
+        }
         if (err != hipSuccess) return static_cast<int>(err);
     }
     hipStream_t capture = nullptr;
@@ -368,6 +373,12 @@ int nb_graph_destroy(nb_graph_t graph) {
 
 int nb_plan_f32(unsigned i_count, unsigned j_count, nb_launch_plan_t* plan) { return plan_query<float>(i_count, j_count, plan); }
 int nb_plan_f64(unsigned i_count, unsigned j_count, nb_launch_plan_t* plan) { return plan_query<double>(i_count, j_count, plan); }
+
+int nb_lds_optin_count(int* count) {
+    if (count == nullptr) return NB_ERR_INVALID_ARGUMENT;
+    *count = nb::lds_optins.load();
+    return 0;
+}
 
 int nb_set_plan_override(int bodies_per_lane, int lanes_per_body, int tile_bodies) {
     auto ok = [](int v, std::initializer_list<int> allowed) {

@@ -658,6 +658,9 @@ template <typename T, int R, int LPT, int BLOCK> __global__ __launch_bounds__(BL
 }
 
 template <typename T, int R, int LPT, int BLOCK> hipError_t launch_wavesplit(const Shard<T>& s, const Plan& p, hipStream_t stream, bool prepare_only) {
+    if (p.lds_bytes > 64u * 1024u) {
+        if (const auto err = allow_large_lds<&integrate_bodies_wavesplit<T, R, LPT, BLOCK>>(); err != hipSuccess) return err;
+    }
     if (prepare_only) return hipSuccess;
     hipLaunchKernelGGL((integrate_bodies_wavesplit<T, R, LPT, BLOCK>), dim3(p.grid_blocks), dim3(BLOCK), p.lds_bytes, stream, s);
     return hipGetLastError();
@@ -674,21 +677,9 @@ template <typename T, int R> hipError_t dispatch_wavesplit(const Shard<T>& s, co
     }
 }
 
-// Dynamic LDS above 64 KiB needs an opt-in per kernel AND per device (gfx950 has 160 KiB per CU); one bit per device.
-template <typename Kernel> hipError_t allow_large_lds(Kernel kernel) {
-    static std::atomic<unsigned long long> armed{0};
-    int device = 0;
-    if (const auto err = hipGetDevice(&device); err != hipSuccess) return err;
-    const unsigned long long bit = 1ull << (device & 63);
-    if (armed.load(std::memory_order_acquire) & bit) return hipSuccess;
-    const auto err = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (err == hipSuccess) armed.fetch_or(bit, std::memory_order_release);
-    return err;
-}
-
 template <typename T, int R, int S, int LPT> hipError_t launch_one(const Shard<T>& s, const Plan& p, hipStream_t stream, bool prepare_only) {
     if (p.lds_bytes > 64u * 1024u) {
-        if (const auto err = allow_large_lds(&integrate_bodies_fast<T, R, S, LPT>); err != hipSuccess) return err;
+        if (const auto err = allow_large_lds<&integrate_bodies_fast<T, R, S, LPT>>(); err != hipSuccess) return err;
     }
     if (prepare_only) return hipSuccess;  // graph capture arms the attribute before hipStreamBeginCapture
     hipLaunchKernelGGL((integrate_bodies_fast<T, R, S, LPT>), dim3(p.grid_blocks), dim3(block_threads_for(S)), p.lds_bytes, stream, s);

@@ -5,7 +5,25 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+
 namespace nb {
+
+// Dynamic LDS above 64 KiB needs an opt-in per KERNEL and per DEVICE (gfx950 has 160 KiB per CU).  The state is keyed on the
+// kernel itself -- it is a non-type template parameter, so every instantiation of a kernel template owns its own bit mask
+// (round 2 keyed it on the kernel's pointer TYPE, which all integrate_bodies_fast<T,...> of one precision share: once one
+// was armed the others skipped the call).  `lds_optins` counts the (kernel, device) pairs armed so far (nb_lds_optin_count).
+inline std::atomic<int> lds_optins{0};
+template <auto Kernel> hipError_t allow_large_lds() {
+    static std::atomic<unsigned long long> armed{0};  // one bit per device
+    int device = 0;
+    if (const auto err = hipGetDevice(&device); err != hipSuccess) return err;
+    const unsigned long long bit = 1ull << (device & 63);
+    if (armed.load(std::memory_order_acquire) & bit) return hipSuccess;
+    const auto err = hipFuncSetAttribute(reinterpret_cast<const void*>(Kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (err == hipSuccess && !(armed.fetch_or(bit, std::memory_order_acq_rel) & bit)) lds_optins.fetch_add(1, std::memory_order_relaxed);
+    return err;
+}
 
 template <typename T> struct Shard {
     T*       new_pos;  // vec4[N], written for i in the shard when finalize
@@ -30,6 +48,6 @@ struct Plan {
 
 template <typename T> Plan       plan_fast(unsigned i_count, unsigned j_count, int cu_count, int ovr_i, int ovr_s, int ovr_tile);
 template <typename T> hipError_t launch_fast(const Shard<T>& s, const Plan& p, hipStream_t stream, bool prepare_only = false);
-template <typename T> hipError_t launch_strict(const Shard<T>& s, int block_size, int cu_count, hipStream_t stream);
+template <typename T> hipError_t launch_strict(const Shard<T>& s, int block_size, int cu_count, hipStream_t stream, bool prepare_only = false);
 
 }  // namespace nb

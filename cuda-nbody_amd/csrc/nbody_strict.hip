@@ -402,17 +402,21 @@ template <typename T> __global__ __launch_bounds__(512, 4) void integrate_bodies
 // otherwise a hint).  512-thread workgroups (two waves per SIMD each, kept level by the priority scheme; two of them
 // share a CU) while that still gives every CU at least one; smaller workgroups for smaller shards so that the bodies
 // spread over all CUs.
-template <typename T> hipError_t launch_strict(const Shard<T>& s, int block_size, int cu_count, hipStream_t stream) {
+template <typename T> hipError_t launch_strict(const Shard<T>& s, int block_size, int cu_count, hipStream_t stream, bool prepare_only) {
     (void)block_size;
     unsigned p = 512;
     while (p > 64 && (s.i_count + p - 1) / p < static_cast<unsigned>(cu_count)) p /= 2;
     const unsigned blocks = (s.i_count + p - 1) / p;
     const size_t   smem   = static_cast<size_t>(p / 64) * 2 * kChunk * 4 * sizeof(T) + 256;  // the waves' rings + progress words
+    if (smem > 64u * 1024u) {  // fp64 at p = 512: 65 792 B
+        if (const auto err = allow_large_lds<&integrate_bodies_strict<T>>(); err != hipSuccess) return err;
+    }
+    if (prepare_only) return hipSuccess;  // graph capture arms the attribute before hipStreamBeginCapture
     hipLaunchKernelGGL(integrate_bodies_strict<T>, dim3(blocks), dim3(p), smem, stream, s);
     return hipGetLastError();
 }
 
-template hipError_t launch_strict<float>(const Shard<float>&, int, int, hipStream_t);
-template hipError_t launch_strict<double>(const Shard<double>&, int, int, hipStream_t);
+template hipError_t launch_strict<float>(const Shard<float>&, int, int, hipStream_t, bool);
+template hipError_t launch_strict<double>(const Shard<double>&, int, int, hipStream_t, bool);
 
 }  // namespace nb

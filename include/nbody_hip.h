@@ -214,6 +214,10 @@ NB_API int nb_plan_f64(unsigned i_count, unsigned j_count, nb_launch_plan_t* pla
 /* Override the automatic plan (0 = automatic) -- used by the tuning sweep in bench.py --sweep. */
 NB_API int nb_set_plan_override(int bodies_per_lane, int lanes_per_body, int tile_bodies);
 
+/* How many (kernel, device) pairs have been granted more than 64 KiB of dynamic LDS so far (the opt-in is made once per
+ * kernel instantiation and device, on first use, and before any graph capture) -- tests. */
+NB_API int nb_lds_optin_count(int* count);
+
 NB_API const char* nb_version(void);
 
 #ifdef __cplusplus

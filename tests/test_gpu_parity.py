@@ -19,6 +19,7 @@ from conftest import golden_steps, load_golden, xyz
 
 pytestmark = pytest.mark.gpu
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DT = np.float32(0.016)
 
 
@@ -100,8 +101,28 @@ def test_fast_fp32_vs_golden(gpu, n):
     assert errs[1].max() <= 2e-6, errs[1].max()
     assert errs[10].max() <= 2e-5, errs[10].max()
     if 100 in errs:
-        assert np.median(errs[100]) <= 1e-4, np.median(errs[100])  # the north_star figure, on the median (chaos)
-        assert np.percentile(errs[100], 99) <= 5e-3, np.percentile(errs[100], 99)  # measured 8.5e-4 (N = 1024), 2.6e-5 (N = 256)
+        # the measured envelope: N = 1024: max 1.8e-3, p99 8.5e-4, median 2.4e-5; N = 256: 4.7e-5 / 2.6e-5 / 1.7e-7
+        assert np.median(errs[100]) <= 5e-5, np.median(errs[100])  # the north_star figure is 1e-4: met on the median
+        assert np.percentile(errs[100], 99) <= 2e-3, np.percentile(errs[100], 99)
+        assert errs[100].max() <= 1e-2, errs[100].max()  # bodies that went through a close encounter (chaos, see below)
+
+
+@pytest.mark.parametrize("n", [256, 1024])
+def test_fast_is_as_close_to_the_fp64_trajectory_as_the_cpu_fp32_path(gpu, oracle, n):
+    """Which of the two fp32 trajectories is 'right' after 100 steps?  Neither: both are roundings of a chaotic system.  The
+    yardstick is the fp64 CPU path started from the SAME fp32 bodies.  FAST (v_rsq + FMA, two-level sums) must be at least as
+    close to it as the reference's own fp32 CPU arithmetic (the golden trajectory) is -- median, 99th percentile and max."""
+    g = load_golden(n, "f32")
+    truth_p, truth_v = g["pos_0"].astype(np.float64), g["vel_0"].astype(np.float64)
+    oracle.update(truth_p, truth_v, np.float64(DT), steps=100)
+    fast, _ = run_gpu(gpu, g["pos_0"], g["vel_0"], 100, gpu.NB_MODE_FAST)
+    e_fast = rel_err(fast.astype(np.float64), truth_p)
+    e_cpu = rel_err(g["pos_100"].astype(np.float64), truth_p)
+    print(f"N={n}, 100 steps, rel. error against the fp64 trajectory  FAST: max {e_fast.max():.2e} p99 {np.percentile(e_fast, 99):.2e} median {np.median(e_fast):.2e}"
+          f"   CPU fp32 path: max {e_cpu.max():.2e} p99 {np.percentile(e_cpu, 99):.2e} median {np.median(e_cpu):.2e}")
+    assert np.median(e_fast) <= 1.5 * np.median(e_cpu)
+    assert np.percentile(e_fast, 99) <= 3 * np.percentile(e_cpu, 99)
+    assert e_fast.max() <= 5 * e_cpu.max()
 
 
 @pytest.mark.parametrize("n", [8, 256, 1024, 4096])
@@ -719,3 +740,43 @@ def test_fast_conserves_what_the_cpu_path_conserves(gpu, oracle):
     de_fast = abs(energy(fast_pos, fast_vel) - e0) / abs(e0)
     de_cpu = abs(energy(cpu_pos, cpu_vel) - e0) / abs(e0)
     assert de_fast <= max(1.5 * de_cpu, 1e-4), (de_fast, de_cpu)
+
+
+def test_large_lds_optin_is_made_once_per_kernel_instantiation(tmp_path):
+    """Round-2 finding: the >64 KiB dynamic-LDS opt-in (hipFuncSetAttribute) was cached per kernel pointer TYPE, so after one
+    FAST instantiation was armed every other one of that precision skipped it.  In a fresh process: plans (4,16,1024) and
+    (4,16,2048) -- two instantiations, 95 488 B of LDS each -- must each be armed exactly once, a repeat must arm nothing,
+    fp64 STRICT at 512 threads (65 792 B) arms its own kernel, and so does a graph of it (before the capture)."""
+    import subprocess
+    import sys
+
+    script = r'''
+import ctypes, sys
+import numpy as np
+sys.path.insert(0, %r)
+import __graft_entry__ as entry
+pkg = entry.load_package(); lib = pkg.lib()
+pkg.check(lib.nb_set_device(0))
+def count():
+    c = ctypes.c_int(-1); pkg.check(lib.nb_lds_optin_count(ctypes.byref(c))); return c.value
+n = 65536
+pos = np.random.default_rng(0).random(4 * n, dtype=np.float32)
+seen = [count()]
+for plan in ((4, 16, 1024), (4, 16, 2048), (4, 16, 1024), (4, 16, 2048)):
+    pkg.set_plan_override(*plan)
+    s = pkg.BodySystemHIP(n, 256, pkg.NBodyParams(), np.float32, pos, np.zeros_like(pos), mode=pkg.NB_MODE_FAST)
+    s.update(np.float32(0.016)); s.synchronize(); s.free()
+    seen.append(count())
+pkg.set_plan_override(0, 0, 0)
+n64 = 512 * 256
+pos64 = np.random.default_rng(1).random(4 * n64)
+s = pkg.BodySystemHIP(n64, 256, pkg.NBodyParams(), np.float64, pos64, np.zeros_like(pos64), mode=pkg.NB_MODE_STRICT)
+s.update_many(0.016, 2); s.synchronize(); seen.append(count())
+s.update(0.016); s.synchronize(); seen.append(count())
+s.free()
+print("COUNTS", *seen)
+''' % ROOT
+    out = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    counts = [int(x) for x in out.stdout.split("COUNTS")[1].split()]
+    assert counts == [0, 1, 2, 2, 2, 3, 3], counts
