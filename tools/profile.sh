@@ -3,9 +3,9 @@
 # Counters go in their own passes, never combined with any trace option other than --kernel-trace.
 set -o pipefail
 export TMPDIR=/tmp
-OUT=gpurun_out/prof
+OUT=${PROF_OUT:-gpurun_out/prof}
 rm -rf $OUT; mkdir -p $OUT
-ARGS="bench.py --no-cpu-baseline ${*:---steps 20 --warmup 3}"
+ARGS="bench.py --no-cpu-baseline --no-configs ${*:---steps 20 --warmup 3}"  # --no-configs: only the headline kernel in the trace
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ARGS > $OUT/trace.log 2>&1 || { echo trace failed; tail -5 $OUT/trace.log; exit 1; }
 echo trace ok
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $ARGS > $OUT/pmc_fetch.log 2>&1 || { echo fetch failed; tail -5 $OUT/pmc_fetch.log; exit 1; }

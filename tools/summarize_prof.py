@@ -58,12 +58,19 @@ if "GRBM_GUI_ACTIVE" in counters:
 if "SQ_INSTS_VALU" in counters:
     d["valu_wave_instructions_per_launch"] = counters["SQ_INSTS_VALU"]
 # the launch plan and commit the counters belong to (bench.py only quotes `traffic` from a summary whose plan matches its own)
+out["mode"] = "strict" if "strict" in KERNEL else "fast"
 try:
     with open(os.path.join(src, "trace.log")) as fh:
         line = next(l for l in reversed(fh.read().splitlines()) if l.startswith("{") and "kernel_plan" in l)
-    out["kernel_plan"] = json.loads(line)["config"]["kernel_plan"]
+    bench_line = json.loads(line)
+    out["workload"] = bench_line["config"]["workload"]
+    # nb_plan_* describes the FAST geometry only: it says nothing about a STRICT launch
+    out["kernel_plan"] = bench_line["config"]["kernel_plan"] if out["mode"] == "fast" else None
 except (OSError, StopIteration, KeyError, ValueError):
     out["kernel_plan"] = None
+out["notes"] = ("kernel.VGPR_Count / LDS_Block_Size are rocprofv3's dispatch-packet fields as it prints them (VGPR_Count in allocation granules as "
+                "reported by the tool, LDS_Block_Size without the dynamic part requested at launch); the register and LDS figures quoted in "
+                "DESIGN.md come from the compiled ISA (make -C cuda-nbody_amd/csrc asm) and from nb_plan_*")
 json.dump(out, open(f"{prefix}_pmc_summary.json", "w"), indent=1)
 print(json.dumps(out["derived"], indent=1))
 print("kernel avg ms", out["kernel_trace_avg_ms"])
