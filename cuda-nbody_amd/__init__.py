@@ -62,6 +62,12 @@ class DeviceInfo(ctypes.Structure):
                 ("lds_bytes_per_cu", ctypes.c_int), ("total_memory", ctypes.c_size_t)]
 
 
+class PairPlan(ctypes.Structure):
+    _fields_ = [("applies", ctypes.c_int), ("bodies_per_lane", ctypes.c_int), ("waves_per_block", ctypes.c_int), ("splits", ctypes.c_uint),
+                ("blocks", ctypes.c_uint), ("block_bodies", ctypes.c_uint), ("reaction_slots", ctypes.c_uint), ("grid_blocks", ctypes.c_uint),
+                ("lds_bytes", ctypes.c_uint), ("workspace_bytes", ctypes.c_size_t)]
+
+
 class LaunchPlan(ctypes.Structure):
     _fields_ = [("bodies_per_lane", ctypes.c_int), ("lanes_per_body", ctypes.c_int), ("tile_bodies", ctypes.c_int),
                 ("block_threads", ctypes.c_int), ("grid_blocks", ctypes.c_uint), ("lds_bytes", ctypes.c_uint)]
@@ -105,6 +111,15 @@ SIGNATURES = {
     "nb_integrate_shard_f64": (_ci, [_vp, _vp, _vp, _vp, _cu, _cu, _cu, _cu, _cu, _cd, _cd, _ci, _ci, _vp]),
     "nb_graph_create_f32": (_ci, [_P(_vp), _vp, _vp, _vp, _cf, _cf, _cu, _ci, _ci, _cu]),
     "nb_graph_create_f64": (_ci, [_P(_vp), _vp, _vp, _vp, _cd, _cd, _cu, _ci, _ci, _cu]),
+    "nb_graph_create_ws_f32": (_ci, [_P(_vp), _vp, _vp, _vp, _cf, _cf, _cu, _ci, _ci, _cu, _vp, _sz]),
+    "nb_graph_create_ws_f64": (_ci, [_P(_vp), _vp, _vp, _vp, _cd, _cd, _cu, _ci, _ci, _cu, _vp, _sz]),
+    "nb_workspace_bytes_f32": (_ci, [_cu, _ci, _P(_sz)]),
+    "nb_workspace_bytes_f64": (_ci, [_cu, _ci, _P(_sz)]),
+    "nb_integrate_ws_f32": (_ci, [_vp, _vp, _vp, _cf, _cf, _cu, _ci, _ci, _vp, _sz, _vp]),
+    "nb_integrate_ws_f64": (_ci, [_vp, _vp, _vp, _cd, _cd, _cu, _ci, _ci, _vp, _sz, _vp]),
+    "nb_pair_plan_f32": (_ci, [_cu, _P(PairPlan)]),
+    "nb_pair_plan_f64": (_ci, [_cu, _P(PairPlan)]),
+    "nb_set_pair_plan_override": (_ci, [_ci, _ci, _ci, _ci]),
     "nb_graph_launch": (_ci, [_vp, _vp]),
     "nb_graph_destroy": (_ci, [_vp]),
     "nb_comm_unique_id": (_ci, [_vp]),
@@ -169,6 +184,17 @@ def plan(i_count: int, j_count: int, dtype=np.float32) -> LaunchPlan:
     fn = lib().nb_plan_f32 if np.dtype(dtype) == np.float32 else lib().nb_plan_f64
     check(fn(i_count, j_count, ctypes.byref(p)), "nb_plan")
     return p
+
+
+def pair_plan(num_bodies: int, dtype=np.float32) -> PairPlan:
+    p = PairPlan()
+    fn = lib().nb_pair_plan_f32 if np.dtype(dtype) == np.float32 else lib().nb_pair_plan_f64
+    check(fn(num_bodies, ctypes.byref(p)), "nb_pair_plan")
+    return p
+
+
+def set_pair_plan_override(vectors_per_lane: int = 0, waves_per_block: int = 0, splits: int = 0, min_bodies: int = 0) -> None:
+    check(lib().nb_set_pair_plan_override(vectors_per_lane, waves_per_block, splits, min_bodies), "nb_set_pair_plan_override")
 
 
 def set_plan_override(bodies_per_lane: int = 0, lanes_per_body: int = 0, tile_bodies: int = 0) -> None:
@@ -237,7 +263,10 @@ class BodySystemHIP:
     """
 
     def __init__(self, nb_bodies: int, block_size: int = 256, params: NBodyParams | None = None, dtype=np.float32,
-                 positions: np.ndarray | None = None, velocities: np.ndarray | None = None, mode: int = NB_MODE_FAST):
+                 positions: np.ndarray | None = None, velocities: np.ndarray | None = None, mode: int = NB_MODE_FAST,
+                 workspace: bool = False):
+        """`workspace=True`: own the scratch memory nb_workspace_bytes_* asks for and step through nb_integrate_ws_* (FAST mode
+        then takes the pairwise layout where it applies), as BodySystemHIPStored does in the C++ host."""
         self.dtype = np.dtype(dtype)
         if self.dtype not in (np.dtype(np.float32), np.dtype(np.float64)):
             raise TypeError("float32 or float64")
@@ -252,6 +281,14 @@ class BodySystemHIP:
         self._vel = DeviceBuffer(nbytes)
         self._host_pos = np.zeros(4 * self.nb_bodies, dtype=self.dtype)
         self._host_vel = np.zeros(4 * self.nb_bodies, dtype=self.dtype)
+        self._workspace, self._workspace_bytes = None, 0
+        if workspace:
+            need = _sz(0)
+            fn = lib().nb_workspace_bytes_f32 if self.dtype == np.float32 else lib().nb_workspace_bytes_f64
+            check(fn(self.nb_bodies, self.mode, ctypes.byref(need)), "nb_workspace_bytes")
+            if need.value:
+                self._workspace, self._workspace_bytes = _vp(), need.value
+                check(lib().nb_alloc(ctypes.byref(self._workspace), need.value), "nb_alloc(workspace)")
         self._set_softening(params.softening)
         if positions is not None:
             self.set_position(positions)
@@ -279,9 +316,15 @@ class BodySystemHIP:
 
     def update(self, delta_time, stream=None) -> None:
         self._apply_softening()
-        integrate_nbody_system(self._pos[1 - self.current_read].ptr, self._pos[self.current_read].ptr, self._vel.ptr,
-                               self.current_read, delta_time, self.damping, self.nb_bodies, self.block_size,
-                               self.dtype, self.mode, stream)
+        if self._workspace is not None:
+            f32 = self.dtype == np.float32
+            fn, scalar = (lib().nb_integrate_ws_f32, np.float32) if f32 else (lib().nb_integrate_ws_f64, float)
+            check(fn(self._pos[1 - self.current_read].ptr, self._pos[self.current_read].ptr, self._vel.ptr, scalar(delta_time), scalar(self.damping),
+                     self.nb_bodies, self.block_size, self.mode, self._workspace, self._workspace_bytes, stream), "nb_integrate_ws")
+        else:
+            integrate_nbody_system(self._pos[1 - self.current_read].ptr, self._pos[self.current_read].ptr, self._vel.ptr,
+                                   self.current_read, delta_time, self.damping, self.nb_bodies, self.block_size,
+                                   self.dtype, self.mode, stream)
         self.current_read, self.current_write = self.current_write, self.current_read
 
     def update_many(self, delta_time, steps: int, stream=None) -> None:
@@ -294,11 +337,11 @@ class BodySystemHIP:
             g = _vp()
             a, b = self._pos[self.current_read].ptr, self._pos[1 - self.current_read].ptr
             if self.dtype == np.float32:
-                rc = lib().nb_graph_create_f32(ctypes.byref(g), a, b, self._vel.ptr, np.float32(delta_time), self.damping,
-                                               self.nb_bodies, self.block_size, self.mode, steps)
+                rc = lib().nb_graph_create_ws_f32(ctypes.byref(g), a, b, self._vel.ptr, np.float32(delta_time), self.damping,
+                                                  self.nb_bodies, self.block_size, self.mode, steps, self._workspace, self._workspace_bytes)
             else:
-                rc = lib().nb_graph_create_f64(ctypes.byref(g), a, b, self._vel.ptr, float(delta_time), float(self.damping),
-                                               self.nb_bodies, self.block_size, self.mode, steps)
+                rc = lib().nb_graph_create_ws_f64(ctypes.byref(g), a, b, self._vel.ptr, float(delta_time), float(self.damping),
+                                                  self.nb_bodies, self.block_size, self.mode, steps, self._workspace, self._workspace_bytes)
             check(rc, "nb_graph_create")
             self._graph, self._graph_key = g, key
         check(lib().nb_graph_launch(self._graph, stream), "nb_graph_launch")  # even step count: read index unchanged
@@ -333,6 +376,9 @@ class BodySystemHIP:
         self._free_graph()
         for b in self._pos + [self._vel]:
             b.free()
+        if self._workspace is not None:
+            lib().nb_free(self._workspace)
+            self._workspace = None
 
 
 class Event:

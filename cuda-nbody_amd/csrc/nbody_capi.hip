@@ -23,6 +23,7 @@ std::atomic<float>  g_softening_sq_f32{0.0f};
 std::atomic<double> g_softening_sq_f64{0.0};
 
 std::atomic<int> g_ovr_i{0}, g_ovr_s{0}, g_ovr_tile{0};
+std::atomic<int> g_pair_r{0}, g_pair_s{0}, g_pair_c{0}, g_pair_min{0};  // overrides of the pairwise plan (0 = automatic)
 
 
 // The HIP runtime sets parts of itself up lazily, on the first call that needs them (the null stream, the first event,
@@ -115,7 +116,43 @@ struct StepGraph {
     hipGraphExec_t exec  = nullptr;
 };
 
-template <typename T> int graph_create(nb_graph_t* out, T* pos_a, T* pos_b, T* vel, T dt, T damping, T eps2, unsigned n, int block_size, int mode, unsigned steps) {
+// Fewer bodies than this and the pairwise layout loses to the one-sided kernels (measured: profiles/round3_pair_crossover.txt)
+constexpr unsigned kPairMinBodies = 16384;
+
+template <typename T> bool pair_applies(unsigned n, int mode, nb::PairPlan* plan) {
+    const int floor_bodies = g_pair_min.load();
+    if (mode != NB_MODE_FAST || n < (floor_bodies > 0 ? static_cast<unsigned>(floor_bodies) : kPairMinBodies)) return false;
+    *plan = nb::plan_pair<T>(n, cu_count_cached(), g_pair_r.load(), g_pair_s.load(), g_pair_c.load());
+    return true;
+}
+
+// nb_integrate_ws_*: the whole system in one step, FAST, with a caller-owned workspace -> the pairwise layout when it
+// applies and the workspace is large enough; in every other case exactly what nb_integrate_* does.
+template <typename T>
+int integrate_ws(T* new_pos, const T* old_pos, T* vel, T dt, T damping, T eps2, unsigned n, int block_size, int mode, void* workspace, size_t workspace_bytes, nb_stream_t stream, bool prepare_only = false) {
+    nb::PairPlan plan{};
+    if (workspace != nullptr && n != 0 && pair_applies<T>(n, mode, &plan) && workspace_bytes >= plan.workspace_bytes) {
+        if (!new_pos || !old_pos || !vel || new_pos == old_pos) return NB_ERR_INVALID_ARGUMENT;
+        if (!aligned_vec4<T>(old_pos) || !aligned_vec4<T>(new_pos) || !aligned_vec4<T>(vel) || (reinterpret_cast<std::uintptr_t>(workspace) % sizeof(T)) != 0) return NB_ERR_INVALID_ARGUMENT;
+        {   // nothing the launch writes may overlap the bodies it reads (old_pos is read-only for the whole launch)
+            const auto lo = [](const void* q) { return reinterpret_cast<std::uintptr_t>(q); };
+            const std::uintptr_t bytes = static_cast<std::uintptr_t>(n) * 4 * sizeof(T);
+            auto overlaps = [&](const void* q, std::uintptr_t len) { return lo(q) < lo(old_pos) + bytes && lo(old_pos) < lo(q) + len; };
+            if (overlaps(new_pos, bytes) || overlaps(vel, bytes) || overlaps(workspace, plan.workspace_bytes)) return NB_ERR_INVALID_ARGUMENT;
+        }
+        nb::Shard<T> s{};
+        s.new_pos = new_pos, s.old_pos = old_pos, s.vel = vel, s.acc = nullptr;
+        s.i_begin = 0, s.i_count = n, s.j_begin = 0, s.j_count = n;
+        s.acc_in = false, s.finalize = true;
+        s.dt = dt, s.damping = damping, s.eps2 = eps2;
+        (void)current_device_ready();
+        return static_cast<int>(nb::launch_pair<T>(s, plan, workspace, as_stream(stream), prepare_only));
+    }
+    if (prepare_only) return 0;
+    return integrate_shard<T>(new_pos, old_pos, vel, nullptr, 0, n, 0, n, NB_SHARD_FINALIZE, dt, damping, eps2, block_size, mode, stream);
+}
+
+template <typename T> int graph_create(nb_graph_t* out, T* pos_a, T* pos_b, T* vel, T dt, T damping, T eps2, unsigned n, int block_size, int mode, unsigned steps, void* workspace = nullptr, size_t workspace_bytes = 0) {
     if (!out || !pos_a || !pos_b || !vel || pos_a == pos_b || n == 0 || steps < 2 || (steps & 1u)) return NB_ERR_INVALID_ARGUMENT;
     NB_KEEP_RAND_STREAM;
     *out = nullptr;
@@ -127,6 +164,10 @@ template <typename T> int graph_create(nb_graph_t* out, T* pos_a, T* pos_b, T* v
         if (mode == NB_MODE_FAST) {
             const nb::Plan p = nb::plan_fast<T>(n, n, cu_count_cached(), g_ovr_i.load(), g_ovr_s.load(), g_ovr_tile.load());
             err              = nb::launch_fast<T>(probe, p, nullptr, /*prepare_only=*/true);
+            if (err == hipSuccess && workspace != nullptr) {
+                const int rc = integrate_ws<T>(pos_b, pos_a, vel, dt, damping, eps2, n, block_size, mode, workspace, workspace_bytes, nullptr, /*prepare_only=*/true);
+                if (rc != 0) return rc;
+            }
         } else if (mode == NB_MODE_STRICT) {
             err = nb::launch_strict<T>(probe, block_size, cu_count_cached(), nullptr, /*prepare_only=*/true);
         }
@@ -142,7 +183,8 @@ template <typename T> int graph_create(nb_graph_t* out, T* pos_a, T* pos_b, T* v
     for (unsigned k = 0; rc == 0 && k < steps; ++k) {
         T* from = (k & 1u) ? pos_b : pos_a;
         T* to   = (k & 1u) ? pos_a : pos_b;
-        rc      = integrate_shard<T>(to, from, vel, nullptr, 0, n, 0, n, NB_SHARD_FINALIZE, dt, damping, eps2, block_size, mode, capture);
+        rc      = workspace != nullptr ? integrate_ws<T>(to, from, vel, dt, damping, eps2, n, block_size, mode, workspace, workspace_bytes, capture)
+                                       : integrate_shard<T>(to, from, vel, nullptr, 0, n, 0, n, NB_SHARD_FINALIZE, dt, damping, eps2, block_size, mode, capture);
     }
     if (err == hipSuccess) {  // always close an opened capture
         const auto end = hipStreamEndCapture(capture, &g->graph);
@@ -163,6 +205,22 @@ template <typename T> int graph_create(nb_graph_t* out, T* pos_a, T* pos_b, T* v
     return 0;
 }
 
+template <typename T> int pair_plan_query(unsigned n, nb_pair_plan_t* out) {
+    if (out == nullptr || n == 0) return NB_ERR_INVALID_ARGUMENT;
+    const nb::PairPlan p  = nb::plan_pair<T>(n, cu_count_cached(), g_pair_r.load(), g_pair_s.load(), g_pair_c.load());
+    nb::PairPlan       chosen{};
+    out->applies          = pair_applies<T>(n, NB_MODE_FAST, &chosen) ? 1 : 0;
+    out->bodies_per_lane  = p.vectors_per_lane * (sizeof(T) == 4 ? 2 : 1);
+    out->waves_per_block  = p.waves;
+    out->splits           = p.splits;
+    out->blocks           = p.blocks;
+    out->block_bodies     = p.block_bodies;
+    out->reaction_slots   = p.slots;
+    out->grid_blocks      = p.grid_blocks;
+    out->lds_bytes        = p.lds_bytes;
+    out->workspace_bytes  = p.workspace_bytes;
+    return 0;
+}
 template <typename T> int plan_query(unsigned i_count, unsigned j_count, nb_launch_plan_t* out) {
     if (!out || i_count == 0) return NB_ERR_INVALID_ARGUMENT;
     const nb::Plan p     = nb::plan_fast<T>(i_count, j_count, cu_count_cached(), g_ovr_i.load(), g_ovr_s.load(), g_ovr_tile.load());
@@ -356,6 +414,52 @@ int nb_graph_create_f32(nb_graph_t* graph, float* position_a, float* position_b,
 int nb_graph_create_f64(nb_graph_t* graph, double* position_a, double* position_b, double* velocities, double dt, double damping, unsigned num_bodies, int block_size, int mode, unsigned steps) {
     return graph_create<double>(graph, position_a, position_b, velocities, dt, damping, g_softening_sq_f64.load(), num_bodies, block_size, mode, steps);
 }
+int nb_graph_create_ws_f32(nb_graph_t* graph, float* position_a, float* position_b, float* velocities, float dt, float damping, unsigned num_bodies, int block_size, int mode, unsigned steps, void* workspace,
+                           size_t workspace_bytes) {
+    return graph_create<float>(graph, position_a, position_b, velocities, dt, damping, g_softening_sq_f32.load(), num_bodies, block_size, mode, steps, workspace, workspace_bytes);
+}
+int nb_graph_create_ws_f64(nb_graph_t* graph, double* position_a, double* position_b, double* velocities, double dt, double damping, unsigned num_bodies, int block_size, int mode, unsigned steps, void* workspace,
+                           size_t workspace_bytes) {
+    return graph_create<double>(graph, position_a, position_b, velocities, dt, damping, g_softening_sq_f64.load(), num_bodies, block_size, mode, steps, workspace, workspace_bytes);
+}
+
+int nb_workspace_bytes_f32(unsigned num_bodies, int mode, size_t* bytes) {
+    if (bytes == nullptr) return NB_ERR_INVALID_ARGUMENT;
+    nb::PairPlan plan{};
+    *bytes = pair_applies<float>(num_bodies, mode, &plan) ? plan.workspace_bytes : 0;
+    return 0;
+}
+int nb_workspace_bytes_f64(unsigned num_bodies, int mode, size_t* bytes) {
+    if (bytes == nullptr) return NB_ERR_INVALID_ARGUMENT;
+    nb::PairPlan plan{};
+    *bytes = pair_applies<double>(num_bodies, mode, &plan) ? plan.workspace_bytes : 0;
+    return 0;
+}
+int nb_integrate_ws_f32(float* new_positions, const float* old_positions, float* velocities, float dt, float damping, unsigned num_bodies, int block_size, int mode, void* workspace, size_t workspace_bytes, nb_stream_t stream) {
+    return integrate_ws<float>(new_positions, old_positions, velocities, dt, damping, g_softening_sq_f32.load(), num_bodies, block_size, mode, workspace, workspace_bytes, stream);
+}
+int nb_integrate_ws_f64(double* new_positions, const double* old_positions, double* velocities, double dt, double damping, unsigned num_bodies, int block_size, int mode, void* workspace, size_t workspace_bytes,
+                        nb_stream_t stream) {
+    return integrate_ws<double>(new_positions, old_positions, velocities, dt, damping, g_softening_sq_f64.load(), num_bodies, block_size, mode, workspace, workspace_bytes, stream);
+}
+
+int nb_pair_plan_f32(unsigned num_bodies, nb_pair_plan_t* plan) { return pair_plan_query<float>(num_bodies, plan); }
+int nb_pair_plan_f64(unsigned num_bodies, nb_pair_plan_t* plan) { return pair_plan_query<double>(num_bodies, plan); }
+
+int nb_set_pair_plan_override(int vectors_per_lane, int waves_per_block, int splits, int min_bodies) {
+    auto ok = [](int v, std::initializer_list<int> allowed) {
+        for (int a : allowed)
+            if (v == a) return true;
+        return false;
+    };
+    if (!ok(vectors_per_lane, {0, 1, 2, 4}) || !ok(waves_per_block, {0, 4, 8, 16}) || splits < 0 || splits > 64 || min_bodies < 0) return NB_ERR_INVALID_ARGUMENT;
+    g_pair_r.store(vectors_per_lane);
+    g_pair_s.store(waves_per_block);
+    g_pair_c.store(splits);
+    g_pair_min.store(min_bodies);
+    return 0;
+}
+
 int nb_graph_launch(nb_graph_t graph, nb_stream_t stream) {
     if (!graph) return NB_ERR_INVALID_ARGUMENT;
     (void)current_device_ready();

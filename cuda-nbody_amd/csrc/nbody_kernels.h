@@ -46,6 +46,21 @@ struct Plan {
     unsigned lds_bytes;
 };
 
+// geometry of the pairwise layout (nbody_pair.hip; nb_pair_plan_t in include/nbody_hip.h)
+struct PairPlan {
+    int      vectors_per_lane;  // R: fp32 packed pairs / fp64 bodies i per lane
+    int      waves;             // S: waves per workgroup (they share the bodies i, split the tiles of bodies j)
+    unsigned splits;            // C: workgroups per block of bodies i
+    unsigned blocks;            // NB
+    unsigned block_bodies;      // 64 * I
+    unsigned slots;             // reaction slots per body in the workspace
+    unsigned grid_blocks;
+    unsigned lds_bytes;
+    size_t   workspace_bytes;
+};
+
+template <typename T> PairPlan   plan_pair(unsigned n, int cu_count, int ovr_r, int ovr_s, int ovr_c);
+template <typename T> hipError_t launch_pair(const Shard<T>& s, const PairPlan& p, void* workspace, hipStream_t stream, bool prepare_only = false);
 template <typename T> Plan       plan_fast(unsigned i_count, unsigned j_count, int cu_count, int ovr_i, int ovr_s, int ovr_tile);
 template <typename T> hipError_t launch_fast(const Shard<T>& s, const Plan& p, hipStream_t stream, bool prepare_only = false);
 template <typename T> hipError_t launch_strict(const Shard<T>& s, int block_size, int cu_count, hipStream_t stream, bool prepare_only = false);

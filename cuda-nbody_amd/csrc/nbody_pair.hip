@@ -1,0 +1,432 @@
+// nbody_pair.hip -- FAST, pairwise layout (round 3): every unordered pair of bodies is evaluated ONCE and applied to both
+// bodies (Newton's third law), instead of once per direction as the reference kernel does
+// (/root/reference/src/nbody/bodysystemcuda.cu:98-146 evaluates all N^2 directed interactions).  gfx950 (CDNA4) only.
+//
+// Why: the one-sided loop of nbody_fast.hip sits at its instruction floor -- 11 v_pk_* + 2 v_rsq_f32 per packed pair of bodies
+// i and body j = 61.5 SIMD cycles per 2 directed interactions and lane (30.75 each), 62 % of the "20 flop" fp32 peak.  The
+// only lever left is the number of evaluations.  A pair evaluation that also feeds the reaction sums of the body j costs
+// 3 more v_pk_fma; what it needs is a place for those sums that a lane can reach:
+//
+//   * A wave holds 64*I bodies i for good (I = R*W per lane: R packed pairs in fp32, R doubles in fp64), exactly as the
+//     one-sided kernel does.  The bodies j come 64 at a time, ONE PER LANE (a coalesced vector load), together with three
+//     reaction sums per lane, and ROTATE through the wave: after each step everything that belongs to the body j moves on
+//     by one lane with DPP wave_ror:1 (a full 64-lane rotation exists on gfx9/CDNA; checked on the chip,
+//     tools/scratch/wave_ror_check.hip).  After 64 steps every body i of the wave has met every body j of the tile and the
+//     reaction sums are back in their home lanes.  Per step and lane: R x (14 v_pk_* + 2 v_rsq_f32) + 9 v_mov_b32_dpp for
+//     4R directed interactions; measured in isolation (tools/sym_microbench.hip, profiles/round3_pairwise_loop_microbench.txt)
+//     275 SIMD cycles per step at R = 4 with 4 waves per SIMD = 17.2 cycles per directed interaction against 30.75.
+//   * Work: the bodies are cut into blocks of 64*I; block pair (a, a+q) is evaluated by the workgroup(s) of block a for
+//     q = 0 .. NB/2 (indices mod NB) -- a round-robin tournament, every workgroup gets the same amount.  q = 0 (the block with
+//     itself) and, for an even block count, q = NB/2 (which both partners list) run the same loop but keep only the i side.
+//     The S waves of a workgroup (and the C workgroups of a block, for small systems) share the bodies i and split the
+//     64-body tiles of those blocks: unit u -> wave u mod (C*S), static, so every sum is formed in the same order in every run.
+//   * The reaction sums of a tile leave the wave once, after its 64 steps: 3 coalesced stores into the caller's WORKSPACE,
+//     slot q-1 of body j (each (slot, body) is written by exactly one wave per step: no atomics, no zeroing).  The i-side
+//     sums are folded over the S waves through LDS in a fixed order (as in nbody_fast.hip) and stored to the workspace too.
+//     A second kernel adds a body's slots in a fixed order and integrates (integrateBodies, bodysystemcuda.cu:166-183).
+//     Workspace traffic: 12 B per tile visit and body = N^2 / (128 I) * 12 B per step (0.8 GB at 262 144 bodies, written once,
+//     read once: ~0.3 ms of a ~8 ms step).
+//   * Masses: sums are kept in units of the first body's mass m_ref, and a unit whose 64 bodies j and 64*I bodies i all have
+//     mass m_ref (every start-up configuration of the reference) runs without a mass multiply; any other unit carries
+//     m_j / m_ref along with the body j and multiplies by the masses of the bodies i (2 more v_pk_mul per pair).  Bodies
+//     beyond N (ragged last block) are zero-mass bodies at a real body's place: they pull nothing, and what they feel is dropped.
+//
+// Results differ from the one-sided FAST kernel in summation order only; both are held to an fp64 direct sum by the tests.
+#include "nbody_kernels.h"
+
+#include <algorithm>
+
+namespace nb {
+namespace {
+
+#include "nbody_lane.h"
+
+// ---- DPP rotation of whatever belongs to the body j: one lane onward (lane l reads lane l-1; lane 0 reads lane 63) ----------
+constexpr int kWaveRor1 = 0x13C;
+__device__ __forceinline__ float rotate(float x) {
+    const int v = __builtin_bit_cast(int, x);
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(v, v, kWaveRor1, 0xf, 0xf, false));
+}
+__device__ __forceinline__ double rotate(double x) {
+    const unsigned long long b  = __builtin_bit_cast(unsigned long long, x);
+    const int                lo = static_cast<int>(b & 0xffffffffull), hi = static_cast<int>(b >> 32);
+    const unsigned           l2 = static_cast<unsigned>(__builtin_amdgcn_update_dpp(lo, lo, kWaveRor1, 0xf, 0xf, false));
+    const unsigned           h2 = static_cast<unsigned>(__builtin_amdgcn_update_dpp(hi, hi, kWaveRor1, 0xf, 0xf, false));
+    return __builtin_bit_cast(double, (static_cast<unsigned long long>(h2) << 32) | l2);
+}
+__device__ __forceinline__ v2f rotate(v2f x) { return v2f{rotate(x.x), rotate(x.y)}; }
+
+__device__ __forceinline__ float  both_halves(v2f a) { return a.x + a.y; }
+__device__ __forceinline__ double both_halves(double a) { return a; }
+
+template <typename T> struct PairArgs {
+    const T* old_pos;
+    T*       new_pos;
+    T*       vel;
+    T*       work;     // [splits][3][npad] i-side sums, then [slots][3][npad] reaction sums
+    unsigned n;        // bodies
+    unsigned blocks;   // NB = ceil(n / (64*I))
+    unsigned npad;     // NB * 64 * I
+    unsigned splits;   // C workgroups per block
+    unsigned slots;    // reaction slots per body
+    T        dt, damping, eps2;
+};
+
+template <typename T> __device__ __forceinline__ T pair_reference_mass(const T* old_pos) {
+    const T m = old_pos[3];
+    const T a = m < 0 ? -m : m;
+    return (a >= T(0x1p-60) && a <= T(0x1p60)) ? m : T(1);  // false for NaN too
+}
+
+// T: float|double   R: vectors per lane (I = R*W bodies i)   S: waves of a workgroup
+template <typename T, int R, int S> __global__ __launch_bounds__(64 * S) __attribute__((amdgpu_waves_per_eu(4, 4))) void pair_forces(PairArgs<T> s) {
+    using LT            = Lane<T>;
+    using vec4          = typename LT::vec4;
+    using vec           = typename LT::vec;
+    using bits          = typename LT::bits;
+    constexpr int W     = LT::W;
+    constexpr int I     = R * W;    // bodies i per lane
+    constexpr int BLOCK = 64 * I;   // bodies per block
+    constexpr int TB    = I;        // 64-body tiles per block
+#ifndef NB_PAIR_UNR
+#define NB_PAIR_UNR 4
+#endif
+#ifndef NB_PAIR_RB
+#define NB_PAIR_RB 2
+#endif
+    constexpr int UNR   = NB_PAIR_UNR;  // steps per trip of the rotation loop
+
+    extern __shared__ __attribute__((aligned(32))) unsigned char smem_raw[];
+
+    const vec4* __restrict__ old_pos = reinterpret_cast<const vec4*>(s.old_pos);
+    const int      tid  = threadIdx.x;
+    const int      wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int      lane = tid & 63;
+    const unsigned a    = blockIdx.x / s.splits;  // the block whose bodies i this workgroup holds
+    const unsigned c    = blockIdx.x % s.splits;
+
+    const T    m_ref     = pair_reference_mass(s.old_pos);
+    const T    inv_mref  = T(1) / m_ref;
+    const bits unit_bits = __builtin_bit_cast(bits, m_ref);
+
+    // bodies i of this lane: block_base + k*64 + lane (coalesced across the wave); a body beyond N sits on body N-1 with mass 0
+    const unsigned block_base = a * BLOCK;
+    vec            px[R], py[R], pz[R], ax[R], ay[R], az[R];
+    bool           all_unit = true;
+#pragma unroll
+    for (int k = 0; k < I; ++k) {
+        const unsigned i = block_base + k * 64 + lane;
+        const vec4     p = old_pos[i < s.n ? i : s.n - 1];
+        LT::set(px[k / W], k % W, p.x);
+        LT::set(py[k / W], k % W, p.y);
+        LT::set(pz[k / W], k % W, p.z);
+        all_unit = all_unit && i < s.n && __builtin_bit_cast(bits, p.w) == unit_bits;
+    }
+    const bool block_unit = __builtin_amdgcn_ballot_w64(!all_unit) == 0;  // wave-uniform: every body i of the block is real and has mass m_ref
+#pragma unroll
+    for (int r = 0; r < R; ++r) ax[r] = ay[r] = az[r] = LT::splat(0);
+    vec eps2 = LT::splat(s.eps2);
+    LT::keep_in_vgpr(eps2);
+    const typename LT::Consts consts = LT::make_consts();
+
+    // ---- LDS: [S][3*I][64] second-level sums (fp32) -- later the fold buffer -- then the progress words ---------------------
+    constexpr size_t kSumBytes = static_cast<size_t>(S) * 3 * I * 64 * sizeof(T);
+    T* const         sums      = reinterpret_cast<T*>(smem_raw);
+    unsigned* const  balance   = reinterpret_cast<unsigned*>(smem_raw + kSumBytes);
+    unsigned* const  simd_count = balance;                                            // [4] waves of this workgroup per SIMD
+    volatile unsigned* progress = reinterpret_cast<volatile unsigned*>(balance + 4);  // [4][8] units done, by SIMD and slot
+    if (tid < 36) balance[tid] = tid < 4 ? 0u : 0xffffffffu;
+    __syncthreads();
+    // SIMD-mate balancing as in nbody_fast.hip: the arbiter is oldest-first, s_setprio outranks age -- a wave level with the
+    // slowest wave of its SIMD (same workgroup) runs at priority 3, one that is ahead at 0; the unit -> wave map stays static.
+    const unsigned simd = static_cast<unsigned>(__builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4));  // HW_REG_HW_ID[5:4] = SIMD_ID
+    unsigned       slot = 0;
+    if (lane == 0) slot = atomicAdd(&simd_count[simd], 1u);
+    slot = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(slot))) & 7u;
+    volatile unsigned* const mine = progress + simd * 8;
+    unsigned                 done = 0;
+    if (lane == 0) mine[slot] = 0;
+
+    // fp32: a register sum collects at most kFlush tiles (1 024 bodies j), then joins the lane's second-level sum in LDS
+    constexpr bool     kTwoLevel = sizeof(T) == 4;
+    constexpr unsigned kFlush    = 16;
+    T* const           second    = sums + static_cast<size_t>(wave) * (3 * I * 64) + lane;
+    if constexpr (kTwoLevel) {
+#pragma unroll
+        for (int q = 0; q < 3 * I; ++q) second[q * 64] = 0;
+    }
+    auto flush = [&]() {
+#pragma unroll
+        for (int k = 0; k < I; ++k) {
+            second[(0 * I + k) * 64] += LT::get(ax[k / W], k % W);
+            second[(1 * I + k) * 64] += LT::get(ay[k / W], k % W);
+            second[(2 * I + k) * 64] += LT::get(az[k / W], k % W);
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) ax[r] = ay[r] = az[r] = LT::splat(0);
+    };
+
+    // ---- the units of this wave ------------------------------------------------------------------------------------------
+    const unsigned NB      = s.blocks;
+    const unsigned Q       = NB / 2;
+    const bool     even    = (NB & 1u) == 0;
+    const unsigned n_units = (Q + 1) * TB;
+    const unsigned G       = s.splits * S;
+    const unsigned g       = c * S + static_cast<unsigned>(wave);
+
+    auto tile_first = [&](unsigned u) {
+        unsigned jb = a + u / TB;
+        if (jb >= NB) jb -= NB;
+        return jb * BLOCK + (u % TB) * 64;
+    };
+    auto load_tile = [&](unsigned u) {
+        const unsigned j = tile_first(u) + lane;
+        vec4           p = old_pos[j < s.n ? j : s.n - 1];
+        if (j >= s.n) p.w = 0;
+        return p;
+    };
+
+    // one rotation step: the lane's bodies i against the body j it holds right now; then the body j and its sums move on.
+    // Written stage by stage over the R vectors (all differences, all squared distances, ...): R independent chains.
+    auto step = [&]<bool UNIT>(T& jx, T& jy, T& jz, T& jm, vec& rx, vec& ry, vec& rz, const vec (&mi)[R]) {
+        constexpr int RB = R < NB_PAIR_RB ? R : NB_PAIR_RB;  // vectors per stage block (more in flight at once spills at R = 4)
+        const vec     bx = LT::splat(jx), by = LT::splat(jy), bz = LT::splat(jz);
+        vec           mj = bx;
+        if constexpr (!UNIT) mj = LT::splat(jm);  // m_j / m_ref
+#pragma unroll
+        for (int h = 0; h < R; h += RB) {
+            vec dx[RB], dy[RB], dz[RB], w[RB];
+#pragma unroll
+            for (int r = 0; r < RB; ++r) dx[r] = bx - px[h + r], dy[r] = by - py[h + r], dz[r] = bz - pz[h + r];
+#pragma unroll
+            for (int r = 0; r < RB; ++r) w[r] = LT::fma(dx[r], dx[r], eps2);
+#pragma unroll
+            for (int r = 0; r < RB; ++r) w[r] = LT::fma(dy[r], dy[r], w[r]);
+#pragma unroll
+            for (int r = 0; r < RB; ++r) w[r] = LT::fma(dz[r], dz[r], w[r]);
+#pragma unroll
+            for (int r = 0; r < RB; ++r) w[r] = LT::template coupling_rel<true>(eps2, w[r], consts);  // d2^(-3/2)
+#pragma unroll
+            for (int r = 0; r < RB; ++r) {
+                vec wi = w[r], wj = w[r];
+                if constexpr (!UNIT) wi = mj * w[r], wj = mi[h + r] * w[r];
+                ax[h + r] = LT::fma(dx[r], wi, ax[h + r]), ay[h + r] = LT::fma(dy[r], wi, ay[h + r]), az[h + r] = LT::fma(dz[r], wi, az[h + r]);
+                rx = LT::fma(dx[r], wj, rx), ry = LT::fma(dy[r], wj, ry), rz = LT::fma(dz[r], wj, rz);
+            }
+        }
+        // the body j and everything that belongs to it move on by one lane
+        jx = rotate(jx), jy = rotate(jy), jz = rotate(jz);
+        if constexpr (!UNIT) jm = rotate(jm);
+        rx = rotate(rx), ry = rotate(ry), rz = rotate(rz);
+    };
+
+    vec4 cur = g < n_units ? load_tile(g) : vec4{};
+    for (unsigned u = g; u < n_units; u += G) {
+        const vec4 next = (u + G) < n_units ? load_tile(u + G) : cur;  // in flight across the 64 steps below
+#ifndef NB_NO_BALANCE
+        {
+            unsigned least = done;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) least = min(least, mine[q]);  // unsynchronised reads: a stale value only delays a priority change
+            if (static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(least))) >= done) {
+                __builtin_amdgcn_s_setprio(3);
+            } else {
+                __builtin_amdgcn_s_setprio(0);
+            }
+        }
+#endif
+        const unsigned q     = u / TB;
+        const unsigned first = tile_first(u);
+        const unsigned j     = first + lane;
+        const bool     tile_unit = block_unit && __builtin_amdgcn_ballot_w64(!(j < s.n && __builtin_bit_cast(bits, cur.w) == unit_bits)) == 0;
+        T   jx = cur.x, jy = cur.y, jz = cur.z, jm = cur.w * inv_mref;
+        vec rx = LT::splat(0), ry = LT::splat(0), rz = LT::splat(0);
+        T   scale;  // what the reaction sums are still to be multiplied by
+        if (tile_unit) {
+            vec none[R];
+#pragma unroll 1
+            for (int it = 0; it < 64 / UNR; ++it) {
+#pragma unroll
+                for (int v = 0; v < UNR; ++v) step.template operator()<true>(jx, jy, jz, jm, rx, ry, rz, none);
+            }
+            scale = m_ref;
+        } else {
+            vec mi[R];  // the masses of the bodies i: only this path holds them, and only while it runs
+#pragma unroll
+            for (int k = 0; k < I; ++k) {
+                const unsigned i = block_base + k * 64 + lane;
+                LT::set(mi[k / W], k % W, i < s.n ? old_pos[i].w : T(0));
+            }
+#pragma unroll 1
+            for (int it = 0; it < 64 / UNR; ++it) {
+#pragma unroll
+                for (int v = 0; v < UNR; ++v) step.template operator()<false>(jx, jy, jz, jm, rx, ry, rz, mi);
+            }
+            scale = T(1);
+        }
+        // 64 steps on: every sum is back in the lane of its body j.  Keep the reaction only when the partner does not list the pair too.
+        const bool symmetric = q != 0 && !(even && q == Q);
+        if (symmetric && j < s.n) {
+            T* const out = s.work + (static_cast<size_t>(s.splits) + (q - 1)) * 3 * s.npad + j;
+            out[0]                               = both_halves(rx) * scale;
+            out[static_cast<size_t>(s.npad)]     = both_halves(ry) * scale;
+            out[2 * static_cast<size_t>(s.npad)] = both_halves(rz) * scale;
+        }
+        cur = next;
+        ++done;
+        if constexpr (kTwoLevel) {
+            if (done % kFlush == 0) flush();
+        }
+        if (lane == 0) mine[slot] = done;
+    }
+    if (lane == 0) mine[slot] = 0xffffffffu;  // finished: never the one the others defer to
+    __builtin_amdgcn_s_setprio(0);
+    if constexpr (kTwoLevel) {
+#pragma unroll
+        for (int k = 0; k < I; ++k) {
+            LT::set(ax[k / W], k % W, second[(0 * I + k) * 64] + LT::get(ax[k / W], k % W));
+            LT::set(ay[k / W], k % W, second[(1 * I + k) * 64] + LT::get(ay[k / W], k % W));
+            LT::set(az[k / W], k % W, second[(2 * I + k) * 64] + LT::get(az[k / W], k % W));
+        }
+    }
+
+    // fold the S partial sums (waves 1..S-1 -> wave 0) through LDS, fixed order; the second-level sums are done with
+    __syncthreads();
+    T* const red = sums;  // [(S-1)][3][I][64]
+    if (wave > 0) {
+#pragma unroll
+        for (int k = 0; k < I; ++k) {
+            red[(((wave - 1) * 3 + 0) * I + k) * 64 + lane] = LT::get(ax[k / W], k % W);
+            red[(((wave - 1) * 3 + 1) * I + k) * 64 + lane] = LT::get(ay[k / W], k % W);
+            red[(((wave - 1) * 3 + 2) * I + k) * 64 + lane] = LT::get(az[k / W], k % W);
+        }
+    }
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll 1
+    for (int w = 1; w < S; ++w) {
+#pragma unroll
+        for (int k = 0; k < I; ++k) {
+            LT::set(ax[k / W], k % W, LT::get(ax[k / W], k % W) + red[(((w - 1) * 3 + 0) * I + k) * 64 + lane]);
+            LT::set(ay[k / W], k % W, LT::get(ay[k / W], k % W) + red[(((w - 1) * 3 + 1) * I + k) * 64 + lane]);
+            LT::set(az[k / W], k % W, LT::get(az[k / W], k % W) + red[(((w - 1) * 3 + 2) * I + k) * 64 + lane]);
+        }
+    }
+    T* const self = s.work + static_cast<size_t>(c) * 3 * s.npad;
+#pragma unroll
+    for (int k = 0; k < I; ++k) {
+        const unsigned i = block_base + k * 64 + lane;
+        if (i >= s.n) continue;
+        self[i]                                   = LT::get(ax[k / W], k % W) * m_ref;
+        self[static_cast<size_t>(s.npad) + i]     = LT::get(ay[k / W], k % W) * m_ref;
+        self[2 * static_cast<size_t>(s.npad) + i] = LT::get(az[k / W], k % W) * m_ref;
+    }
+}
+
+// The second kernel: a body's i-side sums and reaction slots, added in a fixed order, then integrateBodies
+// (bodysystemcuda.cu:166-183): v = (v + a*dt)*damping; p += v*dt.
+template <typename T> __global__ __launch_bounds__(256) void pair_finish(PairArgs<T> s) {
+    using vec4       = typename Lane<T>::vec4;
+    const unsigned k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= s.n) return;
+    const size_t plane = s.npad;
+    T            f[3];
+#pragma unroll
+    for (int comp = 0; comp < 3; ++comp) {
+        T own = 0;
+        for (unsigned c = 0; c < s.splits; ++c) own += s.work[(static_cast<size_t>(c) * 3 + comp) * plane + k];
+        const T* r = s.work + (static_cast<size_t>(s.splits) * 3 + comp) * plane + k;  // slot q at r[q * 3 * plane]
+        T        t0 = 0, t1 = 0, t2 = 0, t3 = 0;  // four interleaved running sums: shorter chains, smaller rounding error
+        unsigned q  = 0;
+        for (; q + 4 <= s.slots; q += 4) {
+            t0 += r[(static_cast<size_t>(q) + 0) * 3 * plane];
+            t1 += r[(static_cast<size_t>(q) + 1) * 3 * plane];
+            t2 += r[(static_cast<size_t>(q) + 2) * 3 * plane];
+            t3 += r[(static_cast<size_t>(q) + 3) * 3 * plane];
+        }
+        for (; q < s.slots; ++q) t0 += r[static_cast<size_t>(q) * 3 * plane];
+        f[comp] = own - ((t0 + t1) + (t2 + t3));  // d = p_j - p_i: what body j feels from body i is -m_i d w
+    }
+    vec4 v  = reinterpret_cast<const vec4*>(s.vel)[k];
+    vec4 pn = reinterpret_cast<const vec4*>(s.old_pos)[k];
+    v.x     = __builtin_fma(f[0], s.dt, v.x) * s.damping;
+    v.y     = __builtin_fma(f[1], s.dt, v.y) * s.damping;
+    v.z     = __builtin_fma(f[2], s.dt, v.z) * s.damping;
+    pn.x    = __builtin_fma(v.x, s.dt, pn.x);
+    pn.y    = __builtin_fma(v.y, s.dt, pn.y);
+    pn.z    = __builtin_fma(v.z, s.dt, pn.z);
+    reinterpret_cast<vec4*>(s.new_pos)[k] = pn;
+    reinterpret_cast<vec4*>(s.vel)[k]     = v;
+}
+
+template <typename T, int R, int S> hipError_t launch_rs(const PairArgs<T>& args, const PairPlan& p, hipStream_t stream, bool prepare_only) {
+    if (p.lds_bytes > 64u * 1024u) {
+        if (const auto err = allow_large_lds<&pair_forces<T, R, S>>(); err != hipSuccess) return err;
+    }
+    if (prepare_only) return hipSuccess;
+    hipLaunchKernelGGL((pair_forces<T, R, S>), dim3(p.grid_blocks), dim3(64 * S), p.lds_bytes, stream, args);
+    if (const auto err = hipGetLastError(); err != hipSuccess) return err;
+    hipLaunchKernelGGL(pair_finish<T>, dim3((args.n + 255) / 256), dim3(256), 0, stream, args);
+    return hipGetLastError();
+}
+
+template <typename T, int R> hipError_t launch_r(const PairArgs<T>& args, const PairPlan& p, hipStream_t stream, bool prepare_only) {
+    switch (p.waves) {
+        case 4: return launch_rs<T, R, 4>(args, p, stream, prepare_only);
+        case 8: return launch_rs<T, R, 8>(args, p, stream, prepare_only);
+        case 16: return launch_rs<T, R, 16>(args, p, stream, prepare_only);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace
+
+// Geometry.  R = 4 vectors per lane (fp32: 8 bodies i, fp64: 4) is what 128 VGPRs hold and what amortises the 9 rotation
+// moves best; S = 8 waves per workgroup, two workgroups per CU.  C workgroups per block once the blocks alone do not fill
+// the chip twice over.
+template <typename T> PairPlan plan_pair(unsigned n, int cu_count, int ovr_r, int ovr_s, int ovr_c) {
+    constexpr int W = sizeof(T) == 4 ? 2 : 1;
+    PairPlan      p{};
+    int           R = 4, S = 8;
+    if (ovr_r == 1 || ovr_r == 2 || ovr_r == 4) R = ovr_r;
+    if (ovr_s == 4 || ovr_s == 8 || ovr_s == 16) S = ovr_s;
+    const unsigned block  = 64u * static_cast<unsigned>(R * W);
+    const unsigned blocks = (n + block - 1) / block;
+    const unsigned units  = (blocks / 2 + 1) * static_cast<unsigned>(R * W);
+    unsigned       C      = 1;
+    const unsigned want   = 2u * static_cast<unsigned>(cu_count) * 8u / static_cast<unsigned>(S);  // workgroups that fill every SIMD four deep
+    while (blocks * C < want && units / (C * 2 * static_cast<unsigned>(S)) >= 2) C *= 2;         // ... while a wave keeps >= 2 units
+    if (ovr_c > 0) C = static_cast<unsigned>(ovr_c);
+    p.vectors_per_lane = R;
+    p.waves            = S;
+    p.splits           = C;
+    p.blocks           = blocks;
+    p.block_bodies     = block;
+    p.slots            = blocks < 2 ? 0u : ((blocks & 1u) ? blocks / 2 : blocks / 2 - 1);
+    p.grid_blocks      = blocks * C;
+    p.lds_bytes        = static_cast<unsigned>(static_cast<size_t>(S) * 3 * R * W * 64 * sizeof(T)) + 256u;
+    p.workspace_bytes  = (static_cast<size_t>(C) + p.slots) * 3 * static_cast<size_t>(blocks) * block * sizeof(T);
+    return p;
+}
+
+template <typename T> hipError_t launch_pair(const Shard<T>& s, const PairPlan& p, void* workspace, hipStream_t stream, bool prepare_only) {
+    PairArgs<T> args{};
+    args.old_pos = s.old_pos, args.new_pos = s.new_pos, args.vel = s.vel, args.work = static_cast<T*>(workspace);
+    args.n = s.i_count, args.blocks = p.blocks, args.npad = p.blocks * p.block_bodies, args.splits = p.splits, args.slots = p.slots;
+    args.dt = s.dt, args.damping = s.damping, args.eps2 = s.eps2;
+    constexpr int W = sizeof(T) == 4 ? 2 : 1;
+    (void)W;
+    switch (p.vectors_per_lane) {
+        case 1: return launch_r<T, 1>(args, p, stream, prepare_only);
+        case 2: return launch_r<T, 2>(args, p, stream, prepare_only);
+        case 4: return launch_r<T, 4>(args, p, stream, prepare_only);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+template PairPlan   plan_pair<float>(unsigned, int, int, int, int);
+template PairPlan   plan_pair<double>(unsigned, int, int, int, int);
+template hipError_t launch_pair<float>(const Shard<float>&, const PairPlan&, void*, hipStream_t, bool);
+template hipError_t launch_pair<double>(const Shard<double>&, const PairPlan&, void*, hipStream_t, bool);
+
+}  // namespace nb

@@ -130,6 +130,24 @@ NB_API int nb_integrate_f64(double* new_positions, const double* old_positions, 
                             double delta_time, double damping, unsigned num_bodies, int block_size,
                             int mode, nb_stream_t stream);
 
+/* ---- the same step with a caller-owned WORKSPACE (new).  The reference kernel evaluates every directed interaction
+ *  (src/nbody/bodysystemcuda.cu:98-146: N^2 calls of bodyBodyInteraction per step).  Given scratch memory the FAST mode
+ *  evaluates every PAIR of bodies once and applies it to both (csrc/nbody_pair.hip: the bodies j and their reaction sums
+ *  rotate through the wavefront, the reaction sums leave through the workspace and a second kernel adds them in a fixed
+ *  order and integrates): same result up to summation order, about half the arithmetic.  The ownership rule stays the
+ *  reference's -- the library allocates nothing: the caller asks nb_workspace_bytes_*(N, mode) once (0 = this N / mode has
+ *  no use for a workspace), allocates that much device memory, and passes it to every step.  The contents need not be
+ *  preserved or cleared between steps, and one workspace serves any number of systems of that size on one stream.
+ *  With workspace == NULL, too few bytes, STRICT mode or a system too small to gain, nb_integrate_ws_* IS nb_integrate_*. */
+NB_API int nb_workspace_bytes_f32(unsigned num_bodies, int mode, size_t* bytes);
+NB_API int nb_workspace_bytes_f64(unsigned num_bodies, int mode, size_t* bytes);
+NB_API int nb_integrate_ws_f32(float* new_positions, const float* old_positions, float* velocities,
+                               float delta_time, float damping, unsigned num_bodies, int block_size, int mode,
+                               void* workspace, size_t workspace_bytes, nb_stream_t stream);
+NB_API int nb_integrate_ws_f64(double* new_positions, const double* old_positions, double* velocities,
+                               double delta_time, double damping, unsigned num_bodies, int block_size, int mode,
+                               void* workspace, size_t workspace_bytes, nb_stream_t stream);
+
 /* ---- sharded form for multi-GPU body sharding (new; the reference is single-GPU).
  *
  *  Bodies i in [i_begin, i_begin+i_count) accumulate the pull of bodies j in [j_begin, j_begin+j_count)
@@ -196,6 +214,12 @@ NB_API int nb_graph_create_f32(nb_graph_t* graph, float* position_a, float* posi
                                float delta_time, float damping, unsigned num_bodies, int block_size, int mode, unsigned steps);
 NB_API int nb_graph_create_f64(nb_graph_t* graph, double* position_a, double* position_b, double* velocities,
                                double delta_time, double damping, unsigned num_bodies, int block_size, int mode, unsigned steps);
+NB_API int nb_graph_create_ws_f32(nb_graph_t* graph, float* position_a, float* position_b, float* velocities,
+                                  float delta_time, float damping, unsigned num_bodies, int block_size, int mode, unsigned steps,
+                                  void* workspace, size_t workspace_bytes);   /* the steps are nb_integrate_ws_* */
+NB_API int nb_graph_create_ws_f64(nb_graph_t* graph, double* position_a, double* position_b, double* velocities,
+                                  double delta_time, double damping, unsigned num_bodies, int block_size, int mode, unsigned steps,
+                                  void* workspace, size_t workspace_bytes);
 NB_API int nb_graph_launch(nb_graph_t graph, nb_stream_t stream);
 NB_API int nb_graph_destroy(nb_graph_t graph);
 
@@ -213,6 +237,24 @@ NB_API int nb_plan_f32(unsigned i_count, unsigned j_count, nb_launch_plan_t* pla
 NB_API int nb_plan_f64(unsigned i_count, unsigned j_count, nb_launch_plan_t* plan);
 /* Override the automatic plan (0 = automatic) -- used by the tuning sweep in bench.py --sweep. */
 NB_API int nb_set_plan_override(int bodies_per_lane, int lanes_per_body, int tile_bodies);
+
+/* ... and of the pairwise layout behind nb_integrate_ws_* */
+typedef struct nb_pair_plan {
+    int      applies;          /* 1: nb_integrate_ws_* takes the pairwise layout for this N (FAST mode)              */
+    int      bodies_per_lane;  /* I: bodies i a lane holds for good                                                  */
+    int      waves_per_block;  /* S: waves of a workgroup; they share the bodies i and split the tiles of bodies j   */
+    unsigned splits;           /* C: workgroups per block of bodies i                                                */
+    unsigned blocks;           /* NB = ceil(N / block_bodies); block a meets blocks a .. a + NB/2 (mod NB)           */
+    unsigned block_bodies;     /* 64 * I                                                                             */
+    unsigned reaction_slots;   /* per body: partial reaction sums in the workspace                                   */
+    unsigned grid_blocks;
+    unsigned lds_bytes;
+    size_t   workspace_bytes;
+} nb_pair_plan_t;
+NB_API int nb_pair_plan_f32(unsigned num_bodies, nb_pair_plan_t* plan);
+NB_API int nb_pair_plan_f64(unsigned num_bodies, nb_pair_plan_t* plan);
+/* 0 = automatic; min_bodies: smallest system that takes the pairwise layout -- tuning sweeps (bench.py --pair-sweep). */
+NB_API int nb_set_pair_plan_override(int vectors_per_lane, int waves_per_block, int splits, int min_bodies);
 
 /* How many (kernel, device) pairs have been granted more than 64 KiB of dynamic LDS so far (the opt-in is made once per
  * kernel instantiation and device, on first use, and before any graph capture) -- tests. */

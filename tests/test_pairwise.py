@@ -1,0 +1,176 @@
+"""The pairwise FAST layout behind nb_integrate_ws_* (csrc/nbody_pair.hip): every pair of bodies evaluated once and applied to
+both, the reaction sums through a caller-owned workspace.  Everything goes through the C-ABI; the yardstick is an fp64 direct
+sum (oracle.accel_f64 / numpy long double), the same one the one-sided FAST kernel is held to -- the reference has no pairwise
+kernel to compare with (bodysystemcuda.cu:125-146 evaluates every directed interaction), so parity here means: the same
+accelerations as bodyBodyInteraction summed over all j, to fp32/fp64 summation accuracy.
+
+A step with zero velocities, dt = 1 and damping = 1 leaves v = a: the accelerations are read straight from the velocity array.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+
+from conftest import xyz
+from test_gpu_parity import direct_sum_f64
+
+pytestmark = pytest.mark.gpu
+
+
+def accel_ws(pkg, pos, dtype, workspace=True, softening=0.1):
+    """accelerations of all bodies through nb_integrate_ws_* (FAST): one step from rest with dt = 1"""
+    n = pos.size // 4
+    params = pkg.NBodyParams(softening=softening)
+    system = pkg.BodySystemHIP(n, 256, params, dtype, pos.astype(dtype), np.zeros(4 * n, dtype), mode=pkg.NB_MODE_FAST, workspace=workspace)
+    system.update(dtype(1))
+    acc = system.get_velocity().copy()
+    new_pos = system.get_position().copy()
+    system.free()
+    return acc, new_pos
+
+
+def random_bodies(oracle, n, seed=3, masses="unit"):
+    oracle.srand(seed)
+    pos, _ = oracle.randomise(0, n, 1.54, 8.0, np.float32)
+    m = pos.reshape(n, 4)[:, 3]
+    if masses == "ramp":
+        m[:] = np.linspace(0.5, 2.0, n).astype(np.float32)
+    elif masses == "species":  # three species in contiguous blocks whose borders fall inside tiles and blocks
+        m[n // 3 + 5:] = 2.0
+        m[2 * n // 3 + 11:] = 0.25
+    elif masses == "odd":  # zero, negative and huge masses sprinkled in; the first body (the reference mass) stays 1
+        m[1::7] = 0.0
+        m[3::11] = -1.5
+        m[5::13] = 1.0e6
+    elif masses == "first_zero":  # a reference mass the kernel must not divide by
+        m[0] = 0.0
+    return pos
+
+
+@pytest.mark.parametrize("plan", [(4, 8, 1), (4, 8, 2), (4, 16, 1), (4, 4, 3), (2, 8, 1), (2, 16, 2), (1, 8, 1), (1, 4, 5)])
+@pytest.mark.parametrize("n", [3000, 4096 + 64, 517])
+def test_pair_force_error_every_geometry_fp32(gpu, oracle, plan, n):
+    """Every (vectors per lane, waves, workgroups per block) instantiation, ragged body counts (a last block and a last tile
+    that are partly empty, odd and even block counts, a single block), masses from 0.5 to 2: against the fp64 direct sum."""
+    pos = random_bodies(oracle, n, masses="ramp")
+    gpu.set_pair_plan_override(*plan, 1)
+    try:
+        assert gpu.pair_plan(n, np.float32).applies == 1
+        acc, new_pos = accel_ws(gpu, pos, np.float32)
+    finally:
+        gpu.set_pair_plan_override(0, 0, 0, 0)
+    ref = oracle.accel_f64(pos, 0, n)
+    err = np.linalg.norm(xyz(acc) - ref, axis=1) / np.linalg.norm(ref, axis=1)
+    assert err.max() < 5e-6, err.max()
+    assert np.all(acc.reshape(n, 4)[:, 3] == 0)  # velocity .w is preserved (tipsy keeps eps there)
+    assert np.all(new_pos.reshape(n, 4)[:, 3] == pos.reshape(n, 4)[:, 3])  # and so is the mass
+
+
+@pytest.mark.parametrize("masses", ["unit", "species", "odd", "first_zero"])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_pair_mass_forms(gpu, oracle, dtype, masses):
+    """Unit-mass tiles (no mass multiply), tiles of mixed masses, zero / negative / huge masses, a first body of mass zero."""
+    n = 64 * 37 + 41
+    pos = random_bodies(oracle, n, seed=5, masses=masses)
+    gpu.set_pair_plan_override(0, 0, 0, 1)
+    try:
+        acc, _ = accel_ws(gpu, pos, dtype)
+    finally:
+        gpu.set_pair_plan_override(0, 0, 0, 0)
+    eps2 = float(np.float64(np.float32(0.1)) ** 2) if dtype == np.float64 else float(np.float32(0.1) * np.float32(0.1))
+    ref, size = direct_sum_f64(pos.reshape(n, 4).astype(np.float64), 0, n, 0, n, eps2)
+    # error relative to the sum of the magnitudes of a body's terms (what rounding scales with: with +-1e6 masses the terms cancel)
+    err = np.linalg.norm(xyz(acc).astype(np.float64) - ref, axis=1) / size
+    assert err.max() < (2e-6 if dtype == np.float32 else 1e-14), err.max()
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_pair_agrees_with_one_sided_kernel_and_is_reproducible(gpu, oracle, dtype):
+    n = 20000
+    pos0, vel0 = oracle.startup_state(n, np.float32)
+    runs = []
+    for ws in (True, True, False):
+        s = gpu.BodySystemHIP(n, 256, gpu.NBodyParams(), dtype, pos0.astype(dtype), vel0.astype(dtype), mode=gpu.NB_MODE_FAST, workspace=ws)
+        for _ in range(3):
+            s.update(dtype(np.float32(0.016)))
+        runs.append((s.get_position().copy(), s.get_velocity().copy()))
+        s.free()
+    assert runs[0][0].tobytes() == runs[1][0].tobytes() and runs[0][1].tobytes() == runs[1][1].tobytes()  # static work map: same bits every run
+    tol = 2e-5 if dtype == np.float32 else 1e-12
+    np.testing.assert_allclose(runs[0][0], runs[2][0], rtol=tol, atol=tol)
+    assert runs[0][0].tobytes() != runs[2][0].tobytes() or dtype == np.float64  # (another summation order: not the same kernel)
+
+
+def test_workspace_rules(gpu, oracle):
+    """nb_workspace_bytes_* says 0 where a workspace is of no use; too small a workspace, none at all, or STRICT mode make
+    nb_integrate_ws_* exactly nb_integrate_*; a workspace that overlaps the bodies is refused."""
+    lib = gpu.lib()
+    need = ctypes.c_size_t(1)
+    gpu.check(lib.nb_workspace_bytes_f32(1024, gpu.NB_MODE_FAST, ctypes.byref(need)))
+    assert need.value == 0  # too small a system to gain
+    gpu.check(lib.nb_workspace_bytes_f32(65536, gpu.NB_MODE_STRICT, ctypes.byref(need)))
+    assert need.value == 0  # STRICT keeps the CPU path's summation order
+    gpu.check(lib.nb_workspace_bytes_f32(65536, gpu.NB_MODE_FAST, ctypes.byref(need)))
+    plan = gpu.pair_plan(65536, np.float32)
+    assert need.value == plan.workspace_bytes > 0 and plan.applies == 1
+    assert plan.workspace_bytes == (plan.splits + plan.reaction_slots) * 3 * plan.blocks * plan.block_bodies * 4
+
+    n = 32768
+    pos0, vel0 = oracle.startup_state(n, np.float32)
+    gpu.set_softening_squared(np.float32(0.1) * np.float32(0.1))
+    bufs = [gpu.DeviceBuffer(pos0.nbytes) for _ in range(3)]
+    gpu.check(lib.nb_workspace_bytes_f32(n, gpu.NB_MODE_FAST, ctypes.byref(need)))
+    work = gpu.DeviceBuffer(need.value)
+
+    def step(mode, workspace, nbytes):
+        bufs[0].upload(pos0), bufs[2].upload(vel0)
+        gpu.check(lib.nb_integrate_ws_f32(bufs[1].ptr, bufs[0].ptr, bufs[2].ptr, np.float32(0.016), np.float32(1), n, 256, mode, workspace, nbytes, None), "nb_integrate_ws_f32")
+        return bufs[1].download(np.zeros_like(pos0)).copy()
+
+    def plain(mode):
+        bufs[0].upload(pos0), bufs[2].upload(vel0)
+        gpu.check(lib.nb_integrate_f32(bufs[1].ptr, bufs[0].ptr, bufs[2].ptr, np.float32(0.016), np.float32(1), n, 256, mode, None))
+        return bufs[1].download(np.zeros_like(pos0)).copy()
+
+    one_sided = plain(gpu.NB_MODE_FAST)
+    assert step(gpu.NB_MODE_FAST, None, 0).tobytes() == one_sided.tobytes()
+    assert step(gpu.NB_MODE_FAST, work.ptr, need.value - 4).tobytes() == one_sided.tobytes()
+    assert step(gpu.NB_MODE_STRICT, work.ptr, need.value).tobytes() == plain(gpu.NB_MODE_STRICT).tobytes()
+    pairwise = step(gpu.NB_MODE_FAST, work.ptr, need.value)
+    assert pairwise.tobytes() != one_sided.tobytes()
+    np.testing.assert_allclose(pairwise, one_sided, rtol=1e-5, atol=1e-5)
+    # the workspace may not overlap the bodies the launch reads
+    assert lib.nb_integrate_ws_f32(bufs[1].ptr, bufs[0].ptr, bufs[2].ptr, np.float32(0.016), np.float32(1), n, 256, gpu.NB_MODE_FAST, bufs[0].ptr, need.value, None) == 10001
+    assert lib.nb_integrate_ws_f32(bufs[0].ptr, bufs[0].ptr, bufs[2].ptr, np.float32(0.016), np.float32(1), n, 256, gpu.NB_MODE_FAST, work.ptr, need.value, None) == 10001
+    for b in bufs + [work]:
+        b.free()
+
+
+def test_pair_graph_replay_equals_the_step_loop(gpu, oracle):
+    n = 16384
+    pos0, vel0 = oracle.startup_state(n, np.float32)
+    a = gpu.BodySystemHIP(n, 256, gpu.NBodyParams(), np.float32, pos0, vel0, mode=gpu.NB_MODE_FAST, workspace=True)
+    b = gpu.BodySystemHIP(n, 256, gpu.NBodyParams(), np.float32, pos0, vel0, mode=gpu.NB_MODE_FAST, workspace=True)
+    assert a._workspace is not None
+    for _ in range(6):
+        a.update(np.float32(0.016))
+    b.update_many(np.float32(0.016), 6)
+    assert a.get_position().tobytes() == b.get_position().tobytes() and a.get_velocity().tobytes() == b.get_velocity().tobytes()
+    a.free(), b.free()
+
+
+@pytest.mark.parametrize("n,dtype", [(262144, np.float32), (1048576, np.float32), (262144, np.float64)])
+def test_pair_full_size_sampled_forces_and_momentum(gpu, oracle, n, dtype):
+    """BASELINE sizes: accelerations of 512 sampled bodies against the fp64 direct sum, and a size-independent property the
+    pairwise evaluation has by construction: what body i feels from j is, term by term, the opposite of what j feels from i,
+    so the total momentum change sum(m a) vanishes to summation accuracy."""
+    pos0, _ = oracle.startup_state(n, np.float32)
+    acc, _ = accel_ws(gpu, pos0, dtype)
+    a = xyz(acc).astype(np.float64)
+    rng = np.random.default_rng(7)
+    sample = np.sort(rng.choice(n, 512, replace=False))
+    ref = np.stack([oracle.accel_f64(pos0, int(i), 1)[0] for i in sample])
+    err = np.linalg.norm(a[sample] - ref, axis=1) / np.linalg.norm(ref, axis=1)
+    assert err.max() < (1e-5 if dtype == np.float32 else 1e-10), err.max()
+    total = np.abs(a.sum(axis=0)).max() / np.abs(a).sum(axis=0).max()
+    assert total < (1e-6 if dtype == np.float32 else 1e-14), total

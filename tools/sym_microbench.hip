@@ -170,7 +170,7 @@ template <int VARIANT, int R> __global__ __launch_bounds__(1024) void bench(Out*
 }
 
 template <int VARIANT, int R> void run(const char* name, const float4* bodies, Out* out, int block) {
-    const int rounds = 2000, grid = 256, waves = grid * block / 64;
+    const int rounds = 8000, grid = 256, waves = grid * block / 64;
     std::vector<Out> host(waves);
     for (int rep = 0; rep < 2; ++rep) {
         hipLaunchKernelGGL((bench<VARIANT, R>), dim3(grid), dim3(block), 0, nullptr, out, bodies, rounds);
@@ -188,7 +188,7 @@ template <int VARIANT, int R> void run(const char* name, const float4* bodies, O
                 step_cyc / directed, 30.75 / (step_cyc / directed));
 }
 
-int main() {
+int main(int argc, char**) {
     float4* bodies = nullptr;
     Out*    out    = nullptr;
     hipMalloc(&bodies, sizeof(float4) * 4096);
@@ -198,6 +198,11 @@ int main() {
     auto     rnd  = [&] { seed = seed * 1664525u + 1013904223u; return static_cast<float>(seed >> 8) / 16777216.0f * 10.0f - 5.0f; };
     for (auto& b : host) b = float4{rnd(), rnd(), rnd(), 1.0f};
     hipMemcpy(bodies, host.data(), sizeof(float4) * 4096, hipMemcpyHostToDevice);
+    if (argc > 1) {  // quick mode (for rocprofv3 --pmc): the production candidate only, long run
+        run<kBW, 4>("pairwise B, wave_ror:1 (64-lane rotation)", bodies, out, 1024);
+        run<kOne, 1>("one-sided, body j per lane", bodies, out, 1024);
+        return 0;
+    }
     for (int block : {256, 512, 1024}) {
         run<kOne, 1>("one-sided, body j per lane", bodies, out, block);
         run<kOne, 2>("one-sided, body j per lane", bodies, out, block);
