@@ -66,6 +66,9 @@ def parse_args():
                          "host: gloo + host-staged all-gather, so that several ranks can share ONE GPU (functional rehearsal of the "
                          "N-rank code path on a one-GPU box; RCCL refuses two ranks per device); host-tiles: the same rehearsal with the TILE "
                          "schedule (gloo send/recv rounds staged through host memory).  host* is never a performance number.")
+    ap.add_argument("--layout", choices=["pairwise", "one-sided"], default="pairwise",
+                    help="FAST on one GPU: pairwise = nb_integrate_ws_* with a caller-owned workspace (every pair of bodies evaluated once and "
+                         "applied to both, csrc/nbody_pair.hip); one-sided = nb_integrate_* (every directed interaction, as the reference kernel)")
     ap.add_argument("--dump-state", type=str, default="", help="rank 0 writes its final positions (.npy) here (tests)")
     ap.add_argument("--no-configs", action="store_true", help="skip the extra BASELINE configs timed after the headline measurement (N=1)")
     ap.add_argument("--launch-timeout", type=float, default=600.0,
@@ -180,8 +183,9 @@ FP64_ISSUE_CEILING_INTERACTIONS_PER_S = 1024 * 64 * 2.4e9 / 78.0
 
 
 def other_configs(pkg, lib, headline):
-    """BASELINE.json configs besides the headline one, plus STRICT (the parity-exact mode), each as
-    {workload, bodies, dtype, mode, steps, ms_per_step, interactions_per_s, frac}: 1 warm-up step, then K steps between two
+    """BASELINE.json configs besides the headline one, plus STRICT (the parity-exact mode) and, for FAST, both layouts
+    (pairwise = nb_integrate_ws_* with a workspace, one-sided = nb_integrate_*), each as
+    {workload, bodies, dtype, mode, layout, steps, ms_per_step, interactions_per_s, frac}: 1 warm-up step, then K steps between two
     HIP events on the launch stream (the reference's GPU protocol, compute_cuda.cpp:183-195); frac against the same
     vector-FMA peaks as the headline (20 flop per fp32 interaction, 30 per fp64: compute.cpp:16-18)."""
     cases = [
@@ -197,26 +201,32 @@ def other_configs(pkg, lib, headline):
     ]
     out = []
     for what, n, fp64, mode_name, steps in cases:
-        if (n, fp64, mode_name) == headline:
-            continue
         dtype = np.float64 if fp64 else np.float32
-        pos0, vel0 = make_bodies(n, dtype)
         mode = pkg.NB_MODE_FAST if mode_name == "fast" else pkg.NB_MODE_STRICT
-        system = pkg.BodySystemHIP(n, 256, pkg.NBodyParams(), dtype, pos0, vel0, mode=mode)
-        dt = dtype(np.float32(0.016))
-        system.update(dt)
-        e0, e1 = pkg.Event(), pkg.Event()
-        system.synchronize()
-        e0.record(None)
-        for _ in range(steps):
+        layouts = ["one-sided"] if mode_name == "fast" else ["strict"]
+        if mode_name == "fast" and pkg.workspace_bytes(n, dtype, mode):
+            layouts.insert(0, "pairwise")
+        pos0 = vel0 = None
+        for layout in layouts:
+            if (n, fp64, mode_name, layout) == headline:
+                continue
+            if pos0 is None:
+                pos0, vel0 = make_bodies(n, dtype)
+            system = pkg.BodySystemHIP(n, 256, pkg.NBodyParams(), dtype, pos0, vel0, mode=mode, workspace=(layout == "pairwise"))
+            dt = dtype(np.float32(0.016))
             system.update(dt)
-        e1.record(None)
-        e1.synchronize()
-        ms = e0.elapsed_ms(e1) / steps
-        system.free()
-        flops, peak = (30, FP64_VECTOR_PEAK_TFLOPS) if fp64 else (20, FP32_VECTOR_PEAK_TFLOPS)
-        out.append({"workload": what, "bodies": n, "dtype": "f64" if fp64 else "f32", "mode": mode_name, "steps": steps, "ms_per_step": ms,
-                    "interactions_per_s": float(n) * n / (ms * 1e-3), "frac": flops * float(n) * n / (ms * 1e-3) / (peak * 1e12)})
+            e0, e1 = pkg.Event(), pkg.Event()
+            system.synchronize()
+            e0.record(None)
+            for _ in range(steps):
+                system.update(dt)
+            e1.record(None)
+            e1.synchronize()
+            ms = e0.elapsed_ms(e1) / steps
+            system.free()
+            flops, peak = (30, FP64_VECTOR_PEAK_TFLOPS) if fp64 else (20, FP32_VECTOR_PEAK_TFLOPS)
+            out.append({"workload": what, "bodies": n, "dtype": "f64" if fp64 else "f32", "mode": mode_name, "layout": layout, "steps": steps, "ms_per_step": ms,
+                        "interactions_per_s": float(n) * n / (ms * 1e-3), "frac": flops * float(n) * n / (ms * 1e-3) / (peak * 1e12)})
     return out
 
 
@@ -295,6 +305,15 @@ def main():
     vel_t = torch.from_numpy(vel0.reshape(n, 4)).to(dev, tdtype)
     stream = torch.cuda.current_stream()
 
+    # scratch memory of the pairwise layout: caller-owned (a torch tensor here), sized by the library, contents irrelevant
+    work_t, work_bytes = None, 0
+    if args.layout == "pairwise" and world == 1 and not args.sweep and not args.emulate_gpus and not args.plan:
+        work_bytes = pkg.workspace_bytes(n, dtype, mode)
+        if work_bytes:
+            work_t = torch.empty(work_bytes, dtype=torch.uint8, device=dev)
+    pairwise = work_t is not None
+    ws_fn = lib.nb_integrate_ws_f64 if args.fp64 else lib.nb_integrate_ws_f32
+
     kernel_launches = [0]
 
     def launch(new_pos, old_pos, vel, acc, i0, ni, j0, nj, flags):
@@ -331,6 +350,8 @@ def main():
                                                 ctypes.c_void_p(stream.cuda_stream))
                     # bring the communicator up (channels, first-call set-up) outside any timed step, whatever --warmup says;
                     # every rank holds identical positions at this point, so exchanging them changes nothing
+                    if pairwise:
+                        capi_rank.set_workspace(work_t.data_ptr(), work_bytes)  # a world of one: the single-GPU step with its workspace
                     capi_rank.exchange_once(0)
                     torch.cuda.synchronize()
                 except pkg.NBodyHipError as exc:
@@ -346,7 +367,7 @@ def main():
 
         if capi_rank is not None:
             def step():
-                kernel_launches[0] += world  # one kernel per position tile
+                kernel_launches[0] += 1 if pairwise else world  # one kernel per position tile (a world of one with a workspace: one call)
                 capi_rank.update(dt, damping)
 
             finish = capi_rank.finish
@@ -392,7 +413,12 @@ def main():
 
         def step():
             r = state["read"]
-            launch(bufs[1 - r], bufs[r], vel_t, acc_t, 0, n, 0, n, pkg.NB_SHARD_FINALIZE)
+            if pairwise:
+                kernel_launches[0] += 1  # (one call = the forces kernel + the kernel that adds the reaction slots and integrates)
+                pkg.check(ws_fn(bufs[1 - r].data_ptr(), bufs[r].data_ptr(), vel_t.data_ptr(), dt, damping, n, 256, mode, work_t.data_ptr(), work_bytes,
+                                ctypes.c_void_p(stream.cuda_stream)), "nb_integrate_ws")
+            else:
+                launch(bufs[1 - r], bufs[r], vel_t, acc_t, 0, n, 0, n, pkg.NB_SHARD_FINALIZE)
             state["read"] = 1 - r
 
         def finish():
@@ -540,15 +566,20 @@ def main():
         per_launch_interactions = float(n) * float(n) * args.steps / max(launches, 1) / world
         achieved_tflops = flops_per * per_launch_interactions / (ms_per_launch * 1e-3) / 1e12
         plan = pkg.plan(n // world, n, dtype)
+        pair = pkg.pair_plan(n, dtype) if pairwise else None
         # HBM traffic cannot be counted from inside this process: it comes from the separate rocprofv3 --pmc passes
         # of this same command (tools/profile.sh -> tools/summarize_prof.py), committed under profiles/.
         traffic, traffic_src = None, None
         plan_now = {"bodies_per_lane": plan.bodies_per_lane, "lane_groups": plan.lanes_per_body, "lds_tile_bodies": plan.tile_bodies,
                     "grid": plan.grid_blocks, "lds_bytes": plan.lds_bytes}
+        if pairwise:
+            plan_now = {"layout": "pairwise", "bodies_per_lane": pair.bodies_per_lane, "waves_per_block": pair.waves_per_block, "workgroups_per_block": pair.splits,
+                        "blocks": pair.blocks, "block_bodies": pair.block_bodies, "reaction_slots": pair.reaction_slots, "grid": pair.grid_blocks,
+                        "lds_bytes": pair.lds_bytes, "workspace_bytes": pair.workspace_bytes}
         if world == 1 and args.mode == "fast":
             import glob
 
-            tag = f"n{n}_{'f64' if args.fp64 else 'f32'}"
+            tag = f"n{n}_{'f64' if args.fp64 else 'f32'}" + ("_pairwise" if pairwise else "")
             found = sorted(glob.glob(os.path.join(ROOT, "profiles", f"round*_{tag}_pmc_summary.json")))
             if found:
                 with open(found[-1]) as fh:
@@ -588,7 +619,9 @@ def main():
                     "only on round k, the own-slice chunk runs first" if capi_rank is not None else
                     "torch.distributed re-implementation (sharded.py) of the tile schedule: batch_isend_irecv rounds on RCCL's stream" if system.exchange == "tiles" else
                     "torch.distributed (sharded.py): RCCL all_gather_into_tensor of the new positions per step, overlapped with the own-slice j chunk"),
-                "step_entry_point": "nb_integrate_shard_*" if not distributed else ("nb_sharded_step_*" if capi_rank is not None else "sharded.py -> nb_integrate_shard_*"),
+                "layout": "pairwise (every pair of bodies evaluated once, reaction sums through a caller-owned workspace)" if pairwise else
+                          "one-sided (every directed interaction evaluated, as bodysystemcuda.cu:125-146 does)",
+                "step_entry_point": ("nb_integrate_ws_*" if pairwise else "nb_integrate_shard_*") if not distributed else ("nb_sharded_step_*" if capi_rank is not None else "sharded.py -> nb_integrate_shard_*"),
                 "kernel_plan": plan_now,
                 "device": info.name.decode(),
                 "arch": info.arch.decode(),
@@ -606,11 +639,20 @@ def main():
                 # achieved / what this instruction mix can issue at best on the chip (see FP32_ISSUE_CEILING_...): how close
                 # the kernel is to ITS ceiling; `frac` above is against the nominal "20 flop" peak
                 # (the ceilings are those of the FAST instruction mix; STRICT executes other, exactly rounded, operations)
-                "issue_ceiling_frac": None if args.mode != "fast" else value / world / (FP64_ISSUE_CEILING_INTERACTIONS_PER_S if args.fp64 else FP32_ISSUE_CEILING_INTERACTIONS_PER_S),
-                "issue_ceiling_interactions_per_s": None if args.mode != "fast" else (FP64_ISSUE_CEILING_INTERACTIONS_PER_S if args.fp64 else FP32_ISSUE_CEILING_INTERACTIONS_PER_S),
+                "issue_ceiling_frac": None if (args.mode != "fast" or pairwise) else value / world / (FP64_ISSUE_CEILING_INTERACTIONS_PER_S if args.fp64 else FP32_ISSUE_CEILING_INTERACTIONS_PER_S),
+                "issue_ceiling_interactions_per_s": None if (args.mode != "fast" or pairwise) else (FP64_ISSUE_CEILING_INTERACTIONS_PER_S if args.fp64 else FP32_ISSUE_CEILING_INTERACTIONS_PER_S),
                 "kernel_ms": ms_per_launch,
+                # pairwise layout: the step is two kernels (pair_forces, pair_finish) and evaluates each pair of bodies once; `achieved` and
+                # `frac` above count the ALGORITHMIC 20 (30) flop per directed interaction of the reference convention (compute.cpp:16-18),
+                # `executed` counts what the kernels really issue: 24 (36) flop per pair evaluation
+                "executed": None if not pairwise else {
+                    "pair_evaluations_per_launch": float(pair.blocks) * (pair.blocks // 2 + 1) * pair.block_bodies * pair.block_bodies,
+                    "flops_per_pair_evaluation": 36 if args.fp64 else 24,
+                    "tflops": (36 if args.fp64 else 24) * float(pair.blocks) * (pair.blocks // 2 + 1) * pair.block_bodies * pair.block_bodies / (ms_per_launch * 1e-3) / 1e12,
+                    "frac": (36 if args.fp64 else 24) * float(pair.blocks) * (pair.blocks // 2 + 1) * pair.block_bodies * pair.block_bodies / (ms_per_launch * 1e-3) / 1e12 / peak},
                 "algorithmic_flops_per_launch": flops_per * per_launch_interactions,
-                "algorithmic_hbm_bytes_per_launch": (128 if args.fp64 else 64) * (n // world),
+                # positions + velocities in and out; the pairwise layout also writes and reads its reaction slots once
+                "algorithmic_hbm_bytes_per_launch": (128 if args.fp64 else 64) * (n // world) + (2 * pair.workspace_bytes if pairwise else 0),
             },
         }
         if not args.no_cpu_baseline and world == 1:
@@ -645,7 +687,7 @@ def main():
             # The other BASELINE configs and the parity-exact mode, timed AFTER the headline measurement (never inside it)
             # so that one driver-run line carries them all.  A failure here costs only this list, never the headline.
             try:
-                line["configs"] = other_configs(pkg, lib, (n, args.fp64, args.mode))
+                line["configs"] = other_configs(pkg, lib, (n, args.fp64, args.mode, "pairwise" if pairwise else ("one-sided" if args.mode == "fast" else "strict")))
             except Exception as exc:  # noqa: BLE001
                 line["configs"] = [{"error": repr(exc)}]
         print(json.dumps(line), flush=True)

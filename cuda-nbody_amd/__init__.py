@@ -127,6 +127,7 @@ SIGNATURES = {
     "nb_comm_init_all": (_ci, [_P(_vp), _ci, _P(_ci)]),
     "nb_comm_destroy": (_ci, [_vp]),
     "nb_comm_info": (_ci, [_vp, _P(_ci), _P(_ci), _P(_ci)]),
+    "nb_comm_set_workspace": (_ci, [_vp, _vp, _sz]),
     "nb_sharded_step_f32": (_ci, [_vp, _vp, _vp, _vp, _vp, _cu, _cf, _cf, _ci, _ci, _vp]),
     "nb_sharded_step_f64": (_ci, [_vp, _vp, _vp, _vp, _vp, _cu, _cd, _cd, _ci, _ci, _vp]),
     "nb_sharded_step_all_f32": (_ci, [_P(_vp), _ci, _P(_vp), _P(_vp), _P(_vp), _P(_vp), _cu, _cf, _cf, _ci, _ci, _P(_vp)]),
@@ -431,6 +432,10 @@ class ShardedRank:
         self._tiles = lib().nb_exchange_tiles_f32 if f32 else lib().nb_exchange_tiles_f64
         self._scalar = np.float32 if f32 else float
 
+    def set_workspace(self, workspace, nbytes: int) -> None:
+        """nb_comm_set_workspace: lend this rank the scratch memory of workspace_bytes() (used by a world of one)."""
+        check(lib().nb_comm_set_workspace(self.comm, workspace, nbytes), "nb_comm_set_workspace")
+
     def update(self, delta_time, damping) -> None:
         """pos[1-read][own slice], vel[own slice] <- one step from pos[read]; then the tiles of pos[1-read] start moving."""
         check(self._step(self.comm, self.pos[1 - self.read], self.pos[self.read], self.vel, self.acc, self.n, self._scalar(delta_time),
@@ -451,6 +456,14 @@ class ShardedRank:
         if self.comm:
             lib().nb_comm_destroy(self.comm)
             self.comm = _vp()
+
+
+def workspace_bytes(num_bodies: int, dtype=np.float32, mode: int = NB_MODE_FAST) -> int:
+    """nb_workspace_bytes_*: scratch memory nb_integrate_ws_* wants for this system (0 = none)."""
+    need = _sz(0)
+    fn = lib().nb_workspace_bytes_f32 if np.dtype(dtype) == np.float32 else lib().nb_workspace_bytes_f64
+    check(fn(num_bodies, mode, ctypes.byref(need)), "nb_workspace_bytes")
+    return need.value
 
 
 def comm_unique_id() -> bytes:

@@ -103,6 +103,8 @@ struct Comm {
     hipEvent_t  ready  = nullptr;          // "what the exchange has to wait for has been enqueued" (recorded on the compute stream)
     std::vector<hipEvent_t> arrived;       // [world]: arrived[p] = the round that brings rank p's tile is done
     const void* in_flight = nullptr;       // the array whose tiles are (or were last) being exchanged
+    void*       workspace = nullptr;       // caller-owned scratch memory (nb_comm_set_workspace): a world of one steps through nb_integrate_ws_*
+    size_t      workspace_bytes = 0;
     std::vector<Comm*> group;              // all local ranks of this communicator (just {this} with one process per GPU)
 };
 
@@ -205,12 +207,18 @@ int exchange_tiles(const std::vector<Comm*>& locals, void* const* positions, uns
 template <typename T> struct Api;
 template <> struct Api<float> {
     static constexpr int nccl_type = ncclFloat32;
+    static int whole(float* np, const float* op, float* v, float dt, float damping, unsigned n, int bs, int mode, void* ws, size_t bytes, nb_stream_t s) {
+        return nb_integrate_ws_f32(np, op, v, dt, damping, n, bs, mode, ws, bytes, s);
+    }
     static int shard(float* np, const float* op, float* v, float* a, unsigned i0, unsigned ni, unsigned j0, unsigned nj, unsigned flags, float dt, float damping, int bs, int mode, nb_stream_t s) {
         return nb_integrate_shard_f32(np, op, v, a, i0, ni, j0, nj, flags, dt, damping, bs, mode, s);
     }
 };
 template <> struct Api<double> {
     static constexpr int nccl_type = ncclFloat64;
+    static int whole(double* np, const double* op, double* v, double dt, double damping, unsigned n, int bs, int mode, void* ws, size_t bytes, nb_stream_t s) {
+        return nb_integrate_ws_f64(np, op, v, dt, damping, n, bs, mode, ws, bytes, s);
+    }
     static int shard(double* np, const double* op, double* v, double* a, unsigned i0, unsigned ni, unsigned j0, unsigned nj, unsigned flags, double dt, double damping, int bs, int mode, nb_stream_t s) {
         return nb_integrate_shard_f64(np, op, v, a, i0, ni, j0, nj, flags, dt, damping, bs, mode, s);
     }
@@ -237,6 +245,11 @@ int sharded_step(nb_comm_t const* comms, int n_local, T* const* new_pos, const T
         hipStream_t   stream   = reinterpret_cast<hipStream_t>(streams[k]);
         const bool    waiting  = c->in_flight == static_cast<const void*>(old_pos[k]);  // else: every rank holds the whole array already
         const unsigned i0      = static_cast<unsigned>(c->rank) * ni;
+        if (G == 1 && c->workspace != nullptr) {  // one rank holds every body: the single-GPU step, with its workspace
+            const int rc = Api<T>::whole(new_pos[k], old_pos[k], vel[k], dt, damping, num_bodies, block_size, mode, c->workspace, c->workspace_bytes, streams[k]);
+            if (rc != 0) return rc;
+            continue;
+        }
         for (int t = 0; t < G; ++t) {
             // FAST: own slice, then the tiles in arrival order (rank+1, rank+2, ...); STRICT: ascending rank = ascending j
             const int  peer = mode == NB_MODE_STRICT ? t : (c->rank + t) % G;
@@ -352,6 +365,14 @@ int nb_comm_destroy(nb_comm_t comm) {
         if (Rccl* lib = rccl(); lib != nullptr) (void)lib->CommDestroy(c->nccl);
     free_resources(c);
     delete c;
+    return 0;
+}
+
+int nb_comm_set_workspace(nb_comm_t comm, void* workspace, size_t workspace_bytes) {
+    Comm* c = as_comm(comm);
+    if (c == nullptr || (workspace == nullptr && workspace_bytes != 0)) return NB_ERR_INVALID_ARGUMENT;
+    c->workspace       = workspace;
+    c->workspace_bytes = workspace_bytes;
     return 0;
 }
 

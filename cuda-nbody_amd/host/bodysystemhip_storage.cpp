@@ -40,9 +40,33 @@ template <std::floating_point T, template <std::floating_point> class Storage> a
 // (bodysystemcuda_default.cu:19-24).  Asynchronous on the default stream.
 template <std::floating_point T, template <std::floating_point> class Storage> auto BodySystemHIPStored<T, Storage>::update(T deltaTime) -> void {
     this->apply_softening();
-    integrateNbodySystem<T>(storage_.position_ptr(this->current_write_), storage_.position_ptr(this->current_read_), storage_.velocity_ptr(), this->current_read_, deltaTime, this->damping_, this->nb_bodies_,
-                            static_cast<int>(this->block_size_));
+    ensure_workspace();
+    if (workspace_bytes_ != 0) {
+        integrateNbodySystemWs<T>(storage_.position_ptr(this->current_write_), storage_.position_ptr(this->current_read_), storage_.velocity_ptr(), this->current_read_, deltaTime, this->damping_, this->nb_bodies_,
+                                  static_cast<int>(this->block_size_), workspace_.data(), workspace_bytes_);
+    } else {
+        integrateNbodySystem<T>(storage_.position_ptr(this->current_write_), storage_.position_ptr(this->current_read_), storage_.velocity_ptr(), this->current_read_, deltaTime, this->damping_, this->nb_bodies_,
+                                static_cast<int>(this->block_size_));
+    }
     std::swap(this->current_read_, this->current_write_);
+}
+
+// The library allocates nothing (the reference's ownership rule): the body system asks how much scratch memory the current
+// mode wants for this many bodies and owns it, like its three body arrays.
+template <std::floating_point T, template <std::floating_point> class Storage> auto BodySystemHIPStored<T, Storage>::ensure_workspace() -> void {
+    const int mode = (Storage<T>::workspace_capable && nbody_hip::use_workspace()) ? nbody_hip::integration_mode() : -2;
+    if (mode == workspace_mode_) return;
+    workspace_mode_  = mode;
+    std::size_t need = 0;
+    if (mode >= 0) {
+        if constexpr (std::same_as<T, float>) {
+            hip_check(nb_workspace_bytes_f32(this->nb_bodies_, mode, &need), "nb_workspace_bytes_f32");
+        } else {
+            hip_check(nb_workspace_bytes_f64(this->nb_bodies_, mode, &need), "nb_workspace_bytes_f64");
+        }
+    }
+    if (need > workspace_.size()) workspace_ = DeviceArray<unsigned char>(need);
+    workspace_bytes_ = need;
 }
 
 template <std::floating_point T, template <std::floating_point> class Storage> auto BodySystemHIPStored<T, Storage>::drop_graph() noexcept -> void {
@@ -56,8 +80,10 @@ template <std::floating_point T, template <std::floating_point> class Storage> a
     const auto mode = nbody_hip::integration_mode();
     // everything nb_graph_create_* bakes into the captured launches is part of the key: dt, step count, which buffer is
     // read first, mode, and -- kernel arguments too -- this system's damping and softening^2 (update_params changes them)
+    ensure_workspace();
+    const void* const workspace = workspace_bytes_ != 0 ? workspace_.data() : nullptr;
     if (graph_ != nullptr && graph_dt_ == deltaTime && graph_steps_ == steps && graph_read_ == this->current_read_ && graph_mode_ == mode && graph_damping_ == this->damping_ &&
-        graph_softening_squared_ == this->softening_squared_) {
+        graph_softening_squared_ == this->softening_squared_ && graph_workspace_ == workspace) {
         return;
     }
     drop_graph();
@@ -66,13 +92,13 @@ template <std::floating_point T, template <std::floating_point> class Storage> a
     T*  to   = storage_.position_ptr(this->current_write_);
     int status;
     if constexpr (std::same_as<T, float>) {
-        status = nb_graph_create_f32(&graph_, from, to, storage_.velocity_ptr(), deltaTime, this->damping_, this->nb_bodies_, static_cast<int>(this->block_size_), mode, steps);
+        status = nb_graph_create_ws_f32(&graph_, from, to, storage_.velocity_ptr(), deltaTime, this->damping_, this->nb_bodies_, static_cast<int>(this->block_size_), mode, steps, workspace_.data(), workspace_bytes_);
     } else {
-        status = nb_graph_create_f64(&graph_, from, to, storage_.velocity_ptr(), deltaTime, this->damping_, this->nb_bodies_, static_cast<int>(this->block_size_), mode, steps);
+        status = nb_graph_create_ws_f64(&graph_, from, to, storage_.velocity_ptr(), deltaTime, this->damping_, this->nb_bodies_, static_cast<int>(this->block_size_), mode, steps, workspace_.data(), workspace_bytes_);
     }
     hip_check(status, "nb_graph_create");
     graph_dt_ = deltaTime, graph_steps_ = steps, graph_read_ = this->current_read_, graph_mode_ = mode;
-    graph_damping_ = this->damping_, graph_softening_squared_ = this->softening_squared_;
+    graph_damping_ = this->damping_, graph_softening_squared_ = this->softening_squared_, graph_workspace_ = workspace;
 }
 
 template <std::floating_point T, template <std::floating_point> class Storage> auto BodySystemHIPStored<T, Storage>::update_many(T deltaTime, unsigned steps) -> void {

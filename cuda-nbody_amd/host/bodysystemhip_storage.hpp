@@ -37,6 +37,8 @@ template <std::floating_point T> class DeviceStorage {
         return host_vel_;
     }
     constexpr static bool graph_capable = true;  // plain device pointers: the step loop can be captured in a hipGraph
+    // the pairwise FAST layout re-reads the bodies j once per workgroup with vector loads: fine from HBM
+    constexpr static bool workspace_capable = true;
 
  private:
     std::array<DeviceArray<T>, 2> pos_;
@@ -72,6 +74,8 @@ template <std::floating_point T> class MappedStorage {
         return {vel_.host_ptr(), values_};
     }
     constexpr static bool graph_capable = true;
+    // ... and not over PCIe: mapped host memory keeps the one-sided kernels (bodies j through the scalar cache)
+    constexpr static bool workspace_capable = false;
 
  private:
     std::array<MappedArray<T>, 2> pos_;
@@ -99,8 +103,14 @@ template <std::floating_point T, template <std::floating_point> class Storage> c
  private:
     auto rewind() noexcept -> void;  // set_* restart the ping-pong at read = 0 / write = 1
     auto drop_graph() noexcept -> void;
+    auto ensure_workspace() -> void;  // (re)allocates what nb_workspace_bytes_* asks for in the current mode; 0 bytes = none
 
     Storage<T> storage_{static_cast<std::size_t>(this->nb_bodies_) * 4};
+
+    // scratch memory of the pairwise FAST layout (nb_integrate_ws_*): owned here, as the three body arrays are
+    DeviceArray<unsigned char> workspace_;
+    std::size_t                workspace_bytes_ = 0;
+    int                        workspace_mode_  = -1;
 
     // captured step loop (nb_graph_*): valid for one (dt, steps, read index, mode, damping, softening^2) combination
     nb_graph_t   graph_       = nullptr;
@@ -110,6 +120,7 @@ template <std::floating_point T, template <std::floating_point> class Storage> c
     int          graph_mode_  = 0;
     T            graph_damping_           = 0;
     T            graph_softening_squared_ = 0;
+    const void*  graph_workspace_         = nullptr;
 };
 
 template <std::floating_point T> using BodySystemHIPDefault    = BodySystemHIPStored<T, DeviceStorage>;

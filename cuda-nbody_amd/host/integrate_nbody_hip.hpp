@@ -9,6 +9,7 @@
 #include "hip_check.hpp"
 
 #include <concepts>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 
@@ -18,6 +19,13 @@ namespace nbody_hip {
 inline int& integration_mode() {
     static int mode = NB_MODE_FAST;
     return mode;
+}
+// Extension: body systems that own device memory also own the scratch memory nb_workspace_bytes_* asks for, and step through
+// nb_integrate_ws_* (FAST mode then evaluates every pair of bodies once, csrc/nbody_pair.hip).  `nbody --no-workspace`
+// switches it off: every step is then exactly the reference-shaped integrateNbodySystem below.
+inline bool& use_workspace() {
+    static bool on = true;
+    return on;
 }
 }  // namespace nbody_hip
 
@@ -32,6 +40,23 @@ void integrateNbodySystem(T* new_positions, const T* old_positions, T* velocitie
     } else {
         static_assert(std::same_as<T, double>, "float or double");
         status = nb_integrate_f64(new_positions, old_positions, velocities, deltaTime, damping, numBodies, blockSize, nbody_hip::integration_mode(), nullptr);
+    }
+    if (status != 0) {
+        std::fprintf(stderr, "%s(%i) : HIP error : Kernel execution failed : (%d) %s.\n", __FILE__, __LINE__, status, nb_error_string(status));
+        std::exit(EXIT_FAILURE);
+    }
+}
+
+// The same seam with a caller-owned workspace (include/nbody_hip.h, nb_integrate_ws_*): same arguments, same error behaviour.
+template <std::floating_point T>
+void integrateNbodySystemWs(T* new_positions, const T* old_positions, T* velocities, [[maybe_unused]] unsigned int currentRead, T deltaTime, T damping, unsigned int numBodies, int blockSize, void* workspace,
+                            std::size_t workspace_bytes) {
+    int status;
+    if constexpr (std::same_as<T, float>) {
+        status = nb_integrate_ws_f32(new_positions, old_positions, velocities, deltaTime, damping, numBodies, blockSize, nbody_hip::integration_mode(), workspace, workspace_bytes, nullptr);
+    } else {
+        static_assert(std::same_as<T, double>, "float or double");
+        status = nb_integrate_ws_f64(new_positions, old_positions, velocities, deltaTime, damping, numBodies, blockSize, nbody_hip::integration_mode(), workspace, workspace_bytes, nullptr);
     }
     if (status != 0) {
         std::fprintf(stderr, "%s(%i) : HIP error : Kernel execution failed : (%d) %s.\n", __FILE__, __LINE__, status, nb_error_string(status));

@@ -6,7 +6,7 @@
 //                     --tipsy=<file> -i,--iterations=<n> --blockSize=<n>      (single-dash spellings accepted too)
 //   extensions      : --numdevices=<n> | --devices=<list> (the NVIDIA sample's -numdevices, which this fork of it dropped)
 //                     --mode=fast|strict  --config=shell|random|expand  --demo=<0..6>  --steps=<n>  --dump=<file>
-//                     --seed=<n>  --graph  --inject-error=<x> (test hook for --compare)
+//                     --seed=<n>  --graph  --no-workspace  --inject-error=<x> (test hook for --compare)
 #include "compute.hpp"
 #include "integrate_nbody_hip.hpp"
 
@@ -48,6 +48,7 @@ struct Options {
     std::filesystem::path dump;
     std::optional<unsigned> seed;
     bool                  graph = false;
+    bool                  no_workspace = false;
     std::vector<int>      devices;  // --numdevices=<n> (devices 0..n-1) or --devices=<a,b,...>: bodies sharded over several GPUs
     std::optional<std::size_t> demo;   // row of Compute::demo_params (the reference reaches them from the viewer's keys only)
     double                inject_error = 0.0;
@@ -78,6 +79,8 @@ Options:
   --dump TEXT                 Write final positions then velocities (raw little-endian T[4N] each) to this file
   --seed UINT                 srand() this value first (the reference never seeds: default stream = seed 1)
   --graph                     --benchmark issues its (even number of) iterations as one captured hipGraph
+  --no-workspace              Fast mode without scratch memory: every directed interaction evaluated, as the reference kernel does
+                              (default: the body system owns a workspace and every PAIR of bodies is evaluated once)
   --inject-error FLOAT        Test hook: added to body 0's x of the fast result before --compare checks it
 )";
 
@@ -136,6 +139,7 @@ auto parse_args(int argc, char** argv) -> std::pair<Status, Options> {
         else if (name == "qatest") ok = flag(options.qatest);
         else if (name == "cpu") ok = flag(options.cpu);
         else if (name == "graph") ok = flag(options.graph);
+        else if (name == "no-workspace" || name == "no_workspace") ok = flag(options.no_workspace);
         else if (name == "numbodies") {
             const auto v = take_value();
             ok           = v && parse_number(*v, options.numbodies) && options.numbodies >= 1;
@@ -239,6 +243,7 @@ auto main(int argc, char** argv) -> int {
 
         if (cmd_options.seed) std::srand(*cmd_options.seed);
         nbody_hip::integration_mode() = cmd_options.mode;
+        nbody_hip::use_workspace()    = !cmd_options.no_workspace;
 
         const auto compare_to_cpu = (cmd_options.compare || cmd_options.qatest) && (!cmd_options.cpu);
         const auto headless_run   = cmd_options.benchmark || compare_to_cpu || cmd_options.steps > 0 || !cmd_options.dump.empty();

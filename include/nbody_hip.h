@@ -185,6 +185,10 @@ NB_API int nb_comm_init_rank(nb_comm_t* comm, const void* id, int world_size, in
 NB_API int nb_comm_init_all(nb_comm_t* comms /* [num_devices] */, int num_devices, const int* devices /* NULL = 0..n-1 */);
 NB_API int nb_comm_destroy(nb_comm_t comm);
 NB_API int nb_comm_info(nb_comm_t comm, int* rank, int* world_size, int* device);
+/* Lend a rank the scratch memory of nb_workspace_bytes_*(N, mode) (caller-owned, as everywhere): a communicator of ONE rank
+ * then steps through nb_integrate_ws_* -- the 1-GPU point of a scaling series is the best single-GPU step.  With more
+ * ranks the workspace is not used yet (the tiles are rectangles of the pair matrix). */
+NB_API int nb_comm_set_workspace(nb_comm_t comm, void* workspace, size_t workspace_bytes);
 NB_API int nb_sharded_step_f32(nb_comm_t comm, float* new_positions, const float* old_positions, float* velocities, float* acc,
                                unsigned num_bodies, float delta_time, float damping, int block_size, int mode, nb_stream_t stream);
 NB_API int nb_sharded_step_f64(nb_comm_t comm, double* new_positions, const double* old_positions, double* velocities, double* acc,

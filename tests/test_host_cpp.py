@@ -239,13 +239,36 @@ def test_cli_fast_hostmem_equals_device_memory_bitwise(tmp_path, flags):
     memory (--hostmem) the run must produce the same bits as with device arrays -- same kernel, same data, and FAST is
     deterministic from run to run."""
     dumps = []
-    for extra in ([], ["--hostmem"]):
+    for extra in (["--no-workspace"], ["--hostmem"]):  # (device arrays would own a workspace and take the pairwise layout)
         dump = tmp_path / ("state" + "_".join(extra) + ".bin")
         r = run_cli("--numbodies=32768", "--steps=3", f"--dump={dump}", *flags, *extra)
         assert r.returncode == 0, r.stderr
         dumps.append(np.fromfile(dump, dtype=np.uint8))
     assert dumps[0].size == 32768 * 8 * (8 if flags else 4)
     assert dumps[0].tobytes() == dumps[1].tobytes()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flags", [[], ["--fp64"]])
+def test_cli_owns_a_workspace_by_default(tmp_path, flags):
+    """BodySystemHIPDefault owns the scratch memory nb_workspace_bytes_* asks for and steps through nb_integrate_ws_*: at
+    32 768 bodies that is the pairwise layout.  Same trajectory as --no-workspace (the one-sided kernel) up to summation order,
+    not the same bits; --compare passes; --benchmark (plain loop and captured as a hipGraph) prints the reference's lines."""
+    dumps = {}
+    for name, extra in (("default", []), ("again", []), ("one_sided", ["--no-workspace"])):
+        dump = tmp_path / f"state_{name}.bin"
+        r = run_cli("--numbodies=32768", "--steps=4", f"--dump={dump}", *flags, *extra)
+        assert r.returncode == 0, r.stderr
+        dumps[name] = np.fromfile(dump, dtype=np.float64 if flags else np.float32)
+    assert dumps["default"].tobytes() == dumps["again"].tobytes()  # reproducible from run to run
+    assert dumps["default"].tobytes() != dumps["one_sided"].tobytes()
+    tol = 1e-11 if flags else 5e-5
+    np.testing.assert_allclose(dumps["default"], dumps["one_sided"], rtol=tol, atol=tol)
+    r = run_cli("--compare", "--numbodies=32768", *flags)
+    assert r.returncode == 0 and "  OK" in r.stdout, r.stdout + r.stderr
+    for extra in ([], ["--graph"]):
+        r = run_cli("--benchmark", "--numbodies=32768", "-i", "4", *flags, *extra)
+        assert r.returncode == 0 and "billion interactions per second" in r.stdout, r.stdout + r.stderr
 
 
 @pytest.mark.gpu
