@@ -116,12 +116,13 @@ struct StepGraph {
     hipGraphExec_t exec  = nullptr;
 };
 
-// Fewer bodies than this and the pairwise layout loses to the one-sided kernels (measured: profiles/round3_pair_crossover.txt)
-constexpr unsigned kPairMinBodies = 16384;
+// Fewer bodies than this and the pairwise layout loses to the one-sided kernels (measured: profiles/round3_pair_crossover_*.jsonl:
+// fp32 8 192 bodies 33.5 against 27.1 us, 12 288 bodies 53.3 against 61.9 us; fp64 4 096: 29.6 / 18.8 us, 8 192: 50.5 / 55.2 us)
+template <typename T> constexpr unsigned kPairMinBodies = sizeof(T) == 4 ? 12288u : 8192u;
 
 template <typename T> bool pair_applies(unsigned n, int mode, nb::PairPlan* plan) {
     const int floor_bodies = g_pair_min.load();
-    if (mode != NB_MODE_FAST || n < (floor_bodies > 0 ? static_cast<unsigned>(floor_bodies) : kPairMinBodies)) return false;
+    if (mode != NB_MODE_FAST || n < (floor_bodies > 0 ? static_cast<unsigned>(floor_bodies) : kPairMinBodies<T>)) return false;
     *plan = nb::plan_pair<T>(n, cu_count_cached(), g_pair_r.load(), g_pair_s.load(), g_pair_c.load());
     return true;
 }

@@ -324,28 +324,40 @@ template <typename T, int R, int S> __global__ __launch_bounds__(64 * S) __attri
 }
 
 // The second kernel: a body's i-side sums and reaction slots, added in a fixed order, then integrateBodies
-// (bodysystemcuda.cu:166-183): v = (v + a*dt)*damping; p += v*dt.
+// (bodysystemcuda.cu:166-183): v = (v + a*dt)*damping; p += v*dt.  A 256-thread workgroup takes 64 bodies: wave w adds the
+// slots q = w, w+4, w+8, ... (four interleaved running sums: shorter chains, smaller rounding error, coalesced reads), the
+// four are combined as (t0 + t1) + (t2 + t3) through LDS -- the same order for any launch geometry.
 template <typename T> __global__ __launch_bounds__(256) void pair_finish(PairArgs<T> s) {
-    using vec4       = typename Lane<T>::vec4;
-    const unsigned k = blockIdx.x * 256 + threadIdx.x;
-    if (k >= s.n) return;
-    const size_t plane = s.npad;
-    T            f[3];
+    using vec4 = typename Lane<T>::vec4;
+    __shared__ T   part[3][3][64];  // [wave 1..3][component][body]
+    const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned k    = blockIdx.x * 64 + lane;
+    const bool     live = k < s.n;
+    const size_t   plane = s.npad;
+    T              t[3] = {0, 0, 0};
+    if (live) {
+#pragma unroll
+        for (int comp = 0; comp < 3; ++comp) {
+            const T* r = s.work + (static_cast<size_t>(s.splits) * 3 + comp) * plane + k;  // slot q at r[q * 3 * plane]
+            T        sum = 0;
+            for (unsigned q = wave; q < (s.slots & ~3u); q += 4) sum += r[static_cast<size_t>(q) * 3 * plane];
+            if (wave == 0)
+                for (unsigned q = s.slots & ~3u; q < s.slots; ++q) sum += r[static_cast<size_t>(q) * 3 * plane];  // the odd slots join t0
+            t[comp] = sum;
+        }
+    }
+    if (wave != 0) {
+#pragma unroll
+        for (int comp = 0; comp < 3; ++comp) part[wave - 1][comp][lane] = t[comp];
+    }
+    __syncthreads();
+    if (wave != 0 || !live) return;
+    T f[3];
 #pragma unroll
     for (int comp = 0; comp < 3; ++comp) {
         T own = 0;
         for (unsigned c = 0; c < s.splits; ++c) own += s.work[(static_cast<size_t>(c) * 3 + comp) * plane + k];
-        const T* r = s.work + (static_cast<size_t>(s.splits) * 3 + comp) * plane + k;  // slot q at r[q * 3 * plane]
-        T        t0 = 0, t1 = 0, t2 = 0, t3 = 0;  // four interleaved running sums: shorter chains, smaller rounding error
-        unsigned q  = 0;
-        for (; q + 4 <= s.slots; q += 4) {
-            t0 += r[(static_cast<size_t>(q) + 0) * 3 * plane];
-            t1 += r[(static_cast<size_t>(q) + 1) * 3 * plane];
-            t2 += r[(static_cast<size_t>(q) + 2) * 3 * plane];
-            t3 += r[(static_cast<size_t>(q) + 3) * 3 * plane];
-        }
-        for (; q < s.slots; ++q) t0 += r[static_cast<size_t>(q) * 3 * plane];
-        f[comp] = own - ((t0 + t1) + (t2 + t3));  // d = p_j - p_i: what body j feels from body i is -m_i d w
+        f[comp] = own - ((t[comp] + part[0][comp][lane]) + (part[1][comp][lane] + part[2][comp][lane]));  // d = p_j - p_i: what body j feels from body i is -m_i d w
     }
     vec4 v  = reinterpret_cast<const vec4*>(s.vel)[k];
     vec4 pn = reinterpret_cast<const vec4*>(s.old_pos)[k];
@@ -366,7 +378,7 @@ template <typename T, int R, int S> hipError_t launch_rs(const PairArgs<T>& args
     if (prepare_only) return hipSuccess;
     hipLaunchKernelGGL((pair_forces<T, R, S>), dim3(p.grid_blocks), dim3(64 * S), p.lds_bytes, stream, args);
     if (const auto err = hipGetLastError(); err != hipSuccess) return err;
-    hipLaunchKernelGGL(pair_finish<T>, dim3((args.n + 255) / 256), dim3(256), 0, stream, args);
+    hipLaunchKernelGGL(pair_finish<T>, dim3((args.n + 63) / 64), dim3(256), 0, stream, args);
     return hipGetLastError();
 }
 
@@ -381,22 +393,32 @@ template <typename T, int R> hipError_t launch_r(const PairArgs<T>& args, const 
 
 }  // namespace
 
-// Geometry.  R = 4 vectors per lane (fp32: 8 bodies i, fp64: 4) is what 128 VGPRs hold and what amortises the 9 rotation
-// moves best; S = 8 waves per workgroup, two workgroups per CU.  C workgroups per block once the blocks alone do not fill
-// the chip twice over.
+// Geometry (measured: tools/pair_crossover.py -> profiles/round3_pair_crossover_f32.jsonl, _f64.jsonl).
+//   R = 4 vectors per lane (fp32: 8 bodies i, fp64: 4) is what 128 VGPRs hold and what amortises the 9 rotation moves best;
+//   smaller systems take R = 2: twice the blocks, so twice the workgroups to spread over the chip.
+//   S = 8 waves per workgroup, two workgroups per CU (fp64 from 65 536 bodies: S = 16, one per CU, 2-3 % better).
+//   C workgroups share a block of bodies i (and split its tiles) while the blocks alone do not fill the chip.
 template <typename T> PairPlan plan_pair(unsigned n, int cu_count, int ovr_r, int ovr_s, int ovr_c) {
     constexpr int W = sizeof(T) == 4 ? 2 : 1;
+    (void)cu_count;
     PairPlan      p{};
     int           R = 4, S = 8;
+    unsigned      C = 1;
+    if (sizeof(T) == 4) {
+        R = n < 32768 ? 2 : 4;
+        C = n < 32768 ? (n <= 16384 ? 4 : 8) : (n < 262144 ? 4 : 1);
+    } else {
+        R = n < 16384 ? 2 : 4;
+        S = n >= 65536 ? 16 : 8;
+        C = n < 65536 ? 4 : (n < 131072 ? 2 : 1);
+    }
     if (ovr_r == 1 || ovr_r == 2 || ovr_r == 4) R = ovr_r;
     if (ovr_s == 4 || ovr_s == 8 || ovr_s == 16) S = ovr_s;
     const unsigned block  = 64u * static_cast<unsigned>(R * W);
     const unsigned blocks = (n + block - 1) / block;
     const unsigned units  = (blocks / 2 + 1) * static_cast<unsigned>(R * W);
-    unsigned       C      = 1;
-    const unsigned want   = 2u * static_cast<unsigned>(cu_count) * 8u / static_cast<unsigned>(S);  // workgroups that fill every SIMD four deep
-    while (blocks * C < want && units / (C * 2 * static_cast<unsigned>(S)) >= 2) C *= 2;         // ... while a wave keeps >= 2 units
     if (ovr_c > 0) C = static_cast<unsigned>(ovr_c);
+    while (C > 1 && units < C * static_cast<unsigned>(S)) C /= 2;  // no wave without a unit
     p.vectors_per_lane = R;
     p.waves            = S;
     p.splits           = C;

@@ -115,6 +115,7 @@ auto Compute::run_benchmark(int nb_iterations) -> void {
 auto Compute::use_graph(bool enable) -> void { compute_hip_->use_graph(enable); }
 
 auto Compute::compare_results(double injected_error) -> bool { return compute_hip_->compare_results(active_params_, injected_error); }
+auto Compute::report_trajectory_error(std::size_t steps) -> void { compute_hip_->report_trajectory_error(active_params_, steps); }
 
 auto Compute::positions_fp32() const -> std::span<const float> { return compute_hip_->get_position_fp32(); }
 auto Compute::positions_fp64() const -> std::span<const double> { return compute_hip_->get_position_fp64(); }

@@ -45,6 +45,7 @@ class Compute {
     // ---- what a run does ---------------------------------------------------------------------------------------
     auto run_benchmark(int nb_iterations) -> void;  // prints the reference's three result lines
     auto compare_results(double injected_error = 0.0) -> bool;  // --compare / --qatest (injected_error: test hook)
+    auto report_trajectory_error(std::size_t steps) -> void;    // --compare --steps=K: fast against strict after K steps
     auto update_simulation() -> void;               // one step of the active demo's time step
     auto reset(NBodyConfig initial_configuration) -> void;
     auto select_demo(std::size_t index) -> void;

@@ -6,6 +6,7 @@
 #include "integrate_nbody_hip.hpp"
 #include "text.hpp"
 
+#include <algorithm>
 #include <cassert>
 #include <cmath>
 #include <cstdio>
@@ -232,6 +233,46 @@ template <std::floating_point T> auto ComputeHIP::compare_results(const NBodyPar
     nbody_hip::integration_mode() = saved_mode;
     if (passed) std::printf("  OK\n");
     return passed;
+}
+
+// Extension (--compare --steps=K): how far the FAST trajectory has drifted from the STRICT one -- the CPU BodySystem path's
+// bits -- after K steps of the simulation's own time step, per body and relative to the body's distance from the origin.
+// The system is chaotic: both are roundings of it, and against an fp64 trajectory the two are equally far
+// (tests/test_gpu_parity.py); this prints which half of "fast and within 1e-4 of the CPU path after 100 steps" a mode meets.
+template <std::floating_point T> auto ComputeHIP::report_trajectory_error(const NBodyParams& params, BodySystemHIP<T>& nbody, std::size_t steps) const -> void {
+    const auto pos_span = nbody.get_position();
+    const auto pos0     = std::vector<T>(pos_span.begin(), pos_span.end());
+    const auto vel_span = nbody.get_velocity();
+    const auto vel0     = std::vector<T>(vel_span.begin(), vel_span.end());
+    const auto dt       = static_cast<T>(params.time_step);
+    const auto saved    = nbody_hip::integration_mode();
+    auto       run      = [&](int mode) {
+        nbody_hip::integration_mode() = mode;
+        auto system = BodySystemHIPDefault<T>(static_cast<unsigned int>(nb_bodies_), static_cast<unsigned int>(block_size_), params, pos0, vel0);
+        for (auto s = std::size_t{0}; s < steps; ++s) system.update(dt);
+        const auto span = system.get_position();
+        return std::vector<T>(span.begin(), span.end());
+    };
+    const auto strict = run(NB_MODE_STRICT);
+    const auto fast   = run(NB_MODE_FAST);
+    nbody_hip::integration_mode() = saved;
+    auto errors = std::vector<double>(nb_bodies_);
+    for (auto i = std::size_t{0}; i < nb_bodies_; ++i) {
+        double d2 = 0, r2 = 0;
+        for (auto c = std::size_t{0}; c < 3; ++c) {
+            const auto a = static_cast<double>(strict[4 * i + c]), b = static_cast<double>(fast[4 * i + c]);
+            d2 += (a - b) * (a - b), r2 += a * a;
+        }
+        errors[i] = std::sqrt(d2 / (r2 > 0 ? r2 : 1));
+    }
+    std::sort(errors.begin(), errors.end());
+    const auto at = [&](double q) { return errors[std::min(errors.size() - 1, static_cast<std::size_t>(q * static_cast<double>(errors.size())))]; };
+    std::printf("> after %zu steps of dt = %s: |fast - strict| / |strict| per body: max %.3g, 99th percentile %.3g, median %.3g (strict = the CPU BodySystem path, 0 ulp)\n", steps,
+                text::shortest(params.time_step).c_str(), errors.back(), at(0.99), at(0.5));
+}
+
+auto ComputeHIP::report_trajectory_error(const NBodyParams& params, std::size_t steps) -> void {
+    with_active([&](auto& nbody) { report_trajectory_error(params, nbody, steps); });
 }
 
 auto ComputeHIP::compare_results(const NBodyParams& params, double injected_error) -> bool {

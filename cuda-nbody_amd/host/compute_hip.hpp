@@ -56,12 +56,14 @@ class ComputeHIP {
     // `injected_error` (test hook, --inject-error) is added to the x coordinate of body 0 of the FAST result before
     // the check, so that a test can see the check fail (and the process exit with 1, nbody.cpp:375-379).
     auto compare_results(const NBodyParams& params, double injected_error = 0.0) -> bool;
+    auto report_trajectory_error(const NBodyParams& params, std::size_t steps) -> void;  // --compare --steps=K (extension)
 
  private:
     // calls f(system) with the active precision's body system
     template <typename F> auto with_active(F&& f) -> decltype(auto);
     template <std::floating_point To, std::floating_point From> auto convert_state(BodySystemHIP<To>& to, const BodySystemHIP<From>& from) -> void;
     template <std::floating_point T> auto compare_results(const NBodyParams& params, BodySystemHIP<T>& nbody, double injected_error) const -> bool;
+    template <std::floating_point T> auto report_trajectory_error(const NBodyParams& params, BodySystemHIP<T>& nbody, std::size_t steps) const -> void;
 
     std::size_t nb_bodies_ = 0;
     int         block_size_;

@@ -75,7 +75,8 @@ Options:
   --numdevices UINT           Shard the bodies over GPUs 0..n-1 of this node (position tiles exchanged over RCCL / xGMI)
   --devices LIST              ... or over the GPUs in this comma-separated list
   --demo UINT                 Select row 0..6 of the demo parameter table (dt, scales, softening, damping) and reset
-  --steps UINT                Advance this many steps (untimed) before --dump
+  --steps UINT                Advance this many steps (untimed) before --dump; with --compare: also print how far the fast
+                              trajectory is from the strict one after this many steps (max / 99th percentile / median)
   --dump TEXT                 Write final positions then velocities (raw little-endian T[4N] each) to this file
   --seed UINT                 srand() this value first (the reference never seeds: default stream = seed 1)
   --graph                     --benchmark issues its (even number of) iterations as one captured hipGraph
@@ -261,6 +262,7 @@ auto main(int argc, char** argv) -> int {
             return 0;
         }
         if (compare_to_cpu) {
+            if (cmd_options.steps > 0) compute.report_trajectory_error(cmd_options.steps);  // (before the check steps the system)
             const auto result = compute.compare_results(cmd_options.inject_error);
             return static_cast<int>(!result);
         }

@@ -175,3 +175,68 @@ def test_strict_fast_form_loops_keep_their_instruction_mix():
             packed.append(count("v_pk_"))
     assert sorted(packed) == [80, 92], packed
     assert int(re.search(r"; ScratchSize: (\d+)", "\n".join(lines[end:end + 60])).group(1)) == 0
+
+
+def test_pair_plan_heuristics_without_gpu(pkg):
+    """nb_pair_plan_* / nb_workspace_bytes_* are pure host logic: where the pairwise layout applies, the geometry the
+    BASELINE sizes get (measured: profiles/round3_pair_crossover_*.jsonl), and the workspace formula
+    (workgroups per block + reaction slots) x 3 x padded bodies x sizeof(T)."""
+    import ctypes
+
+    import numpy as np
+
+    def plan(n, dtype=np.float32):
+        p = pkg.pair_plan(n, dtype)
+        assert p.block_bodies == 64 * p.bodies_per_lane and p.blocks == -(-n // p.block_bodies) and p.grid_blocks == p.blocks * p.splits
+        assert p.reaction_slots == (0 if p.blocks < 2 else (p.blocks // 2 if p.blocks % 2 else p.blocks // 2 - 1))
+        assert p.workspace_bytes == (p.splits + p.reaction_slots) * 3 * p.blocks * p.block_bodies * np.dtype(dtype).itemsize
+        return p.applies, p.bodies_per_lane, p.waves_per_block, p.splits, p.blocks
+
+    assert plan(262144) == (1, 8, 8, 1, 512)       # the headline: 512 workgroups of 8 waves, two per CU, 255 reaction slots
+    assert plan(1048576) == (1, 8, 8, 1, 2048)
+    assert plan(65536) == (1, 8, 8, 4, 128)        # four workgroups share a block of bodies i and split its tiles
+    assert plan(16384) == (1, 4, 8, 4, 64)         # small systems: half the bodies per lane, twice the blocks
+    assert plan(8192)[0] == 0 and plan(12288)[0] == 1
+    assert plan(262144, np.float64) == (1, 4, 16, 1, 1024)
+    assert plan(4096, np.float64)[0] == 0 and plan(8192, np.float64)[0] == 1
+    assert plan(600, np.float32)[4] == 3 and plan(64, np.float32)[4] == 1  # odd block counts, a single block
+    need = ctypes.c_size_t(7)
+    lib = pkg.lib()
+    assert lib.nb_workspace_bytes_f32(262144, pkg.NB_MODE_FAST, ctypes.byref(need)) == 0 and need.value == 256 * 3 * 262144 * 4
+    assert lib.nb_workspace_bytes_f32(262144, pkg.NB_MODE_STRICT, ctypes.byref(need)) == 0 and need.value == 0
+    assert lib.nb_workspace_bytes_f32(4096, pkg.NB_MODE_FAST, ctypes.byref(need)) == 0 and need.value == 0
+    assert lib.nb_workspace_bytes_f32(262144, pkg.NB_MODE_FAST, None) == 10001
+    assert lib.nb_set_pair_plan_override(3, 8, 1, 0) == 10001 and lib.nb_set_pair_plan_override(4, 8, 65, 0) == 10001
+    pkg.set_pair_plan_override(2, 16, 3, 1)
+    try:
+        assert plan(20000) == (1, 4, 16, 3, 79)
+    finally:
+        pkg.set_pair_plan_override(0, 0, 0, 0)
+
+
+def test_pairwise_inner_loops_keep_their_instruction_mix():
+    """The rotation loops of the pairwise headline kernel (fp32, 4 packed pairs of bodies i per lane), four steps per trip:
+    per step 4 x (14 v_pk_* + 2 v_rsq_f32) + 9 v_mov_b32_dpp wave_ror:1 (unit masses; 16 + 2 and 10 moves with masses), nothing
+    else on the vector unit but a few moves, no scratch access and no LDS inside the loops, <= 128 VGPRs."""
+    import subprocess
+
+    csrc = os.path.join(ROOT, "cuda-nbody_amd", "csrc")
+    subprocess.run(["make", "-s", "-C", csrc, "asm"], check=True, capture_output=True)
+    lines = open(os.path.join(csrc, "nbody_pair.s")).read().split("\n")
+    kernel = "_ZN2nb12_GLOBAL__N_111pair_forcesIfLi4ELi8EEEvNS0_8PairArgsIT_EE"
+    start = next(i for i, l in enumerate(lines) if l.startswith(kernel + ":"))
+    end = next(i for i in range(start, len(lines)) if lines[i].startswith(".Lfunc_end"))
+    mixes = []
+    for i in range(start, end):
+        if "Inner Loop Header: Depth=2" not in lines[i]:
+            continue
+        label = lines[i - 1].split(":")[0].strip()
+        stop = next(k for k in range(i, end) if "s_cbranch" in lines[k] and label in lines[k])
+        body = [l.strip() for l in lines[i + 1:stop] if l.strip() and not l.strip().startswith(";")]
+        count = lambda what: sum(1 for l in body if what in l.split()[0])  # noqa: E731
+        rotations = sum(1 for l in body if l.startswith("v_mov_b32_dpp") and "wave_ror:1" in l)
+        other = sum(1 for l in body if l.startswith("v_") and not l.startswith(("v_pk_", "v_rsq_f32", "v_mov_b32")))
+        mixes.append((count("v_pk_"), count("v_rsq_f32"), rotations, other, count("scratch_"), count("ds_"), count("s_nop")))
+    assert sorted(mixes) == [(224, 32, 36, 0, 0, 0, 0), (256, 32, 40, 0, 0, 0, 0)], mixes
+    tail = "\n".join(lines[end:end + 60])
+    assert int(re.search(r"; NumVgprs: (\d+)", tail).group(1)) <= 128

@@ -172,6 +172,13 @@ def test_compare_can_fail(host, fp64):
     assert r.returncode == 1 and "Error: (strict)" in r.stdout and "  OK" not in r.stdout
     r = run_cli("--qatest", "--numbodies=1024", "--inject-error=0.0001", *flags)
     assert r.returncode == 0 and "  OK" in r.stdout
+    # --compare --steps=K also reports where the fast trajectory stands against the strict one after K steps
+    r = run_cli("--compare", "--numbodies=1024", "--steps=100", *flags)
+    assert r.returncode == 0 and "  OK" in r.stdout
+    m = re.search(r"> after 100 steps of dt = 0.016: \|fast - strict\| / \|strict\| per body: max ([0-9.e+-]+), 99th percentile ([0-9.e+-]+), median ([0-9.e+-]+)", r.stdout)
+    assert m, r.stdout
+    worst, p99, median = (float(x) for x in m.groups())
+    assert median <= p99 <= worst and (median < 1e-10 if fp64 else 1e-6 < median < 1e-4) and worst < 1e-2
 
 
 @pytest.mark.gpu
