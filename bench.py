@@ -311,7 +311,7 @@ def main():
         work_bytes = pkg.workspace_bytes(n, dtype, mode)
         if work_bytes:
             work_t = torch.empty(work_bytes, dtype=torch.uint8, device=dev)
-    pairwise = work_t is not None
+    pairwise = work_t is not None  # (several ranks: decided below, once the communicator says what it can use)
     ws_fn = lib.nb_integrate_ws_f64 if args.fp64 else lib.nb_integrate_ws_f32
 
     kernel_launches = [0]
@@ -350,8 +350,13 @@ def main():
                                                 ctypes.c_void_p(stream.cuda_stream))
                     # bring the communicator up (channels, first-call set-up) outside any timed step, whatever --warmup says;
                     # every rank holds identical positions at this point, so exchanging them changes nothing
+                    if args.layout == "pairwise" and world > 1:  # pairs once across the ranks: reaction sums travel to their owners
+                        work_bytes = capi_rank.workspace_bytes()
+                        if work_bytes:
+                            work_t = torch.empty(work_bytes, dtype=torch.uint8, device=dev)
+                            pairwise = True
                     if pairwise:
-                        capi_rank.set_workspace(work_t.data_ptr(), work_bytes)  # a world of one: the single-GPU step with its workspace
+                        capi_rank.set_workspace(work_t.data_ptr(), work_bytes)  # (a world of one: the single-GPU step with its workspace)
                     capi_rank.exchange_once(0)
                     torch.cuda.synchronize()
                 except pkg.NBodyHipError as exc:
@@ -367,7 +372,7 @@ def main():
 
         if capi_rank is not None:
             def step():
-                kernel_launches[0] += 1 if pairwise else world  # one kernel per position tile (a world of one with a workspace: one call)
+                kernel_launches[0] += 1 if (pairwise and world == 1) else (world // 2 + 1 if pairwise else world)  # one per position tile / per diagonal + partner
                 capi_rank.update(dt, damping)
 
             finish = capi_rank.finish
@@ -469,6 +474,33 @@ def main():
         print("best:", json.dumps(min(rows, key=lambda r: r["ms"])))
         return
 
+    if args.emulate_gpus > 1 and world == 1 and args.layout == "pairwise" and mode == pkg.NB_MODE_FAST:
+        # one rank's kernels of the pairwise step across G ranks (nb_emulate_pair_rank_*: diagonal, G/2 rectangles, folds, finish)
+        G = args.emulate_gpus
+        emulate = lib.nb_emulate_pair_rank_f64 if args.fp64 else lib.nb_emulate_pair_rank_f32
+        need = ctypes.c_size_t(0)
+        pkg.check(emulate(None, None, None, None, ctypes.byref(need), n, G, 0, dt, damping, None), "nb_emulate_pair_rank (size)")
+        work = torch.empty(need.value, dtype=torch.uint8, device=dev)
+        nxt, out = pos_t.clone(), []
+        for r in sorted({0, G // 2, G - 1}):
+            def one_step():
+                pkg.check(emulate(nxt.data_ptr(), pos_t.data_ptr(), vel_t.data_ptr(), work.data_ptr(), ctypes.byref(need), n, G, r, dt, damping,
+                                  ctypes.c_void_p(stream.cuda_stream)), "nb_emulate_pair_rank")
+            for _ in range(args.warmup):
+                one_step()
+            e0, e1 = pkg.Event(), pkg.Event()
+            torch.cuda.synchronize()
+            e0.record(ctypes.c_void_p(stream.cuda_stream))
+            for _ in range(args.steps):
+                one_step()
+            e1.record(ctypes.c_void_p(stream.cuda_stream))
+            e1.synchronize()
+            out.append({"rank": r, "ms_per_step_kernels_only": e0.elapsed_ms(e1) / args.steps, "launches_per_step": 2 * (G // 2) + 2})
+        worst = max(o["ms_per_step_kernels_only"] for o in out)
+        print(json.dumps({"emulated_gpus": G, "bodies": n, "schedule": "pairwise across ranks: diagonal + G/2 rectangles, reaction sums to their owners",
+                          "workspace_bytes_per_rank": need.value, "ranks": out, "projected_interactions_per_s_excluding_exchange": float(n) * n / (worst * 1e-3)}), flush=True)
+        return
+
     if args.emulate_gpus > 1 and world == 1:
         sharded = entry.load_package_module("sharded")
         G = args.emulate_gpus
@@ -566,13 +598,13 @@ def main():
         per_launch_interactions = float(n) * float(n) * args.steps / max(launches, 1) / world
         achieved_tflops = flops_per * per_launch_interactions / (ms_per_launch * 1e-3) / 1e12
         plan = pkg.plan(n // world, n, dtype)
-        pair = pkg.pair_plan(n, dtype) if pairwise else None
+        pair = pkg.pair_plan(n, dtype) if (pairwise and world == 1) else None
         # HBM traffic cannot be counted from inside this process: it comes from the separate rocprofv3 --pmc passes
         # of this same command (tools/profile.sh -> tools/summarize_prof.py), committed under profiles/.
         traffic, traffic_src = None, None
         plan_now = {"bodies_per_lane": plan.bodies_per_lane, "lane_groups": plan.lanes_per_body, "lds_tile_bodies": plan.tile_bodies,
                     "grid": plan.grid_blocks, "lds_bytes": plan.lds_bytes}
-        if pairwise:
+        if pair is not None:
             plan_now = {"layout": "pairwise", "bodies_per_lane": pair.bodies_per_lane, "waves_per_block": pair.waves_per_block, "workgroups_per_block": pair.splits,
                         "blocks": pair.blocks, "block_bodies": pair.block_bodies, "reaction_slots": pair.reaction_slots, "grid": pair.grid_blocks,
                         "lds_bytes": pair.lds_bytes, "workspace_bytes": pair.workspace_bytes}
@@ -614,9 +646,12 @@ def main():
                     "REHEARSAL: gloo, host-staged gather, ranks share one GPU" if args.exchange == "host" else
                     "FALLBACK (no RCCL): gloo all-gather of the slices through host memory, one GPU per rank" if args.exchange == "staged" else
                     "REHEARSAL: gloo send/recv rounds (tile schedule) staged through host memory, ranks share one GPU" if args.exchange == "host-tiles" else
-                    "C-ABI (nb_comm_init_rank + nb_sharded_step_*, csrc/nbody_comm.hip): RCCL all-gather of the new positions per step, issued as "
-                    "G-1 position tiles (grouped ncclSend/ncclRecv rounds on the communicator's high-priority stream); the kernel of tile k waits "
-                    "only on round k, the own-slice chunk runs first" if capi_rank is not None else
+                    ("C-ABI (nb_comm_init_rank + nb_sharded_step_*, csrc/nbody_comm.hip), PAIRWISE across the ranks: each rank evaluates its own slice and "
+                     "the rectangles against ranks r+1 .. r+G/2 once per pair and sends the reaction sums (N/G x 12 B per partner) to their owners; "
+                     "positions all-gathered as G-1 RCCL send/recv tiles on the communicator's high-priority stream" if pairwise else
+                     "C-ABI (nb_comm_init_rank + nb_sharded_step_*, csrc/nbody_comm.hip): RCCL all-gather of the new positions per step, issued as "
+                     "G-1 position tiles (grouped ncclSend/ncclRecv rounds on the communicator's high-priority stream); the kernel of tile k waits "
+                     "only on round k, the own-slice chunk runs first") if capi_rank is not None else
                     "torch.distributed re-implementation (sharded.py) of the tile schedule: batch_isend_irecv rounds on RCCL's stream" if system.exchange == "tiles" else
                     "torch.distributed (sharded.py): RCCL all_gather_into_tensor of the new positions per step, overlapped with the own-slice j chunk"),
                 "layout": "pairwise (every pair of bodies evaluated once, reaction sums through a caller-owned workspace)" if pairwise else
@@ -645,14 +680,14 @@ def main():
                 # pairwise layout: the step is two kernels (pair_forces, pair_finish) and evaluates each pair of bodies once; `achieved` and
                 # `frac` above count the ALGORITHMIC 20 (30) flop per directed interaction of the reference convention (compute.cpp:16-18),
                 # `executed` counts what the kernels really issue: 24 (36) flop per pair evaluation
-                "executed": None if not pairwise else {
+                "executed": None if pair is None else {
                     "pair_evaluations_per_launch": float(pair.blocks) * (pair.blocks // 2 + 1) * pair.block_bodies * pair.block_bodies,
                     "flops_per_pair_evaluation": 36 if args.fp64 else 24,
                     "tflops": (36 if args.fp64 else 24) * float(pair.blocks) * (pair.blocks // 2 + 1) * pair.block_bodies * pair.block_bodies / (ms_per_launch * 1e-3) / 1e12,
                     "frac": (36 if args.fp64 else 24) * float(pair.blocks) * (pair.blocks // 2 + 1) * pair.block_bodies * pair.block_bodies / (ms_per_launch * 1e-3) / 1e12 / peak},
                 "algorithmic_flops_per_launch": flops_per * per_launch_interactions,
                 # positions + velocities in and out; the pairwise layout also writes and reads its reaction slots once
-                "algorithmic_hbm_bytes_per_launch": (128 if args.fp64 else 64) * (n // world) + (2 * pair.workspace_bytes if pairwise else 0),
+                "algorithmic_hbm_bytes_per_launch": (128 if args.fp64 else 64) * (n // world) + (2 * pair.workspace_bytes if pair is not None else 0),
             },
         }
         if not args.no_cpu_baseline and world == 1:

@@ -128,6 +128,11 @@ SIGNATURES = {
     "nb_comm_destroy": (_ci, [_vp]),
     "nb_comm_info": (_ci, [_vp, _P(_ci), _P(_ci), _P(_ci)]),
     "nb_comm_set_workspace": (_ci, [_vp, _vp, _sz]),
+    "nb_comm_workspace_bytes_f32": (_ci, [_vp, _cu, _ci, _P(_sz)]),
+    "nb_comm_workspace_bytes_f64": (_ci, [_vp, _cu, _ci, _P(_sz)]),
+    "nb_comm_set_pair_min_slice": (_ci, [_ci]),
+    "nb_emulate_pair_rank_f32": (_ci, [_vp, _vp, _vp, _vp, _P(_sz), _cu, _ci, _ci, _cf, _cf, _vp]),
+    "nb_emulate_pair_rank_f64": (_ci, [_vp, _vp, _vp, _vp, _P(_sz), _cu, _ci, _ci, _cd, _cd, _vp]),
     "nb_sharded_step_f32": (_ci, [_vp, _vp, _vp, _vp, _vp, _cu, _cf, _cf, _ci, _ci, _vp]),
     "nb_sharded_step_f64": (_ci, [_vp, _vp, _vp, _vp, _vp, _cu, _cd, _cd, _ci, _ci, _vp]),
     "nb_sharded_step_all_f32": (_ci, [_P(_vp), _ci, _P(_vp), _P(_vp), _P(_vp), _P(_vp), _cu, _cf, _cf, _ci, _ci, _P(_vp)]),
@@ -431,6 +436,14 @@ class ShardedRank:
         self._step = lib().nb_sharded_step_f32 if f32 else lib().nb_sharded_step_f64
         self._tiles = lib().nb_exchange_tiles_f32 if f32 else lib().nb_exchange_tiles_f64
         self._scalar = np.float32 if f32 else float
+
+    def workspace_bytes(self) -> int:
+        """nb_comm_workspace_bytes_*: the scratch memory this rank can use in its mode (one rank: the single-GPU pairwise step;
+        several: pairs once across the ranks, reaction sums sent to their owners); 0 = none."""
+        need = _sz(0)
+        fn = lib().nb_comm_workspace_bytes_f32 if self.dtype == np.float32 else lib().nb_comm_workspace_bytes_f64
+        check(fn(self.comm, self.n, self.mode, ctypes.byref(need)), "nb_comm_workspace_bytes")
+        return need.value
 
     def set_workspace(self, workspace, nbytes: int) -> None:
         """nb_comm_set_workspace: lend this rank the scratch memory of workspace_bytes() (used by a world of one)."""

@@ -17,12 +17,14 @@
 // the copy torch already loaded is the one that gets bound (same SONAME).
 #include "../../include/nbody_hip.h"
 
+#include "nbody_kernels.h"
 #include "rand_stream_guard.h"
 
 #include <hip/hip_runtime.h>
 
 #include <dlfcn.h>
 
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -103,8 +105,10 @@ struct Comm {
     hipEvent_t  ready  = nullptr;          // "what the exchange has to wait for has been enqueued" (recorded on the compute stream)
     std::vector<hipEvent_t> arrived;       // [world]: arrived[p] = the round that brings rank p's tile is done
     const void* in_flight = nullptr;       // the array whose tiles are (or were last) being exchanged
-    void*       workspace = nullptr;       // caller-owned scratch memory (nb_comm_set_workspace): a world of one steps through nb_integrate_ws_*
+    void*       workspace = nullptr;       // caller-owned scratch memory (nb_comm_set_workspace)
     size_t      workspace_bytes = 0;
+    std::vector<hipEvent_t> react_ready;   // [world/2 + 1] pairwise step: "the reaction sums for partner s are in the send buffer" (compute stream)
+    std::vector<hipEvent_t> react_arrived; // [world/2 + 1] ... "round s of the reaction exchange is done" (exchange stream)
     std::vector<Comm*> group;              // all local ranks of this communicator (just {this} with one process per GPU)
 };
 
@@ -136,17 +140,22 @@ int make_resources(Comm* c) {
     err = hipEventCreateWithFlags(&c->ready, hipEventDisableTiming);
     if (err != hipSuccess) return static_cast<int>(err);
     c->arrived.assign(static_cast<size_t>(c->world), nullptr);
-    for (auto& e : c->arrived) {
-        err = hipEventCreateWithFlags(&e, hipEventDisableTiming);
-        if (err != hipSuccess) return static_cast<int>(err);
+    c->react_ready.assign(static_cast<size_t>(c->world / 2 + 1), nullptr);
+    c->react_arrived.assign(static_cast<size_t>(c->world / 2 + 1), nullptr);
+    for (auto* events : {&c->arrived, &c->react_ready, &c->react_arrived}) {
+        for (auto& e : *events) {
+            err = hipEventCreateWithFlags(&e, hipEventDisableTiming);
+            if (err != hipSuccess) return static_cast<int>(err);
+        }
     }
     return 0;
 }
 
 void free_resources(Comm* c) {
     DeviceScope scope(c->device);
-    for (auto e : c->arrived)
-        if (e) (void)hipEventDestroy(e);
+    for (auto* events : {&c->arrived, &c->react_ready, &c->react_arrived})
+        for (auto e : *events)
+            if (e) (void)hipEventDestroy(e);
     if (c->ready) (void)hipEventDestroy(c->ready);
     if (c->stream) (void)hipStreamDestroy(c->stream);
 }
@@ -224,6 +233,164 @@ template <> struct Api<double> {
     }
 };
 
+// ---- FAST with a workspace: every PAIR of bodies once, across the ranks too (round 3) -----------------------------------------
+// One GPU evaluates each pair of bodies once (nbody_pair.hip).  A shard that evaluates rectangles of the pair matrix
+// one-sidedly does twice that arithmetic, so the same tournament runs across the ranks: rank r evaluates
+//   * its own slice against itself, pairwise (the diagonal);
+//   * its slice against the slices of ranks r+1 .. r+H (H = G/2), pairwise: it keeps the sums of its own bodies and SENDS the
+//     reaction sums -- folded to one value per body and component, N/G * 12 B, as little as a position tile -- to the owner;
+//   * for an even G the partner at distance G/2 lists the pair too: the two split that rectangle, the lower rank taking
+//     (its slice) x (the first half of the partner's blocks), the higher one (the second half of its own blocks) x (the
+//     partner's slice), and reaction sums travel both ways;
+// and the finish kernel adds a body's own sums, its diagonal reaction slots and the H arrays it RECEIVED, in a fixed order.
+// Half the arithmetic per rank, one more exchange leg of the size of the existing one (same stream, same rounds, after the
+// tiles' kernels; the position exchange is unchanged, so every rank still ends a step with all positions).
+struct PairShard {
+    bool         applies = false;
+    nb::PairGeom diag{}, rect{};
+    unsigned     ni = 0, block = 0, blocks = 0, plane = 0, half = 0, H = 0, diag_slots = 0;
+    bool         even = false;
+    size_t       self_at = 0, react_d_at = 0, react_r_at = 0, send_at = 0, recv_at = 0, elements = 0;  // offsets in T
+};
+
+template <typename T> PairShard plan_pair_shard(unsigned num_bodies, int G, int min_slice) {
+    constexpr unsigned W = sizeof(T) == 4 ? 2 : 1;
+    PairShard          p;
+    if (G < 2 || num_bodies % static_cast<unsigned>(G)) return p;
+    p.ni = num_bodies / static_cast<unsigned>(G);
+    if (p.ni < static_cast<unsigned>(min_slice > 0 ? min_slice : 2048) || G / 2 > nb::kMaxRecv || G / 2 + 1 > nb::kMaxSelfSets) return p;
+    const int R = (sizeof(T) == 4 ? p.ni >= 16384 : p.ni >= 8192) ? 4 : 2;
+    p.block  = 64u * static_cast<unsigned>(R) * W;
+    p.blocks = (p.ni + p.block - 1) / p.block;
+    p.plane  = (p.ni + 63u) / 64u * 64u;
+    p.H      = static_cast<unsigned>(G) / 2;
+    p.even   = (G % 2) == 0;
+    p.half   = (p.blocks / 2) * p.block;
+    p.diag_slots = p.blocks < 2 ? 0u : ((p.blocks & 1u) ? p.blocks / 2 : p.blocks / 2 - 1);
+    auto splits = [&](unsigned units) {  // workgroups per block: fill the chip (~512 workgroups of 8 waves) while a wave keeps >= 2 units
+        unsigned C = 1;
+        while (p.blocks * C * 2 <= 512 && units >= C * 2 * 8 * 2) C *= 2;
+        return C;
+    };
+    p.diag = {R, 8, splits((p.blocks / 2 + 1) * static_cast<unsigned>(R) * W)};
+    p.rect = {R, 8, splits((p.ni + 63) / 64)};
+    const size_t plane3 = 3 * static_cast<size_t>(p.plane);
+    p.self_at    = 0;
+    p.react_d_at = p.self_at + (p.diag.splits + static_cast<size_t>(p.H) * p.rect.splits) * plane3;
+    p.react_r_at = p.react_d_at + p.diag_slots * plane3;
+    p.send_at    = p.react_r_at + p.blocks * plane3;
+    p.recv_at    = p.send_at + p.H * plane3;
+    p.elements   = p.recv_at + p.H * plane3;
+    p.applies    = true;
+    return p;
+}
+
+std::atomic<int> g_pair_shard_min{0};  // nb_set_pair_plan_override(.., min_bodies): tests run the pairwise step on small slices
+
+// The kernels ONE rank launches in a pairwise step, up to (not including) the finish kernel: the diagonal, then per partner
+// the rectangle and the fold of its reaction sums into the send buffer.  `c` == nullptr: no communicator (nb_emulate_pair_rank_*:
+// kernel-time projection of a rank of a G-rank system on one GPU) -- no waits for tiles, no events.
+template <typename T>
+int pair_rank_tiles(Comm* c, unsigned r, int G, const PairShard& plan, T* work, T* new_pos, const T* old_pos, T* vel, unsigned num_bodies, T dt, T damping, T eps2, hipStream_t stream, bool waiting, nb::FinishArgs<T>& f) {
+    const unsigned ni     = plan.ni, own = r * ni;
+    const size_t   plane3 = 3 * static_cast<size_t>(plan.plane);
+    f = {};
+    f.old_pos = old_pos, f.new_pos = new_pos, f.vel = vel;
+    f.self = work + plan.self_at, f.react = work + plan.react_d_at, f.recv = work + plan.recv_at, f.extra = nullptr;
+    f.origin = own, f.count = ni;
+    f.self_plane = f.react_plane = f.recv_plane = plan.plane;
+    f.react_slots = plan.diag_slots;
+    f.dt = dt, f.damping = damping;
+
+    nb::PairArgs<T> a{};
+    a.old_pos = old_pos, a.self = work + plan.self_at, a.n = num_bodies, a.eps2 = eps2;
+    a.self_origin = own, a.self_plane = plan.plane, a.react_plane = plan.plane;
+    // the diagonal: the rank's own slice against itself (its positions are local: nothing to wait for)
+    a.react = work + plan.react_d_at, a.react_origin = own;
+    a.i_begin = a.j_begin = own, a.i_count = a.j_count = ni, a.diag = 1, a.keep = 1, a.self_first = 0;
+    if (const auto err = nb::launch_pair_tile<T>(a, plan.diag, stream); err != hipSuccess) return static_cast<int>(err);
+    f.self_set[f.n_self++] = {0u, plan.diag.splits, 0u, ni};
+    // the rectangles against the partners r+1 .. r+H, each as its positions arrive
+    for (unsigned s = 1; s <= plan.H; ++s) {
+        const unsigned p = (r + s) % static_cast<unsigned>(G);
+        if (c != nullptr && waiting) {
+            if (const auto err = hipStreamWaitEvent(stream, c->arrived[p], 0); err != hipSuccess) return static_cast<int>(err);
+        }
+        a.diag = 0, a.keep = 1, a.react = work + plan.react_r_at;
+        a.i_begin = own, a.i_count = ni, a.j_begin = p * ni, a.j_count = ni;
+        if (plan.even && s == plan.H) {  // both partners list this pair of ranks: split the rectangle
+            if (r < p) a.j_count = plan.half;
+            else a.i_begin = own + plan.half, a.i_count = ni - plan.half;
+        }
+        a.react_origin = a.j_begin;
+        a.self_first   = plan.diag.splits + (s - 1) * plan.rect.splits;
+        if (const auto err = nb::launch_pair_tile<T>(a, plan.rect, stream); err != hipSuccess) return static_cast<int>(err);
+        f.self_set[f.n_self++] = {a.self_first, plan.rect.splits, a.i_begin - own, a.i_count};
+        const unsigned blocks_i = (a.i_count + plan.block - 1) / plan.block;
+        if (const auto err = nb::launch_pair_reduce<T>(a.react, plan.plane, blocks_i, work + plan.send_at + (s - 1) * plane3, plan.plane, a.j_count, stream); err != hipSuccess) return static_cast<int>(err);
+        if (c != nullptr) {
+            if (const auto err = hipEventRecord(c->react_ready[s], stream); err != hipSuccess) return static_cast<int>(err);
+        }
+        // what arrives in round s comes from rank r-s, which covered: all of this slice -- or, splitting the rectangle as the
+        // lower rank, only the first half of its blocks
+        const unsigned q = (r + static_cast<unsigned>(G) - s) % static_cast<unsigned>(G);
+        f.recv_set[f.n_recv++] = {0u, (plan.even && s == plan.H && q < r) ? plan.half : ni};
+    }
+    return 0;
+}
+
+template <typename T>
+int pair_sharded_step(const std::vector<Comm*>& locals, const PairShard& plan, T* const* new_pos, const T* const* old_pos, T* const* vel, unsigned num_bodies, T dt, T damping, T eps2, const nb_stream_t* streams) {
+    Rccl* lib = rccl();
+    if (lib == nullptr) return NB_ERR_UNSUPPORTED;
+    const int      G      = locals.front()->world;
+    const size_t   plane3 = 3 * static_cast<size_t>(plan.plane);
+    std::vector<nb::FinishArgs<T>> finish(locals.size());
+    for (size_t k = 0; k < locals.size(); ++k) {
+        Comm*       c = locals[k];
+        DeviceScope scope(c->device);
+        const bool  waiting = c->in_flight == static_cast<const void*>(old_pos[k]);
+        const int   rc = pair_rank_tiles<T>(c, static_cast<unsigned>(c->rank), G, plan, static_cast<T*>(c->workspace), new_pos[k], old_pos[k], vel[k], num_bodies, dt, damping, eps2,
+                                            reinterpret_cast<hipStream_t>(streams[k]), waiting, finish[k]);
+        if (rc != 0) return rc;
+    }
+    // the reaction exchange: round s = send to r+s what was summed for its bodies, receive from r-s; one RCCL group per round
+    {
+        NB_KEEP_RAND_STREAM;
+        for (unsigned s = 1; s <= plan.H; ++s) {
+            for (Comm* c : locals) {
+                DeviceScope scope(c->device);
+                if (const auto err = hipStreamWaitEvent(c->stream, c->react_ready[s], 0); err != hipSuccess) return static_cast<int>(err);
+            }
+            int rc = lib->GroupStart();
+            for (size_t k = 0; k < locals.size() && rc == 0; ++k) {
+                Comm*     c    = locals[k];
+                T* const  work = static_cast<T*>(c->workspace);
+                const int to = (c->rank + static_cast<int>(s)) % G, from = (c->rank - static_cast<int>(s) + G) % G;
+                rc              = lib->Send(work + plan.send_at + (s - 1) * plane3, plane3, Api<T>::nccl_type, to, c->nccl, c->stream);
+                if (rc == 0) rc = lib->Recv(work + plan.recv_at + (s - 1) * plane3, plane3, Api<T>::nccl_type, from, c->nccl, c->stream);
+            }
+            const int end = lib->GroupEnd();
+            if (rc == 0) rc = end;
+            if (rc != 0) return nccl_status(rc);
+            for (Comm* c : locals) {
+                DeviceScope scope(c->device);
+                if (const auto err = hipEventRecord(c->react_arrived[s], c->stream); err != hipSuccess) return static_cast<int>(err);
+            }
+        }
+    }
+    for (size_t k = 0; k < locals.size(); ++k) {
+        Comm*       c = locals[k];
+        DeviceScope scope(c->device);
+        hipStream_t stream = reinterpret_cast<hipStream_t>(streams[k]);
+        for (unsigned s = 1; s <= plan.H; ++s) {
+            if (const auto err = hipStreamWaitEvent(stream, c->react_arrived[s], 0); err != hipSuccess) return static_cast<int>(err);
+        }
+        if (const auto err = nb::launch_pair_finish<T>(finish[k], stream); err != hipSuccess) return static_cast<int>(err);
+    }
+    return 0;
+}
+
 // One step for every local rank: kernels of the own slice and of each tile as it arrives, integrate, start the next exchange.
 template <typename T>
 int sharded_step(nb_comm_t const* comms, int n_local, T* const* new_pos, const T* const* old_pos, T* const* vel, T* const* acc, unsigned num_bodies, T dt, T damping, int block_size, int mode, const nb_stream_t* streams) {
@@ -239,7 +406,31 @@ int sharded_step(nb_comm_t const* comms, int n_local, T* const* new_pos, const T
     const int G = locals.front()->world;
     if (num_bodies == 0 || num_bodies % static_cast<unsigned>(G)) return NB_ERR_INVALID_ARGUMENT;  // pad with zero-mass bodies (as tipsy.cpp:111-119 does)
     const unsigned ni = num_bodies / static_cast<unsigned>(G);
-    for (int k = 0; k < n_local; ++k) {
+    bool           done_pairwise = false;
+    if (G > 1 && mode == NB_MODE_FAST) {  // every local rank lent a large enough workspace: pairs once, across the ranks too
+        const PairShard plan = plan_pair_shard<T>(num_bodies, G, g_pair_shard_min.load());
+        bool            all  = plan.applies;
+        for (Comm* c : locals) all = all && c->workspace != nullptr && c->workspace_bytes >= plan.elements * sizeof(T);
+        if (all) {
+            T eps2 = 0;
+            if constexpr (sizeof(T) == 4) {
+                float e = 0;
+                (void)nb_get_softening_sq_f32(&e);
+                eps2 = e;
+            } else {
+                double e = 0;
+                (void)nb_get_softening_sq_f64(&e);
+                eps2 = e;
+            }
+            for (int k = 0; k < n_local; ++k) {  // the same argument rules as nb_integrate_shard_*
+                if (new_pos[k] == nullptr || old_pos[k] == nullptr || vel[k] == nullptr || new_pos[k] == old_pos[k]) return NB_ERR_INVALID_ARGUMENT;
+            }
+            const int rc = pair_sharded_step<T>(locals, plan, new_pos, old_pos, vel, num_bodies, dt, damping, eps2, streams);
+            if (rc != 0) return rc;
+            done_pairwise = true;
+        }
+    }
+    for (int k = 0; k < n_local && !done_pairwise; ++k) {
         Comm*         c = locals[static_cast<size_t>(k)];
         DeviceScope   scope(c->device);
         hipStream_t   stream   = reinterpret_cast<hipStream_t>(streams[k]);
@@ -267,6 +458,35 @@ int sharded_step(nb_comm_t const* comms, int n_local, T* const* new_pos, const T
     std::vector<hipStream_t> after(static_cast<size_t>(n_local));
     for (int k = 0; k < n_local; ++k) arrays[static_cast<size_t>(k)] = new_pos[k], after[static_cast<size_t>(k)] = reinterpret_cast<hipStream_t>(streams[k]);
     return exchange_tiles(locals, arrays.data(), num_bodies, 4 * sizeof(T), Api<T>::nccl_type, after.data());
+}
+
+template <typename T> int comm_workspace_bytes(nb_comm_t comm, unsigned num_bodies, int mode, size_t* bytes) {
+    Comm* c = as_comm(comm);
+    if (c == nullptr || bytes == nullptr) return NB_ERR_INVALID_ARGUMENT;
+    *bytes = 0;
+    if (c->world == 1) return sizeof(T) == 4 ? nb_workspace_bytes_f32(num_bodies, mode, bytes) : nb_workspace_bytes_f64(num_bodies, mode, bytes);
+    if (mode != NB_MODE_FAST) return 0;
+    const PairShard plan = plan_pair_shard<T>(num_bodies, c->world, g_pair_shard_min.load());
+    if (plan.applies) *bytes = plan.elements * sizeof(T);
+    return 0;
+}
+// Tuning / projection hook (bench.py --emulate-gpus): the kernels rank `rank` of a `world`-rank pairwise step launches, with
+// no communicator and no exchange (what would arrive from other ranks is whatever the workspace holds), on one GPU.
+template <typename T> int emulate_pair_rank(T* new_pos, const T* old_pos, T* vel, void* workspace, size_t* workspace_bytes, unsigned num_bodies, int world, int rank, T dt, T damping, T eps2, nb_stream_t stream) {
+    if (workspace_bytes == nullptr || world < 2 || rank < 0 || rank >= world) return NB_ERR_INVALID_ARGUMENT;
+    const PairShard plan = plan_pair_shard<T>(num_bodies, world, g_pair_shard_min.load());
+    if (!plan.applies) return NB_ERR_UNSUPPORTED;
+    const size_t need = plan.elements * sizeof(T);
+    if (workspace == nullptr || *workspace_bytes < need) {  // a size query
+        *workspace_bytes = need;
+        return workspace == nullptr ? 0 : NB_ERR_INVALID_ARGUMENT;
+    }
+    if (!new_pos || !old_pos || !vel || new_pos == old_pos) return NB_ERR_INVALID_ARGUMENT;
+    nb::FinishArgs<T> f{};
+    hipStream_t       s  = reinterpret_cast<hipStream_t>(stream);
+    const int         rc = pair_rank_tiles<T>(nullptr, static_cast<unsigned>(rank), world, plan, static_cast<T*>(workspace), new_pos, old_pos, vel, num_bodies, dt, damping, eps2, s, false, f);
+    if (rc != 0) return rc;
+    return static_cast<int>(nb::launch_pair_finish<T>(f, s));
 }
 
 }  // namespace
@@ -373,6 +593,26 @@ int nb_comm_set_workspace(nb_comm_t comm, void* workspace, size_t workspace_byte
     if (c == nullptr || (workspace == nullptr && workspace_bytes != 0)) return NB_ERR_INVALID_ARGUMENT;
     c->workspace       = workspace;
     c->workspace_bytes = workspace_bytes;
+    return 0;
+}
+
+int nb_comm_workspace_bytes_f32(nb_comm_t comm, unsigned num_bodies, int mode, size_t* bytes) { return comm_workspace_bytes<float>(comm, num_bodies, mode, bytes); }
+int nb_comm_workspace_bytes_f64(nb_comm_t comm, unsigned num_bodies, int mode, size_t* bytes) { return comm_workspace_bytes<double>(comm, num_bodies, mode, bytes); }
+int nb_emulate_pair_rank_f32(float* new_positions, const float* old_positions, float* velocities, void* workspace, size_t* workspace_bytes, unsigned num_bodies, int world_size, int rank, float dt, float damping,
+                             nb_stream_t stream) {
+    float eps2 = 0;
+    (void)nb_get_softening_sq_f32(&eps2);
+    return emulate_pair_rank<float>(new_positions, old_positions, velocities, workspace, workspace_bytes, num_bodies, world_size, rank, dt, damping, eps2, stream);
+}
+int nb_emulate_pair_rank_f64(double* new_positions, const double* old_positions, double* velocities, void* workspace, size_t* workspace_bytes, unsigned num_bodies, int world_size, int rank, double dt, double damping,
+                             nb_stream_t stream) {
+    double eps2 = 0;
+    (void)nb_get_softening_sq_f64(&eps2);
+    return emulate_pair_rank<double>(new_positions, old_positions, velocities, workspace, workspace_bytes, num_bodies, world_size, rank, dt, damping, eps2, stream);
+}
+int nb_comm_set_pair_min_slice(int min_bodies_per_rank) {
+    if (min_bodies_per_rank < 0) return NB_ERR_INVALID_ARGUMENT;
+    g_pair_shard_min.store(min_bodies_per_rank);
     return 0;
 }
 

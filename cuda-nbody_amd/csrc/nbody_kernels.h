@@ -59,7 +59,58 @@ struct PairPlan {
     size_t   workspace_bytes;
 };
 
+// One launch of the forces kernel: the bodies i of [i_begin, i_begin + i_count), cut into blocks of 64*I, against
+//   diag = 1: themselves -- the tournament of the header comment within that range (one GPU: the whole system; a rank of a
+//             multi-GPU system: its own slice), reaction slot q-1;
+//   diag = 0: the bodies j of [j_begin, j_begin + j_count), every tile symmetric -- a rectangle of the pair matrix (a tile of
+//             another rank's bodies); the reaction sums of block a go to slot a (keep = 0: they are dropped).
+template <typename T> struct PairArgs {
+    const T* old_pos;
+    T*       self;          // i-side sums: slot (self_first + c), plane self_plane, body index i - self_origin
+    T*       react;         // reaction sums: [slot][3][react_plane], body index j - react_origin
+    unsigned n;             // bodies in the arrays
+    unsigned i_begin, i_count, j_begin, j_count;
+    unsigned blocks;        // NB = ceil(i_count / (64*I))
+    unsigned splits;        // C workgroups per block
+    unsigned diag, keep;
+    unsigned self_first, self_origin, self_plane;
+    unsigned react_origin, react_plane;
+    T        eps2;
+};
+
+// The finish kernel's view of one rank's sums (one GPU: everything with origin 0 and full coverage).
+inline constexpr int kMaxSelfSets = 12, kMaxRecv = 8;
+template <typename T> struct FinishArgs {
+    const T* old_pos;
+    T*       new_pos;
+    T*       vel;
+    const T* self;          // [slot][3][self_plane]
+    const T* react;         // the diagonal launch's reaction slots [react_slots][3][react_plane]
+    const T* recv;          // reaction sums received from other ranks [n_recv][3][recv_plane]
+    const T* extra;         // optional partial accelerations vec4[N] (one-sided tiles), added
+    unsigned origin, count; // the bodies this rank integrates
+    unsigned self_plane, react_plane, react_slots, recv_plane;
+    unsigned n_self, n_recv;
+    struct Cover {
+        unsigned slot, slots, first, count;  // `slots` consecutive slots from `slot` cover bodies [first, first + count) (relative to origin)
+    } self_set[kMaxSelfSets];
+    struct Window {
+        unsigned first, count;
+    } recv_set[kMaxRecv];
+    T dt, damping;
+};
+
+struct PairGeom {
+    int      vectors_per_lane;  // R
+    int      waves;             // S
+    unsigned splits;            // C
+};
+
 template <typename T> PairPlan   plan_pair(unsigned n, int cu_count, int ovr_r, int ovr_s, int ovr_c);
+// the pieces of a pairwise step, for callers that compose them themselves (nbody_comm.hip: one rank of a multi-GPU system)
+template <typename T> hipError_t launch_pair_tile(const PairArgs<T>& args, const PairGeom& g, hipStream_t stream, bool prepare_only = false);  // fills blocks / splits
+template <typename T> hipError_t launch_pair_reduce(const T* react, unsigned react_plane, unsigned slots, T* out, unsigned out_plane, unsigned count, hipStream_t stream);
+template <typename T> hipError_t launch_pair_finish(const FinishArgs<T>& args, hipStream_t stream);
 template <typename T> hipError_t launch_pair(const Shard<T>& s, const PairPlan& p, void* workspace, hipStream_t stream, bool prepare_only = false);
 template <typename T> Plan       plan_fast(unsigned i_count, unsigned j_count, int cu_count, int ovr_i, int ovr_s, int ovr_tile);
 template <typename T> hipError_t launch_fast(const Shard<T>& s, const Plan& p, hipStream_t stream, bool prepare_only = false);

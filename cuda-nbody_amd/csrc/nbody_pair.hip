@@ -59,19 +59,6 @@ __device__ __forceinline__ v2f rotate(v2f x) { return v2f{rotate(x.x), rotate(x.
 __device__ __forceinline__ float  both_halves(v2f a) { return a.x + a.y; }
 __device__ __forceinline__ double both_halves(double a) { return a; }
 
-template <typename T> struct PairArgs {
-    const T* old_pos;
-    T*       new_pos;
-    T*       vel;
-    T*       work;     // [splits][3][npad] i-side sums, then [slots][3][npad] reaction sums
-    unsigned n;        // bodies
-    unsigned blocks;   // NB = ceil(n / (64*I))
-    unsigned npad;     // NB * 64 * I
-    unsigned splits;   // C workgroups per block
-    unsigned slots;    // reaction slots per body
-    T        dt, damping, eps2;
-};
-
 template <typename T> __device__ __forceinline__ T pair_reference_mass(const T* old_pos) {
     const T m = old_pos[3];
     const T a = m < 0 ? -m : m;
@@ -109,18 +96,19 @@ template <typename T, int R, int S> __global__ __launch_bounds__(64 * S) __attri
     const T    inv_mref  = T(1) / m_ref;
     const bits unit_bits = __builtin_bit_cast(bits, m_ref);
 
-    // bodies i of this lane: block_base + k*64 + lane (coalesced across the wave); a body beyond N sits on body N-1 with mass 0
-    const unsigned block_base = a * BLOCK;
+    // bodies i of this lane: block_base + k*64 + lane (coalesced across the wave); a body beyond the range sits on its last body with mass 0
+    const unsigned block_base = s.i_begin + a * BLOCK;
+    const unsigned i_end      = s.i_begin + s.i_count;
     vec            px[R], py[R], pz[R], ax[R], ay[R], az[R];
     bool           all_unit = true;
 #pragma unroll
     for (int k = 0; k < I; ++k) {
         const unsigned i = block_base + k * 64 + lane;
-        const vec4     p = old_pos[i < s.n ? i : s.n - 1];
+        const vec4     p = old_pos[i < i_end ? i : i_end - 1];
         LT::set(px[k / W], k % W, p.x);
         LT::set(py[k / W], k % W, p.y);
         LT::set(pz[k / W], k % W, p.z);
-        all_unit = all_unit && i < s.n && __builtin_bit_cast(bits, p.w) == unit_bits;
+        all_unit = all_unit && i < i_end && __builtin_bit_cast(bits, p.w) == unit_bits;
     }
     const bool block_unit = __builtin_amdgcn_ballot_w64(!all_unit) == 0;  // wave-uniform: every body i of the block is real and has mass m_ref
 #pragma unroll
@@ -170,19 +158,22 @@ template <typename T, int R, int S> __global__ __launch_bounds__(64 * S) __attri
     const unsigned NB      = s.blocks;
     const unsigned Q       = NB / 2;
     const bool     even    = (NB & 1u) == 0;
-    const unsigned n_units = (Q + 1) * TB;
+    const bool     diag    = s.diag != 0;
+    const unsigned j_end   = s.j_begin + s.j_count;
+    const unsigned n_units = diag ? (Q + 1) * TB : (s.j_count + 63) / 64;
     const unsigned G       = s.splits * S;
     const unsigned g       = c * S + static_cast<unsigned>(wave);
 
     auto tile_first = [&](unsigned u) {
+        if (!diag) return s.j_begin + u * 64;
         unsigned jb = a + u / TB;
         if (jb >= NB) jb -= NB;
-        return jb * BLOCK + (u % TB) * 64;
+        return s.j_begin + jb * BLOCK + (u % TB) * 64;
     };
     auto load_tile = [&](unsigned u) {
         const unsigned j = tile_first(u) + lane;
-        vec4           p = old_pos[j < s.n ? j : s.n - 1];
-        if (j >= s.n) p.w = 0;
+        vec4           p = old_pos[j < j_end ? j : j_end - 1];
+        if (j >= j_end) p.w = 0;
         return p;
     };
 
@@ -235,10 +226,10 @@ template <typename T, int R, int S> __global__ __launch_bounds__(64 * S) __attri
             }
         }
 #endif
-        const unsigned q     = u / TB;
+        const unsigned q     = u / TB;  // (diag: the block offset)
         const unsigned first = tile_first(u);
         const unsigned j     = first + lane;
-        const bool     tile_unit = block_unit && __builtin_amdgcn_ballot_w64(!(j < s.n && __builtin_bit_cast(bits, cur.w) == unit_bits)) == 0;
+        const bool     tile_unit = block_unit && __builtin_amdgcn_ballot_w64(!(j < j_end && __builtin_bit_cast(bits, cur.w) == unit_bits)) == 0;
         T   jx = cur.x, jy = cur.y, jz = cur.z, jm = cur.w * inv_mref;
         vec rx = LT::splat(0), ry = LT::splat(0), rz = LT::splat(0);
         T   scale;  // what the reaction sums are still to be multiplied by
@@ -255,7 +246,7 @@ template <typename T, int R, int S> __global__ __launch_bounds__(64 * S) __attri
 #pragma unroll
             for (int k = 0; k < I; ++k) {
                 const unsigned i = block_base + k * 64 + lane;
-                LT::set(mi[k / W], k % W, i < s.n ? old_pos[i].w : T(0));
+                LT::set(mi[k / W], k % W, i < i_end ? old_pos[i].w : T(0));
             }
 #pragma unroll 1
             for (int it = 0; it < 64 / UNR; ++it) {
@@ -265,12 +256,13 @@ template <typename T, int R, int S> __global__ __launch_bounds__(64 * S) __attri
             scale = T(1);
         }
         // 64 steps on: every sum is back in the lane of its body j.  Keep the reaction only when the partner does not list the pair too.
-        const bool symmetric = q != 0 && !(even && q == Q);
-        if (symmetric && j < s.n) {
-            T* const out = s.work + (static_cast<size_t>(s.splits) + (q - 1)) * 3 * s.npad + j;
-            out[0]                               = both_halves(rx) * scale;
-            out[static_cast<size_t>(s.npad)]     = both_halves(ry) * scale;
-            out[2 * static_cast<size_t>(s.npad)] = both_halves(rz) * scale;
+        const bool     symmetric = diag ? (q != 0 && !(even && q == Q)) : (s.keep != 0);
+        const unsigned slot_of   = diag ? q - 1 : a;
+        if (symmetric && j < j_end) {
+            T* const out = s.react + static_cast<size_t>(slot_of) * 3 * s.react_plane + (j - s.react_origin);
+            out[0]                                      = both_halves(rx) * scale;
+            out[static_cast<size_t>(s.react_plane)]     = both_halves(ry) * scale;
+            out[2 * static_cast<size_t>(s.react_plane)] = both_halves(rz) * scale;
         }
         cur = next;
         ++done;
@@ -312,39 +304,41 @@ template <typename T, int R, int S> __global__ __launch_bounds__(64 * S) __attri
             LT::set(az[k / W], k % W, LT::get(az[k / W], k % W) + red[(((w - 1) * 3 + 2) * I + k) * 64 + lane]);
         }
     }
-    T* const self = s.work + static_cast<size_t>(c) * 3 * s.npad;
+    T* const self = s.self + static_cast<size_t>(s.self_first + c) * 3 * s.self_plane;
 #pragma unroll
     for (int k = 0; k < I; ++k) {
         const unsigned i = block_base + k * 64 + lane;
-        if (i >= s.n) continue;
-        self[i]                                   = LT::get(ax[k / W], k % W) * m_ref;
-        self[static_cast<size_t>(s.npad) + i]     = LT::get(ay[k / W], k % W) * m_ref;
-        self[2 * static_cast<size_t>(s.npad) + i] = LT::get(az[k / W], k % W) * m_ref;
+        if (i >= i_end) continue;
+        const size_t at = i - s.self_origin;
+        self[at]                                         = LT::get(ax[k / W], k % W) * m_ref;
+        self[static_cast<size_t>(s.self_plane) + at]     = LT::get(ay[k / W], k % W) * m_ref;
+        self[2 * static_cast<size_t>(s.self_plane) + at] = LT::get(az[k / W], k % W) * m_ref;
     }
 }
 
-// The second kernel: a body's i-side sums and reaction slots, added in a fixed order, then integrateBodies
-// (bodysystemcuda.cu:166-183): v = (v + a*dt)*damping; p += v*dt.  A 256-thread workgroup takes 64 bodies: wave w adds the
-// slots q = w, w+4, w+8, ... (four interleaved running sums: shorter chains, smaller rounding error, coalesced reads), the
-// four are combined as (t0 + t1) + (t2 + t3) through LDS -- the same order for any launch geometry.
-template <typename T> __global__ __launch_bounds__(256) void pair_finish(PairArgs<T> s) {
+// Sum of `slots` planes at r[q * stride], q ascending, as four interleaved running sums (shorter chains, smaller rounding
+// error), wave w of the 256-thread workgroup taking q = w, w+4, ...; the caller combines (t0 + t1) + (t2 + t3).
+template <typename T> __device__ __forceinline__ T quarter_sum(const T* r, size_t stride, unsigned slots, unsigned wave) {
+    T sum = 0;
+    for (unsigned q = wave; q < (slots & ~3u); q += 4) sum += r[static_cast<size_t>(q) * stride];
+    if (wave == 0)
+        for (unsigned q = slots & ~3u; q < slots; ++q) sum += r[static_cast<size_t>(q) * stride];  // the odd slots join t0
+    return sum;
+}
+
+// The last kernel of a step: a body's i-side sums and reaction sums, added in a fixed order, then integrateBodies
+// (bodysystemcuda.cu:166-183): v = (v + a*dt)*damping; p += v*dt.  A 256-thread workgroup takes 64 bodies (four waves = the
+// four interleaved sums over the reaction slots, combined through LDS: the same order for any launch geometry).
+template <typename T> __global__ __launch_bounds__(256) void pair_finish(FinishArgs<T> s) {
     using vec4 = typename Lane<T>::vec4;
     __shared__ T   part[3][3][64];  // [wave 1..3][component][body]
     const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const unsigned k    = blockIdx.x * 64 + lane;
-    const bool     live = k < s.n;
-    const size_t   plane = s.npad;
+    const unsigned k    = blockIdx.x * 64 + lane;  // relative to the rank's first body
+    const bool     live = k < s.count;
     T              t[3] = {0, 0, 0};
     if (live) {
 #pragma unroll
-        for (int comp = 0; comp < 3; ++comp) {
-            const T* r = s.work + (static_cast<size_t>(s.splits) * 3 + comp) * plane + k;  // slot q at r[q * 3 * plane]
-            T        sum = 0;
-            for (unsigned q = wave; q < (s.slots & ~3u); q += 4) sum += r[static_cast<size_t>(q) * 3 * plane];
-            if (wave == 0)
-                for (unsigned q = s.slots & ~3u; q < s.slots; ++q) sum += r[static_cast<size_t>(q) * 3 * plane];  // the odd slots join t0
-            t[comp] = sum;
-        }
+        for (int comp = 0; comp < 3; ++comp) t[comp] = quarter_sum(s.react + static_cast<size_t>(comp) * s.react_plane + k, 3 * static_cast<size_t>(s.react_plane), s.react_slots, wave);
     }
     if (wave != 0) {
 #pragma unroll
@@ -352,41 +346,76 @@ template <typename T> __global__ __launch_bounds__(256) void pair_finish(PairArg
     }
     __syncthreads();
     if (wave != 0 || !live) return;
-    T f[3];
+    const unsigned body = s.origin + k;
+    T              f[3];
 #pragma unroll
     for (int comp = 0; comp < 3; ++comp) {
         T own = 0;
-        for (unsigned c = 0; c < s.splits; ++c) own += s.work[(static_cast<size_t>(c) * 3 + comp) * plane + k];
-        f[comp] = own - ((t[comp] + part[0][comp][lane]) + (part[1][comp][lane] + part[2][comp][lane]));  // d = p_j - p_i: what body j feels from body i is -m_i d w
+        for (unsigned m = 0; m < s.n_self; ++m) {
+            const auto& set = s.self_set[m];
+            if (k < set.first || k - set.first >= set.count) continue;
+            for (unsigned c = 0; c < set.slots; ++c) own += s.self[(static_cast<size_t>(set.slot + c) * 3 + comp) * s.self_plane + k];
+        }
+        T others = (t[comp] + part[0][comp][lane]) + (part[1][comp][lane] + part[2][comp][lane]);
+        for (unsigned m = 0; m < s.n_recv; ++m) {
+            const auto& set = s.recv_set[m];
+            if (k < set.first || k - set.first >= set.count) continue;
+            others += s.recv[(static_cast<size_t>(m) * 3 + comp) * s.recv_plane + k];
+        }
+        f[comp] = own - others;  // d = p_j - p_i: what body j feels from body i is -m_i d w
     }
-    vec4 v  = reinterpret_cast<const vec4*>(s.vel)[k];
-    vec4 pn = reinterpret_cast<const vec4*>(s.old_pos)[k];
+    if (s.extra != nullptr) {
+        const vec4 e = reinterpret_cast<const vec4*>(s.extra)[body];
+        f[0] += e.x, f[1] += e.y, f[2] += e.z;
+    }
+    vec4 v  = reinterpret_cast<const vec4*>(s.vel)[body];
+    vec4 pn = reinterpret_cast<const vec4*>(s.old_pos)[body];
     v.x     = __builtin_fma(f[0], s.dt, v.x) * s.damping;
     v.y     = __builtin_fma(f[1], s.dt, v.y) * s.damping;
     v.z     = __builtin_fma(f[2], s.dt, v.z) * s.damping;
     pn.x    = __builtin_fma(v.x, s.dt, pn.x);
     pn.y    = __builtin_fma(v.y, s.dt, pn.y);
     pn.z    = __builtin_fma(v.z, s.dt, pn.z);
-    reinterpret_cast<vec4*>(s.new_pos)[k] = pn;
-    reinterpret_cast<vec4*>(s.vel)[k]     = v;
+    reinterpret_cast<vec4*>(s.new_pos)[body] = pn;
+    reinterpret_cast<vec4*>(s.vel)[body]     = v;
 }
 
-template <typename T, int R, int S> hipError_t launch_rs(const PairArgs<T>& args, const PairPlan& p, hipStream_t stream, bool prepare_only) {
-    if (p.lds_bytes > 64u * 1024u) {
+// Multi-GPU: the reaction sums of a rectangle, one plane per block of bodies i, folded into ONE array per body j (what
+// travels to the rank that owns those bodies): out[comp][j] = sum over the slots, same fixed order as above.
+template <typename T> __global__ __launch_bounds__(256) void pair_reduce(const T* react, unsigned react_plane, unsigned slots, T* out, unsigned out_plane, unsigned count) {
+    __shared__ T   part[3][3][64];
+    const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned k    = blockIdx.x * 64 + lane;
+    const bool     live = k < count;
+    T              t[3] = {0, 0, 0};
+    if (live) {
+#pragma unroll
+        for (int comp = 0; comp < 3; ++comp) t[comp] = quarter_sum(react + static_cast<size_t>(comp) * react_plane + k, 3 * static_cast<size_t>(react_plane), slots, wave);
+    }
+    if (wave != 0) {
+#pragma unroll
+        for (int comp = 0; comp < 3; ++comp) part[wave - 1][comp][lane] = t[comp];
+    }
+    __syncthreads();
+    if (wave != 0 || !live) return;
+#pragma unroll
+    for (int comp = 0; comp < 3; ++comp) out[static_cast<size_t>(comp) * out_plane + k] = (t[comp] + part[0][comp][lane]) + (part[1][comp][lane] + part[2][comp][lane]);
+}
+
+template <typename T, int R, int S> hipError_t launch_rs(const PairArgs<T>& args, unsigned grid, unsigned lds_bytes, hipStream_t stream, bool prepare_only) {
+    if (lds_bytes > 64u * 1024u) {
         if (const auto err = allow_large_lds<&pair_forces<T, R, S>>(); err != hipSuccess) return err;
     }
     if (prepare_only) return hipSuccess;
-    hipLaunchKernelGGL((pair_forces<T, R, S>), dim3(p.grid_blocks), dim3(64 * S), p.lds_bytes, stream, args);
-    if (const auto err = hipGetLastError(); err != hipSuccess) return err;
-    hipLaunchKernelGGL(pair_finish<T>, dim3((args.n + 63) / 64), dim3(256), 0, stream, args);
+    hipLaunchKernelGGL((pair_forces<T, R, S>), dim3(grid), dim3(64 * S), lds_bytes, stream, args);
     return hipGetLastError();
 }
 
-template <typename T, int R> hipError_t launch_r(const PairArgs<T>& args, const PairPlan& p, hipStream_t stream, bool prepare_only) {
-    switch (p.waves) {
-        case 4: return launch_rs<T, R, 4>(args, p, stream, prepare_only);
-        case 8: return launch_rs<T, R, 8>(args, p, stream, prepare_only);
-        case 16: return launch_rs<T, R, 16>(args, p, stream, prepare_only);
+template <typename T, int R> hipError_t launch_r(const PairArgs<T>& args, int waves, unsigned grid, unsigned lds_bytes, hipStream_t stream, bool prepare_only) {
+    switch (waves) {
+        case 4: return launch_rs<T, R, 4>(args, grid, lds_bytes, stream, prepare_only);
+        case 8: return launch_rs<T, R, 8>(args, grid, lds_bytes, stream, prepare_only);
+        case 16: return launch_rs<T, R, 16>(args, grid, lds_bytes, stream, prepare_only);
         default: return hipErrorInvalidValue;
     }
 }
@@ -431,24 +460,66 @@ template <typename T> PairPlan plan_pair(unsigned n, int cu_count, int ovr_r, in
     return p;
 }
 
-template <typename T> hipError_t launch_pair(const Shard<T>& s, const PairPlan& p, void* workspace, hipStream_t stream, bool prepare_only) {
-    PairArgs<T> args{};
-    args.old_pos = s.old_pos, args.new_pos = s.new_pos, args.vel = s.vel, args.work = static_cast<T*>(workspace);
-    args.n = s.i_count, args.blocks = p.blocks, args.npad = p.blocks * p.block_bodies, args.splits = p.splits, args.slots = p.slots;
-    args.dt = s.dt, args.damping = s.damping, args.eps2 = s.eps2;
-    constexpr int W = sizeof(T) == 4 ? 2 : 1;
-    (void)W;
-    switch (p.vectors_per_lane) {
-        case 1: return launch_r<T, 1>(args, p, stream, prepare_only);
-        case 2: return launch_r<T, 2>(args, p, stream, prepare_only);
-        case 4: return launch_r<T, 4>(args, p, stream, prepare_only);
+template <typename T> hipError_t launch_pair_tile(const PairArgs<T>& args, const PairGeom& g, hipStream_t stream, bool prepare_only) {
+    constexpr int  W         = sizeof(T) == 4 ? 2 : 1;
+    PairArgs<T>    a         = args;
+    const unsigned block     = 64u * static_cast<unsigned>(g.vectors_per_lane * W);
+    a.blocks                 = (a.i_count + block - 1) / block;
+    a.splits                 = g.splits;
+    const unsigned lds_bytes = static_cast<unsigned>(static_cast<size_t>(g.waves) * 3 * g.vectors_per_lane * W * 64 * sizeof(T)) + 256u;
+    if (a.blocks == 0) return hipSuccess;
+    switch (g.vectors_per_lane) {
+        case 1: return launch_r<T, 1>(a, g.waves, a.blocks * a.splits, lds_bytes, stream, prepare_only);
+        case 2: return launch_r<T, 2>(a, g.waves, a.blocks * a.splits, lds_bytes, stream, prepare_only);
+        case 4: return launch_r<T, 4>(a, g.waves, a.blocks * a.splits, lds_bytes, stream, prepare_only);
         default: return hipErrorInvalidValue;
     }
+}
+
+template <typename T> hipError_t launch_pair_reduce(const T* react, unsigned react_plane, unsigned slots, T* out, unsigned out_plane, unsigned count, hipStream_t stream) {
+    if (count == 0) return hipSuccess;
+    hipLaunchKernelGGL(pair_reduce<T>, dim3((count + 63) / 64), dim3(256), 0, stream, react, react_plane, slots, out, out_plane, count);
+    return hipGetLastError();
+}
+
+template <typename T> hipError_t launch_pair_finish(const FinishArgs<T>& args, hipStream_t stream) {
+    if (args.count == 0) return hipSuccess;
+    hipLaunchKernelGGL(pair_finish<T>, dim3((args.count + 63) / 64), dim3(256), 0, stream, args);
+    return hipGetLastError();
+}
+
+// One GPU: the tournament over the whole system, then the finish kernel.  Workspace: [C][3][npad] i-side sums, [slots][3][npad] reaction sums.
+template <typename T> hipError_t launch_pair(const Shard<T>& s, const PairPlan& p, void* workspace, hipStream_t stream, bool prepare_only) {
+    const unsigned npad = p.blocks * p.block_bodies;
+    T* const       work = static_cast<T*>(workspace);
+    PairArgs<T>    a{};
+    a.old_pos = s.old_pos, a.self = work, a.react = work + static_cast<size_t>(p.splits) * 3 * npad;
+    a.n = s.i_count, a.i_begin = 0, a.i_count = s.i_count, a.j_begin = 0, a.j_count = s.i_count;
+    a.diag = 1, a.keep = 1;
+    a.self_first = 0, a.self_origin = 0, a.self_plane = npad, a.react_origin = 0, a.react_plane = npad;
+    a.eps2 = s.eps2;
+    const PairGeom g{p.vectors_per_lane, p.waves, p.splits};
+    if (const auto err = launch_pair_tile<T>(a, g, stream, prepare_only); err != hipSuccess || prepare_only) return err;
+    FinishArgs<T> f{};
+    f.old_pos = s.old_pos, f.new_pos = s.new_pos, f.vel = s.vel;
+    f.self = a.self, f.react = a.react, f.recv = nullptr, f.extra = nullptr;
+    f.origin = 0, f.count = s.i_count;
+    f.self_plane = npad, f.react_plane = npad, f.react_slots = p.slots, f.recv_plane = 0;
+    f.n_self = 1, f.n_recv = 0;
+    f.self_set[0] = {0u, p.splits, 0u, s.i_count};
+    f.dt = s.dt, f.damping = s.damping;
+    return launch_pair_finish<T>(f, stream);
 }
 
 template PairPlan   plan_pair<float>(unsigned, int, int, int, int);
 template PairPlan   plan_pair<double>(unsigned, int, int, int, int);
 template hipError_t launch_pair<float>(const Shard<float>&, const PairPlan&, void*, hipStream_t, bool);
 template hipError_t launch_pair<double>(const Shard<double>&, const PairPlan&, void*, hipStream_t, bool);
+template hipError_t launch_pair_tile<float>(const PairArgs<float>&, const PairGeom&, hipStream_t, bool);
+template hipError_t launch_pair_tile<double>(const PairArgs<double>&, const PairGeom&, hipStream_t, bool);
+template hipError_t launch_pair_reduce<float>(const float*, unsigned, unsigned, float*, unsigned, unsigned, hipStream_t);
+template hipError_t launch_pair_reduce<double>(const double*, unsigned, unsigned, double*, unsigned, unsigned, hipStream_t);
+template hipError_t launch_pair_finish<float>(const FinishArgs<float>&, hipStream_t);
+template hipError_t launch_pair_finish<double>(const FinishArgs<double>&, hipStream_t);
 
 }  // namespace nb

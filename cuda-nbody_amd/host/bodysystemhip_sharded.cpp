@@ -101,8 +101,32 @@ template <std::floating_point T> auto BodySystemHIPSharded<T>::get_velocity() co
     return host_vel_;
 }
 
+// The library allocates nothing: each shard owns what nb_comm_workspace_bytes_* asks for in the current mode (0 bytes: none).
+template <std::floating_point T> auto BodySystemHIPSharded<T>::ensure_workspaces() -> void {
+    const int mode = nbody_hip::use_workspace() ? nbody_hip::integration_mode() : -2;
+    if (mode == workspace_mode_) return;
+    workspace_mode_ = mode;
+    for (std::size_t g = 0; g < shards_.size(); ++g) {
+        std::size_t need = 0;
+        if (mode >= 0) {
+            if constexpr (std::same_as<T, float>) {
+                hip_check(nb_comm_workspace_bytes_f32(comms_[g], this->nb_bodies_, mode, &need), "nb_comm_workspace_bytes_f32");
+            } else {
+                hip_check(nb_comm_workspace_bytes_f64(comms_[g], this->nb_bodies_, mode, &need), "nb_comm_workspace_bytes_f64");
+            }
+        }
+        CurrentDevice scope(shards_[g].device);
+        if (need > shards_[g].workspace.size()) {
+            hip_check(nb_device_synchronize(), "nb_device_synchronize");  // nothing may still be using the old one
+            shards_[g].workspace = DeviceArray<unsigned char>(need);
+        }
+        hip_check(nb_comm_set_workspace(comms_[g], need != 0 ? shards_[g].workspace.data() : nullptr, need), "nb_comm_set_workspace");
+    }
+}
+
 template <std::floating_point T> auto BodySystemHIPSharded<T>::update(T deltaTime) -> void {
     this->apply_softening();
+    ensure_workspaces();
     const auto               n = shards_.size();
     std::vector<T*>          to(n), vel(n), acc(n);
     std::vector<const T*>    from(n);

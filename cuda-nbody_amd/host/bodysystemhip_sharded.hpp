@@ -6,6 +6,8 @@
 // slice of each new position array -- and holds full-size position arrays; every update() is one
 // nb_sharded_step_all_* call (include/nbody_hip.h): per device the kernels of the own slice and of each position tile as
 // it arrives over RCCL / xGMI, then the tile exchange of the new positions.  STRICT mode is bit-identical to one GPU.
+// Like BodySystemHIPDefault, each shard owns the scratch memory the library asks for (nb_comm_workspace_bytes_*): FAST then
+// evaluates every pair of bodies once, across the devices too (reaction sums travel to their owners); --no-workspace: off.
 #pragma once
 
 #include "bodysystemhip.hpp"
@@ -34,8 +36,11 @@ template <std::floating_point T> class BodySystemHIPSharded final : public BodyS
         DeviceArray<T> pos[2];
         DeviceArray<T> vel;
         DeviceArray<T> acc;
+        DeviceArray<unsigned char> workspace;
     };
     auto allocate(std::span<const int> devices) -> void;
+    auto ensure_workspaces() -> void;  // (re)lends every shard what the current mode asks for
+    int  workspace_mode_ = -1;
 
     std::vector<Shard>     shards_;
     std::vector<nb_comm_t> comms_;

@@ -185,10 +185,24 @@ NB_API int nb_comm_init_rank(nb_comm_t* comm, const void* id, int world_size, in
 NB_API int nb_comm_init_all(nb_comm_t* comms /* [num_devices] */, int num_devices, const int* devices /* NULL = 0..n-1 */);
 NB_API int nb_comm_destroy(nb_comm_t comm);
 NB_API int nb_comm_info(nb_comm_t comm, int* rank, int* world_size, int* device);
-/* Lend a rank the scratch memory of nb_workspace_bytes_*(N, mode) (caller-owned, as everywhere): a communicator of ONE rank
- * then steps through nb_integrate_ws_* -- the 1-GPU point of a scaling series is the best single-GPU step.  With more
- * ranks the workspace is not used yet (the tiles are rectangles of the pair matrix). */
+/* Lend a rank scratch memory (caller-owned, as everywhere; nb_comm_workspace_bytes_* says how much for this communicator,
+ * 0 = none needed).  FAST mode then evaluates every PAIR of bodies once, across the ranks too: a communicator of one rank
+ * steps through nb_integrate_ws_*; with G ranks, rank r evaluates its own slice against itself and against the slices of
+ * ranks r+1 .. r+G/2 pairwise, keeps its own bodies' sums and sends the reaction sums (N/G * 12 B per partner, one more
+ * RCCL send/recv round per partner on the exchange stream) to their owners -- half the arithmetic per rank.  Every local
+ * rank of a step must have been lent enough, or the step is the one-sided tile schedule.  STRICT never uses it. */
+NB_API int nb_comm_workspace_bytes_f32(nb_comm_t comm, unsigned num_bodies, int mode, size_t* bytes);
+NB_API int nb_comm_workspace_bytes_f64(nb_comm_t comm, unsigned num_bodies, int mode, size_t* bytes);
 NB_API int nb_comm_set_workspace(nb_comm_t comm, void* workspace, size_t workspace_bytes);
+NB_API int nb_comm_set_pair_min_slice(int min_bodies_per_rank); /* 0 = automatic (2 048); tests run small slices pairwise */
+/* Tuning / projection hook (bench.py --emulate-gpus): exactly the kernels that rank `rank` of a `world_size`-rank pairwise step
+ * launches, on the current device, with no communicator and no exchange (what the other ranks would send is whatever the
+ * workspace holds: the positions written are meaningless, the kernel time is the point).  workspace == NULL: *workspace_bytes
+ * is set to what the rank needs. */
+NB_API int nb_emulate_pair_rank_f32(float* new_positions, const float* old_positions, float* velocities, void* workspace, size_t* workspace_bytes,
+                                    unsigned num_bodies, int world_size, int rank, float delta_time, float damping, nb_stream_t stream);
+NB_API int nb_emulate_pair_rank_f64(double* new_positions, const double* old_positions, double* velocities, void* workspace, size_t* workspace_bytes,
+                                    unsigned num_bodies, int world_size, int rank, double delta_time, double damping, nb_stream_t stream);
 NB_API int nb_sharded_step_f32(nb_comm_t comm, float* new_positions, const float* old_positions, float* velocities, float* acc,
                                unsigned num_bodies, float delta_time, float damping, int block_size, int mode, nb_stream_t stream);
 NB_API int nb_sharded_step_f64(nb_comm_t comm, double* new_positions, const double* old_positions, double* velocities, double* acc,

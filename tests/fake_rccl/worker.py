@@ -3,7 +3,9 @@ nb_exchange_*, nb_allgather_*) with G logical ranks that all live on device 0, R
 tests/fake_rccl/libfake_rccl.so through NBODY_RCCL_LIB (set by the parent; it must be in the environment before the
 library resolves RCCL, which happens once per process -- hence a process of its own).
 
-    python worker.py <case> <in.npz> <out.npz> [G] [steps] [mode] [streams]
+    python worker.py <case> <in.npz> <out.npz> [G] [steps] [mode] [streams] [ws]
+
+`ws`: every rank is lent the workspace nb_comm_workspace_bytes_* asks for (FAST then takes the pairwise step across the ranks).
 
 Everything here goes through ctypes into libnbody_hip.so; nothing is computed in Python.  The parent compares the arrays
 written to <out.npz> with the CPU oracle / the golden fixtures.
@@ -53,6 +55,7 @@ def main():
     steps = int(sys.argv[5]) if len(sys.argv) > 5 else 5
     mode_name = sys.argv[6] if len(sys.argv) > 6 else "strict"
     own_streams = (sys.argv[7] if len(sys.argv) > 7 else "streams") == "streams"
+    with_workspace = len(sys.argv) > 8 and sys.argv[8] == "ws"
     assert os.environ.get("NBODY_RCCL_LIB", "").endswith("libfake_rccl.so"), "the parent must point NBODY_RCCL_LIB at the test double"
 
     pkg = entry.load_package()
@@ -72,6 +75,22 @@ def main():
         pkg.check(lib.nb_set_softening_sq_f32(np.float32(soft * soft)))
     else:
         pkg.check(lib.nb_set_softening_sq_f64(float(soft * soft)))
+    if with_workspace:
+        pkg.check(lib.nb_comm_set_pair_min_slice(64), "nb_comm_set_pair_min_slice")  # (the test systems are small)
+    ws_bytes_fn = lib.nb_comm_workspace_bytes_f32 if f32 else lib.nb_comm_workspace_bytes_f64
+    workspaces = []
+
+    def lend_workspace(comm):
+        if not with_workspace:
+            return 0
+        need = ctypes.c_size_t(0)
+        pkg.check(ws_bytes_fn(comm, n, mode, ctypes.byref(need)), "nb_comm_workspace_bytes")
+        if need.value:
+            buf = pkg.DeviceBuffer(need.value)
+            workspaces.append(buf)
+            pkg.check(lib.nb_comm_set_workspace(comm, buf.ptr, need.value), "nb_comm_set_workspace")
+        return need.value
+
     step_all = lib.nb_sharded_step_all_f32 if f32 else lib.nb_sharded_step_all_f64
     step_one = lib.nb_sharded_step_f32 if f32 else lib.nb_sharded_step_f64
     out = {}
@@ -92,6 +111,7 @@ def main():
                             arr([r.bufs[3].ptr for r in ranks]), n, dt, one, 256, mode, arr([r.stream for r in ranks]))
         rc_single = step_one(comms[0], ranks[0].bufs[1].ptr, ranks[0].bufs[0].ptr, ranks[0].bufs[2].ptr, ranks[0].bufs[3].ptr, n, dt, one, 256, mode, ranks[0].stream)
         out["rejected"] = np.array([rc_subset, rc_twice, rc_single])
+        out["workspace_bytes"] = np.array([lend_workspace(c) for c in comms])
         for _ in range(steps):
             rd = ranks[0].read
             pkg.check(step_all(comms, G, arr([r.bufs[1 - rd].ptr for r in ranks]), arr([r.bufs[rd].ptr for r in ranks]), arr([r.bufs[2].ptr for r in ranks]),
@@ -121,6 +141,7 @@ def main():
                 pkg.check(lib.nb_comm_info(comm, ctypes.byref(r), ctypes.byref(w), ctypes.byref(d)))
                 assert (r.value, w.value, d.value) == (k, G, 0)
                 if case == "threads":
+                    lend_workspace(comm)
                     me = Rank(pkg, pos0, vel0, own_streams)
                     for _ in range(steps):
                         pkg.check(step_one(comm, me.bufs[1 - me.read].ptr, me.bufs[me.read].ptr, me.bufs[2].ptr, me.bufs[3].ptr, n, dt, one, 256, mode, me.stream), "nb_sharded_step")

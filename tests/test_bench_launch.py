@@ -106,3 +106,19 @@ def test_default_line_carries_every_baseline_config():
     assert line["roofline"]["executed"]["frac"] < line["roofline"]["frac"]
     for c in line["configs"]:
         assert c["ms_per_step"] > 0 and 0 < c["frac"] < 1.3  # (pairwise: the algorithmic count may pass the one-sided peak)
+
+
+@pytest.mark.gpu
+def test_emulated_rank_of_a_pairwise_multi_gpu_step():
+    """`bench.py --emulate-gpus 8`: one rank's kernels of the pairwise step across 8 ranks (nb_emulate_pair_rank_*), timed on the
+    one GPU -- the compute side of the strong-scaling projection; and the one-sided tile schedule for comparison."""
+    out = run_bench("--emulate-gpus", "8", "--steps", "5", "--warmup", "1", "--no-cpu-baseline")
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["emulated_gpus"] == 8 and "pairwise" in line["schedule"] and len(line["ranks"]) == 3
+    pair_ms = max(r["ms_per_step_kernels_only"] for r in line["ranks"])
+    out = run_bench("--emulate-gpus", "8", "--steps", "5", "--warmup", "1", "--no-cpu-baseline", "--layout", "one-sided")
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    one_ms = max(r["ms_per_step_kernels_only"] for r in line["ranks"])
+    assert 0 < pair_ms < one_ms

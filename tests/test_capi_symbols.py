@@ -223,8 +223,7 @@ def test_pairwise_inner_loops_keep_their_instruction_mix():
     csrc = os.path.join(ROOT, "cuda-nbody_amd", "csrc")
     subprocess.run(["make", "-s", "-C", csrc, "asm"], check=True, capture_output=True)
     lines = open(os.path.join(csrc, "nbody_pair.s")).read().split("\n")
-    kernel = "_ZN2nb12_GLOBAL__N_111pair_forcesIfLi4ELi8EEEvNS0_8PairArgsIT_EE"
-    start = next(i for i, l in enumerate(lines) if l.startswith(kernel + ":"))
+    start = next(i for i, l in enumerate(lines) if re.match(r"_ZN2nb\S*pair_forcesIfLi4ELi8EE\S*:", l))  # pair_forces<float, 4, 8>
     end = next(i for i in range(start, len(lines)) if lines[i].startswith(".Lfunc_end"))
     mixes = []
     for i in range(start, end):
@@ -237,6 +236,7 @@ def test_pairwise_inner_loops_keep_their_instruction_mix():
         rotations = sum(1 for l in body if l.startswith("v_mov_b32_dpp") and "wave_ror:1" in l)
         other = sum(1 for l in body if l.startswith("v_") and not l.startswith(("v_pk_", "v_rsq_f32", "v_mov_b32")))
         mixes.append((count("v_pk_"), count("v_rsq_f32"), rotations, other, count("scratch_"), count("ds_"), count("s_nop")))
-    assert sorted(mixes) == [(224, 32, 36, 0, 0, 0, 0), (256, 32, 40, 0, 0, 0, 0)], mixes
+    assert sorted(m[:6] for m in mixes) == [(224, 32, 36, 0, 0, 0), (256, 32, 40, 0, 0, 0)], mixes
+    assert all(m[6] <= 2 for m in mixes), mixes  # at most a stray hazard s_nop per four steps (296 instructions)
     tail = "\n".join(lines[end:end + 60])
     assert int(re.search(r"; NumVgprs: (\d+)", tail).group(1)) <= 128

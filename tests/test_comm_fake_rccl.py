@@ -33,13 +33,14 @@ def _env():
     return env
 
 
-def _run(tmp_path, case, pos0, vel0, world, steps, mode, streams="streams"):
+def _run(tmp_path, case, pos0, vel0, world, steps, mode, streams="streams", workspace=False):
     src, dst = tmp_path / f"in_{case}.npz", tmp_path / f"out_{case}.npz"
     np.savez(src, pos=pos0, vel=vel0)
-    r = subprocess.run([sys.executable, os.path.join(FAKE_DIR, "worker.py"), case, str(src), str(dst), str(world), str(steps), mode, streams],
+    r = subprocess.run([sys.executable, os.path.join(FAKE_DIR, "worker.py"), case, str(src), str(dst), str(world), str(steps), mode, streams, "ws" if workspace else "-"],
                        env=_env(), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
-    return np.load(dst, allow_pickle=False)
+    with np.load(dst, allow_pickle=False) as data:  # read everything now: the next run of the same case rewrites the file
+        return {k: data[k] for k in data.files}
 
 
 def test_fake_rccl_builds_and_exports_what_the_library_resolves():
@@ -187,3 +188,93 @@ def test_cli_devices_sharing_one_gpu_match_golden(tmp_path, devices):
         assert raw[:4 * n].tobytes() == g["pos_10"].tobytes() and raw[4 * n:].tobytes() == g["vel_10"].tobytes()
     r = subprocess.run([cli, "--compare", "--numbodies=4096", f"--devices={devices}"], env=_env(), capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "  OK" in r.stdout, r.stdout + r.stderr
+
+
+# ------------------------------------------------------------------------------------------------ pairs once, across the ranks
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("world", [2, 3, 4, 5])
+def test_pairwise_step_across_ranks(tmp_path, oracle, world, dtype):
+    """Every rank lent a workspace: FAST evaluates each pair of bodies once across the ranks -- the diagonal pairwise, the
+    rectangles against ranks r+1 .. r+G/2 pairwise with the reaction sums SENT to their owners (one more send/recv round per
+    partner), for an even world the rectangle at distance G/2 split between the two partners.  Worlds of 2 .. 5 (odd and even,
+    with and without a split rectangle), a slice that is not a multiple of a block: all ranks hold the same positions, within
+    the FAST tolerance of the CPU path, and the same bits in a second run; the transport saw the extra rounds."""
+    n, steps = world * 1000, 4
+    n -= n % 8
+    n -= n % world
+    pos0, vel0 = oracle.startup_state((n + 7) // 8 * 8, np.float32)
+    pos0, vel0 = pos0[:4 * n].astype(dtype), vel0[:4 * n].astype(dtype)
+    got = _run(tmp_path, "all", pos0, vel0, world, steps, "fast", workspace=True)
+    assert np.all(got["workspace_bytes"] > 0)
+    sends, recvs, gathers, groups, copies = got["counters"]
+    assert sends == recvs == (world - 1 + world // 2) * world * steps and groups == (world - 1 + world // 2) * steps
+    ref_p, ref_v = pos0.copy(), vel0.copy()
+    oracle.update(ref_p, ref_v, dtype(np.float32(0.016)), steps=steps)
+    for k in range(1, world):
+        assert got[f"pos_{k}"].tobytes() == got["pos_0"].tobytes()
+    tol = 1e-5 if dtype == np.float32 else 1e-12
+    np.testing.assert_allclose(got["pos_0"], ref_p, rtol=tol, atol=tol)
+    vel = np.concatenate([got[f"vel_{k}"] for k in range(world)])
+    np.testing.assert_allclose(vel, ref_v, rtol=10 * tol, atol=10 * tol)
+    again = _run(tmp_path, "all", pos0, vel0, world, steps, "fast", workspace=True)
+    assert again["pos_0"].tobytes() == got["pos_0"].tobytes()
+    one_sided = _run(tmp_path, "all", pos0, vel0, world, steps, "fast", workspace=False)
+    assert one_sided["pos_0"].tobytes() != got["pos_0"].tobytes()  # (it really is another schedule)
+    # STRICT ignores the workspace: still the CPU path's bits
+    strict = _run(tmp_path, "all", pos0, vel0, world, steps, "strict", workspace=True)
+    assert strict["pos_0"].tobytes() == ref_p.tobytes()
+
+
+@pytest.mark.gpu
+def test_pairwise_step_across_ranks_one_thread_per_rank(tmp_path, oracle):
+    n, steps, world = 4096, 4, 4
+    pos0, vel0 = oracle.startup_state(n, np.float32)
+    got = _run(tmp_path, "threads", pos0, vel0, world, steps, "fast", workspace=True)
+    sends, recvs, gathers, groups, copies = got["counters"]
+    assert sends == recvs == (world - 1 + world // 2) * world * steps
+    ref_p, ref_v = pos0.copy(), vel0.copy()
+    oracle.update(ref_p, ref_v, np.float32(0.016), steps=steps)
+    for k in range(world):
+        assert got[f"pos_{k}"].tobytes() == got["pos_0"].tobytes()
+    np.testing.assert_allclose(got["pos_0"], ref_p, rtol=1e-5, atol=1e-5)
+    same = _run(tmp_path, "all", pos0, vel0, world, steps, "fast", workspace=True)
+    assert same["pos_0"].tobytes() == got["pos_0"].tobytes()  # one thread for all ranks or one per rank: the same sums in the same order
+
+
+@pytest.mark.gpu
+def test_pairwise_step_across_ranks_full_size(tmp_path, oracle):
+    """262 144 bodies over 4 and 8 ranks (BASELINE configs[2] as the strong-scaling series shards it), one step held tightly and
+    three loosely against one rank (this system amplifies any difference ~10x per step, see above)."""
+    n = 262144
+    pos0, vel0 = oracle.startup_state(n, np.float32)
+    for world in (4, 8):
+        for steps, tol in ((1, 2e-5), (3, 5e-3)):
+            got = _run(tmp_path, "all", pos0, vel0, world, steps, "fast", workspace=True)
+            for k in range(1, world):
+                assert got[f"pos_{k}"].tobytes() == got["pos_0"].tobytes()
+            np.testing.assert_allclose(got["pos_0"], got["single_pos"], rtol=0, atol=tol)
+
+
+@pytest.mark.gpu
+def test_cli_sharded_fast_owns_workspaces(tmp_path):
+    """`nbody --devices=0,0,0,0` in FAST mode: BodySystemHIPSharded lends every shard the workspace the library asks for, so the
+    step is the pairwise one across the shards; `--no-workspace` is the one-sided tile schedule.  Same trajectory up to summation
+    order as each other and as the single-GPU run, different bits; --compare passes; the benchmark lines print."""
+    cli = os.path.join(ROOT, "cuda-nbody_amd", "nbody")
+    n = 32768
+    dumps = {}
+    for name, extra in (("pairwise", ["--devices=0,0,0,0"]), ("one_sided", ["--devices=0,0,0,0", "--no-workspace"]), ("single", [])):
+        dump = tmp_path / f"{name}.bin"
+        r = subprocess.run([cli, f"--numbodies={n}", "--steps=3", f"--dump={dump}", *extra], env=_env(), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        dumps[name] = np.fromfile(dump, dtype=np.float32)
+    assert dumps["pairwise"].tobytes() != dumps["one_sided"].tobytes()
+    np.testing.assert_allclose(dumps["pairwise"], dumps["one_sided"], rtol=5e-5, atol=5e-5)
+    np.testing.assert_allclose(dumps["pairwise"], dumps["single"], rtol=5e-5, atol=5e-5)
+    r = subprocess.run([cli, "--compare", f"--numbodies={n}", "--devices=0,0,0"], env=_env(), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 1 and "multiple of the number of devices" in r.stderr  # 32 768 bodies do not shard over 3 devices
+    r = subprocess.run([cli, "--compare", f"--numbodies={n}", "--devices=0,0,0,0"], env=_env(), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "  OK" in r.stdout, r.stdout + r.stderr
+    r = subprocess.run([cli, "--benchmark", f"--numbodies={n}", "--devices=0,0", "-i", "4"], env=_env(), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "billion interactions per second" in r.stdout, r.stdout + r.stderr
