@@ -236,6 +236,12 @@ template <typename T> int plan_query(unsigned i_count, unsigned j_count, nb_laun
 
 }  // namespace
 
+namespace nb {
+void pair_plan_overrides(int* vectors_per_lane, int* waves, int* splits) {
+    *vectors_per_lane = g_pair_r.load(), *waves = g_pair_s.load(), *splits = g_pair_c.load();
+}
+}  // namespace nb
+
 extern "C" {
 
 const char* nb_error_string(int code) {

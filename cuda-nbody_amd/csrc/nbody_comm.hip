@@ -259,7 +259,10 @@ template <typename T> PairShard plan_pair_shard(unsigned num_bodies, int G, int 
     if (G < 2 || num_bodies % static_cast<unsigned>(G)) return p;
     p.ni = num_bodies / static_cast<unsigned>(G);
     if (p.ni < static_cast<unsigned>(min_slice > 0 ? min_slice : 2048) || G / 2 > nb::kMaxRecv || G / 2 + 1 > nb::kMaxSelfSets) return p;
-    const int R = (sizeof(T) == 4 ? p.ni >= 16384 : p.ni >= 8192) ? 4 : 2;
+    int ovr_r = 0, ovr_s = 0, ovr_c = 0;
+    nb::pair_plan_overrides(&ovr_r, &ovr_s, &ovr_c);  // (tuning sweeps: tools/pair_rank_probe.py)
+    const int R = ovr_r > 0 ? ovr_r : ((sizeof(T) == 4 ? p.ni >= 16384 : p.ni >= 8192) ? 4 : 2);
+    const int S = ovr_s > 0 ? ovr_s : 8;
     p.block  = 64u * static_cast<unsigned>(R) * W;
     p.blocks = (p.ni + p.block - 1) / p.block;
     p.plane  = (p.ni + 63u) / 64u * 64u;
@@ -269,11 +272,13 @@ template <typename T> PairShard plan_pair_shard(unsigned num_bodies, int G, int 
     p.diag_slots = p.blocks < 2 ? 0u : ((p.blocks & 1u) ? p.blocks / 2 : p.blocks / 2 - 1);
     auto splits = [&](unsigned units) {  // workgroups per block: fill the chip (~512 workgroups of 8 waves) while a wave keeps >= 2 units
         unsigned C = 1;
-        while (p.blocks * C * 2 <= 512 && units >= C * 2 * 8 * 2) C *= 2;
+        while (p.blocks * C * 2 <= 512 && units >= C * 2 * static_cast<unsigned>(S) * 2) C *= 2;
+        if (ovr_c > 0) C = static_cast<unsigned>(ovr_c);
+        while (C > 1 && units < C * static_cast<unsigned>(S)) C /= 2;
         return C;
     };
-    p.diag = {R, 8, splits((p.blocks / 2 + 1) * static_cast<unsigned>(R) * W)};
-    p.rect = {R, 8, splits((p.ni + 63) / 64)};
+    p.diag = {R, S, splits((p.blocks / 2 + 1) * static_cast<unsigned>(R) * W)};
+    p.rect = {R, S, splits((p.ni + 63) / 64)};
     const size_t plane3 = 3 * static_cast<size_t>(p.plane);
     p.self_at    = 0;
     p.react_d_at = p.self_at + (p.diag.splits + static_cast<size_t>(p.H) * p.rect.splits) * plane3;

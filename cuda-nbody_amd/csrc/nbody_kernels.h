@@ -100,6 +100,9 @@ template <typename T> struct FinishArgs {
     T dt, damping;
 };
 
+// nb_set_pair_plan_override: 0 = automatic (defined in nbody_capi.hip; the multi-GPU layer honours it for its tiles too)
+void pair_plan_overrides(int* vectors_per_lane, int* waves, int* splits);
+
 struct PairGeom {
     int      vectors_per_lane;  // R
     int      waves;             // S

@@ -3,7 +3,7 @@
 (G launches of nb_integrate_shard_*, what round 2 ran) against the pairwise schedule across ranks (nb_emulate_pair_rank_*:
 diagonal + G/2 rectangles + their folds + finish).  Projection of the compute side of strong scaling, not a measurement of it.
 
-    python3 tools/pair_rank_probe.py [bodies] [f32|f64]
+    python3 tools/pair_rank_probe.py [bodies] [f32|f64] [R S C]      (R S C: override the tiles' geometry, 0 = automatic)
 """
 import ctypes
 import json
@@ -30,6 +30,8 @@ pkg.check(lib.nb_set_softening_sq_f32(np.float32(soft * soft)) if f32 else lib.n
 shard = lib.nb_integrate_shard_f32 if f32 else lib.nb_integrate_shard_f64
 emulate = lib.nb_emulate_pair_rank_f32 if f32 else lib.nb_emulate_pair_rank_f64
 dt, one = dtype(np.float32(0.016)), dtype(1)
+if len(sys.argv) > 5:
+    pkg.set_pair_plan_override(0, 0, 0, 0)
 bufs = [pkg.DeviceBuffer(pos0.nbytes) for _ in range(4)]
 bufs[0].upload(pos0), bufs[2].upload(vel0)
 reps = 20 if n <= 262144 else 4
@@ -52,6 +54,9 @@ single = pkg.BodySystemHIP(n, 256, pkg.NBodyParams(), dtype, pos0, vel0, mode=pk
 single_ms = timed(lambda: single.update(dt))
 single.free()
 print(json.dumps({"bodies": n, "dtype": np.dtype(dtype).name, "single_gpu_pairwise_ms": round(single_ms, 4)}), flush=True)
+if len(sys.argv) > 5:
+    pkg.set_pair_plan_override(int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), 0)
+    print("tile geometry override R S C =", sys.argv[3:6], flush=True)
 for G in (2, 4, 8):
     ni = n // G
     need = ctypes.c_size_t(0)
