@@ -60,7 +60,7 @@ def _worker(rank, world, port, n, steps, mode_name, out_dir, exchange="allgather
             return Done()
 
         sharded = entry.load_package_module("sharded")
-        if exchange == "tiles":  # gloo send/recv rounds on the device tensors themselves: the production tile schedule
+        if exchange == "tiles":  # the tile schedule of sharded.py over gloo: its send/recv rounds are staged through host memory (gloo is not stream-aware)
             system = sharded.ShardedBodySystem(pos_t, vel_t, launch, ordered=(mode == pkg.NB_MODE_STRICT), exchange="tiles")
         else:
             system = sharded.ShardedBodySystem(pos_t, vel_t, launch, ordered=(mode == pkg.NB_MODE_STRICT), gather=gather)
@@ -77,8 +77,10 @@ def _worker(rank, world, port, n, steps, mode_name, out_dir, exchange="allgather
 
 @pytest.mark.parametrize("mode_name,exchange,world", [("strict", "allgather", 2), ("fast", "allgather", 2), ("strict", "tiles", 4), ("fast", "tiles", 4)])
 def test_ranks_sharing_one_gpu_match_the_oracle(tmp_path, oracle, mode_name, exchange, world):
-    """2 ranks with the all-gather form (host-staged), 4 ranks with the TILE form (gloo send/recv rounds straight on the device
-    tensors: own slice first, then the tiles in arrival order, each kernel waiting on its own round; STRICT in rank order)."""
+    """The torch.distributed re-implementation (cuda-nbody_amd/sharded.py; the C-ABI path has its own tests with the RCCL test
+    double, tests/test_comm_fake_rccl.py): 2 ranks with the all-gather form (host-staged), 4 ranks with the TILE form -- gloo
+    send/recv rounds, the slices staged through host memory because gloo is not stream-aware (sharded.py:_start_tiles): own slice
+    first, then the tiles in arrival order, each kernel launched once its own round has landed; STRICT in rank order."""
     import torch.multiprocessing as mp
 
     n, steps = 4096, 3
