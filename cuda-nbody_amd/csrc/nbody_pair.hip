@@ -318,12 +318,31 @@ template <typename T, int R, int S> __global__ __launch_bounds__(64 * S) __attri
 
 // Sum of `slots` planes at r[q * stride], q ascending, as four interleaved running sums (shorter chains, smaller rounding
 // error), wave w of the 256-thread workgroup taking q = w, w+4, ...; the caller combines (t0 + t1) + (t2 + t3).
-template <typename T> __device__ __forceinline__ T quarter_sum(const T* r, size_t stride, unsigned slots, unsigned wave) {
-    T sum = 0;
-    for (unsigned q = wave; q < (slots & ~3u); q += 4) sum += r[static_cast<size_t>(q) * stride];
-    if (wave == 0)
-        for (unsigned q = slots & ~3u; q < slots; ++q) sum += r[static_cast<size_t>(q) * stride];  // the odd slots join t0
-    return sum;
+template <typename T> __device__ __forceinline__ void quarter_sums(const T* r, size_t plane, unsigned slots, unsigned wave, T (&t)[3]) {
+    // r: component 0 of slot 0 for this body; component c of slot q at r[(q * 3 + c) * plane]
+    const unsigned full = slots & ~3u;
+    t[0] = t[1] = t[2] = 0;
+    // 24 loads in flight per lane, also for short slot lists (a missing slot adds +0, which changes no bit); the adds keep their order
+    for (unsigned q = wave; q < full; q += 32) {
+        T v[3][8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const bool there = (q + 4 * u) < full;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) v[c][u] = there ? r[(static_cast<size_t>(q + 4 * u) * 3 + c) * plane] : T(0);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) t[c] += v[c][u];
+        }
+    }
+    if (wave == 0) {
+        for (unsigned k = full; k < slots; ++k) {  // the odd slots join t0
+#pragma unroll
+            for (int c = 0; c < 3; ++c) t[c] += r[(static_cast<size_t>(k) * 3 + c) * plane];
+        }
+    }
 }
 
 // The last kernel of a step: a body's i-side sums and reaction sums, added in a fixed order, then integrateBodies
@@ -336,10 +355,7 @@ template <typename T> __global__ __launch_bounds__(256) void pair_finish(FinishA
     const unsigned k    = blockIdx.x * 64 + lane;  // relative to the rank's first body
     const bool     live = k < s.count;
     T              t[3] = {0, 0, 0};
-    if (live) {
-#pragma unroll
-        for (int comp = 0; comp < 3; ++comp) t[comp] = quarter_sum(s.react + static_cast<size_t>(comp) * s.react_plane + k, 3 * static_cast<size_t>(s.react_plane), s.react_slots, wave);
-    }
+    if (live) quarter_sums(s.react + k, s.react_plane, s.react_slots, wave, t);
     if (wave != 0) {
 #pragma unroll
         for (int comp = 0; comp < 3; ++comp) part[wave - 1][comp][lane] = t[comp];
@@ -388,10 +404,7 @@ template <typename T> __global__ __launch_bounds__(256) void pair_reduce(const T
     const unsigned k    = blockIdx.x * 64 + lane;
     const bool     live = k < count;
     T              t[3] = {0, 0, 0};
-    if (live) {
-#pragma unroll
-        for (int comp = 0; comp < 3; ++comp) t[comp] = quarter_sum(react + static_cast<size_t>(comp) * react_plane + k, 3 * static_cast<size_t>(react_plane), slots, wave);
-    }
+    if (live) quarter_sums(react + k, react_plane, slots, wave, t);
     if (wave != 0) {
 #pragma unroll
         for (int comp = 0; comp < 3; ++comp) part[wave - 1][comp][lane] = t[comp];
