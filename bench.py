@@ -230,6 +230,41 @@ def other_configs(pkg, lib, headline):
     return out
 
 
+def rank_projection(pkg, lib, n, dtype, dt, damping, single_ms):
+    """ms of ONE rank's kernels of a 2 / 4 / 8-rank pairwise step on this GPU (rank G/2; diagonal + G/2 rectangles + folds + finish),
+    no exchange -- tools/pair_rank_probe.py has the longer version."""
+    f32 = np.dtype(dtype) == np.float32
+    emulate = lib.nb_emulate_pair_rank_f32 if f32 else lib.nb_emulate_pair_rank_f64
+    pos0, vel0 = make_bodies(n, dtype)
+    bufs = [pkg.DeviceBuffer(pos0.nbytes) for _ in range(3)]
+    bufs[0].upload(pos0), bufs[2].upload(vel0)
+    out = {"what": "kernel time of one rank of a G-rank pairwise step, alone on one GPU, no exchange: a PROJECTION of the compute side of strong scaling, "
+                   "not a multi-GPU measurement", "single_gpu_ms_per_step": single_ms, "ranks": {}}
+    for G in (2, 4, 8):
+        need = ctypes.c_size_t(0)
+        if emulate(None, None, None, None, ctypes.byref(need), n, G, 0, dt, damping, None) != 0:
+            continue
+        work = pkg.DeviceBuffer(need.value)
+
+        def one_step():
+            pkg.check(emulate(bufs[1].ptr, bufs[0].ptr, bufs[2].ptr, work.ptr, ctypes.byref(need), n, G, G // 2, dt, damping, None), "nb_emulate_pair_rank")
+
+        one_step()
+        pkg.check(lib.nb_device_synchronize())
+        e0, e1 = pkg.Event(), pkg.Event()
+        e0.record(None)
+        for _ in range(10):
+            one_step()
+        e1.record(None)
+        e1.synchronize()
+        ms = e0.elapsed_ms(e1) / 10
+        out["ranks"][str(G)] = {"ms_per_step_kernels_only": ms, "projected_speedup_excluding_exchange": single_ms / ms, "workspace_bytes_per_rank": need.value}
+        work.free()
+    for b in bufs:
+        b.free()
+    return out
+
+
 def main():
     args = parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -725,6 +760,13 @@ def main():
                 line["configs"] = other_configs(pkg, lib, (n, args.fp64, args.mode, "pairwise" if pairwise else ("one-sided" if args.mode == "fast" else "strict")))
             except Exception as exc:  # noqa: BLE001
                 line["configs"] = [{"error": repr(exc)}]
+            if pairwise:
+                # No multi-GPU node has run this yet.  What CAN be measured on one GPU is the compute side: exactly the kernels one rank
+                # of a G-rank pairwise step launches (nb_emulate_pair_rank_*), alone on the chip, no exchange.  A projection, labelled so.
+                try:
+                    line["multi_gpu_kernel_projection"] = rank_projection(pkg, lib, n, dtype, dt, damping, elapsed / args.steps * 1e3)
+                except Exception as exc:  # noqa: BLE001
+                    line["multi_gpu_kernel_projection"] = {"error": repr(exc)}
         print(json.dumps(line), flush=True)
         if args.dump_state:
             torch.cuda.synchronize()

@@ -31,6 +31,11 @@
 //     m_j / m_ref along with the body j and multiplies by the masses of the bodies i (2 more v_pk_mul per pair).  Bodies
 //     beyond N (ragged last block) are zero-mass bodies at a real body's place: they pull nothing, and what they feel is dropped.
 //
+//   * Several GPUs (nbody_comm.hip): the same kernel takes a RANGE of bodies i and either that range again (diag: the
+//     tournament within a rank's slice) or a range of bodies j (a rectangle of the pair matrix against another rank's slice,
+//     every tile symmetric, reaction slot = the block of bodies i); pair_reduce folds a rectangle's reaction planes into the
+//     one array that travels to the owner of those bodies, and pair_finish also adds the arrays a rank received.
+//
 // Results differ from the one-sided FAST kernel in summation order only; both are held to an fp64 direct sum by the tests.
 #include "nbody_kernels.h"
 
@@ -316,8 +321,8 @@ template <typename T, int R, int S> __global__ __launch_bounds__(64 * S) __attri
     }
 }
 
-// Sum of `slots` planes at r[q * stride], q ascending, as four interleaved running sums (shorter chains, smaller rounding
-// error), wave w of the 256-thread workgroup taking q = w, w+4, ...; the caller combines (t0 + t1) + (t2 + t3).
+// The three component sums over `slots` reaction planes, q ascending, as four interleaved running sums (shorter chains, smaller
+// rounding error), wave w of the 256-thread workgroup taking q = w, w+4, ...; the caller combines (t0 + t1) + (t2 + t3).
 template <typename T> __device__ __forceinline__ void quarter_sums(const T* r, size_t plane, unsigned slots, unsigned wave, T (&t)[3]) {
     // r: component 0 of slot 0 for this body; component c of slot q at r[(q * 3 + c) * plane]
     const unsigned full = slots & ~3u;

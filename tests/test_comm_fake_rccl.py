@@ -278,3 +278,19 @@ def test_cli_sharded_fast_owns_workspaces(tmp_path):
     assert r.returncode == 0 and "  OK" in r.stdout, r.stdout + r.stderr
     r = subprocess.run([cli, "--benchmark", f"--numbodies={n}", "--devices=0,0", "-i", "4"], env=_env(), capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "billion interactions per second" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_config4_shape_eight_ranks_at_one_mi_bodies(tmp_path, oracle):
+    """BASELINE configs[3]: 1 048 576 bodies sharded over 8 ranks (131 072 each), FAST with workspaces -- the pairwise step across
+    the ranks, every position tile and reaction array through the transport -- one step, all 8 ranks on the one GPU: every rank
+    ends with the positions one rank computes (pairwise single-GPU step), to summation accuracy."""
+    n, world = 1048576, 8
+    pos0, vel0 = oracle.startup_state(n, np.float32)
+    got = _run(tmp_path, "all", pos0, vel0, world, 1, "fast", workspace=True)
+    assert np.all(got["workspace_bytes"] > 0)
+    for k in range(1, world):
+        assert got[f"pos_{k}"].tobytes() == got["pos_0"].tobytes()
+    np.testing.assert_allclose(got["pos_0"], got["single_pos"], rtol=0, atol=5e-5)
+    vel = np.concatenate([got[f"vel_{k}"] for k in range(world)])
+    np.testing.assert_allclose(vel, got["single_vel"], rtol=0, atol=1e-2)
