@@ -116,9 +116,10 @@ struct StepGraph {
     hipGraphExec_t exec  = nullptr;
 };
 
-// Fewer bodies than this and the pairwise layout loses to the one-sided kernels (measured: profiles/round3_pair_crossover_*.jsonl:
-// fp32 8 192 bodies 33.5 against 27.1 us, 12 288 bodies 53.3 against 61.9 us; fp64 4 096: 29.6 / 18.8 us, 8 192: 50.5 / 55.2 us)
-template <typename T> constexpr unsigned kPairMinBodies = sizeof(T) == 4 ? 12288u : 8192u;
+// Fewer bodies than this and the pairwise layout loses to the one-sided kernels (measured: profiles/round3_pair_crossover_*.jsonl
+// and the finer sweep in DESIGN.md section 5: fp32 8 192 bodies 29.4 against 27.1 us, 10 240 bodies 44.8 against 51.5 us;
+// fp64 4 096 bodies 24.3 / 18.9 us, 6 144 bodies 38.5 / 40.8 us)
+template <typename T> constexpr unsigned kPairMinBodies = sizeof(T) == 4 ? 8193u : 6144u;
 
 template <typename T> bool pair_applies(unsigned n, int mode, nb::PairPlan* plan) {
     const int floor_bodies = g_pair_min.load();

@@ -196,9 +196,9 @@ def test_pair_plan_heuristics_without_gpu(pkg):
     assert plan(1048576) == (1, 8, 8, 1, 2048)
     assert plan(65536) == (1, 8, 8, 4, 128)        # four workgroups share a block of bodies i and split its tiles
     assert plan(16384) == (1, 4, 8, 4, 64)         # small systems: half the bodies per lane, twice the blocks
-    assert plan(8192)[0] == 0 and plan(12288)[0] == 1
+    assert plan(8192)[0] == 0 and plan(10240)[0] == 1
     assert plan(262144, np.float64) == (1, 4, 16, 1, 1024)
-    assert plan(4096, np.float64)[0] == 0 and plan(8192, np.float64)[0] == 1
+    assert plan(4096, np.float64)[0] == 0 and plan(6144, np.float64)[0] == 1
     assert plan(600, np.float32)[4] == 3 and plan(64, np.float32)[4] == 1  # odd block counts, a single block
     need = ctypes.c_size_t(7)
     lib = pkg.lib()
