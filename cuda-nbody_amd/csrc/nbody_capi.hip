@@ -30,6 +30,8 @@ std::atomic<int> g_pair_r{0}, g_pair_s{0}, g_pair_c{0}, g_pair_min{0};  // overr
 // the staging path of the first pageable copy), and some of that set-up draws from libc rand().  Do all of it ONCE per
 // device, under the guard, so that the launch path (kernel launches, event records, stream waits) can stay lock-free
 // without ever being the call that triggers a lazy initialisation.
+std::atomic<size_t> g_total_memory[64] = {};  // per device, filled by the one-time warm-up below (0: unknown)
+
 int current_device_ready() {
     static std::atomic<int> cu_count[64] = {};
     int                     dev          = 0;
@@ -38,6 +40,8 @@ int current_device_ready() {
     if (v == 0) {
         NB_KEEP_RAND_STREAM;
         if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        size_t free_bytes = 0, total_bytes = 0;
+        if (hipMemGetInfo(&free_bytes, &total_bytes) == hipSuccess) g_total_memory[dev].store(total_bytes);
         void* scratch = nullptr;
         if (hipMalloc(&scratch, 256) == hipSuccess) {
             const unsigned word  = 0;
@@ -125,6 +129,13 @@ template <typename T> bool pair_applies(unsigned n, int mode, nb::PairPlan* plan
     const int floor_bodies = g_pair_min.load();
     if (mode != NB_MODE_FAST || n < (floor_bodies > 0 ? static_cast<unsigned>(floor_bodies) : kPairMinBodies<T>)) return false;
     *plan = nb::plan_pair<T>(n, cu_count_cached(), g_pair_r.load(), g_pair_s.load(), g_pair_c.load());
+    // The workspace grows with N^2 (12.9 GB at 1 Mi bodies, 206 GB at 4 Mi): past a third of the device's memory the layout
+    // does not apply (nb_workspace_bytes_* says 0 and the step is the one-sided kernel).
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
+        const size_t total_bytes = g_total_memory[dev].load();
+        if (total_bytes != 0 && plan->workspace_bytes > total_bytes / 3) return false;
+    }
     return true;
 }
 

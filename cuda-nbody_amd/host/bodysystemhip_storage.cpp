@@ -3,6 +3,7 @@
 #include "integrate_nbody_hip.hpp"
 
 #include <cassert>
+#include <stdexcept>
 #include <utility>
 
 template <std::floating_point T, template <std::floating_point> class Storage>
@@ -65,7 +66,13 @@ template <std::floating_point T, template <std::floating_point> class Storage> a
             hip_check(nb_workspace_bytes_f64(this->nb_bodies_, mode, &need), "nb_workspace_bytes_f64");
         }
     }
-    if (need > workspace_.size()) workspace_ = DeviceArray<unsigned char>(need);
+    if (need > workspace_.size()) {
+        try {
+            workspace_ = DeviceArray<unsigned char>(need);
+        } catch (const std::runtime_error&) {  // no room for it: the step is then the one-sided kernel, nothing else changes
+            need = 0;
+        }
+    }
     workspace_bytes_ = need;
 }
 
