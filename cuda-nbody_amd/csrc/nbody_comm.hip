@@ -595,7 +595,7 @@ int nb_comm_destroy(nb_comm_t comm) {
 
 int nb_comm_set_workspace(nb_comm_t comm, void* workspace, size_t workspace_bytes) {
     Comm* c = as_comm(comm);
-    if (c == nullptr || (workspace == nullptr && workspace_bytes != 0)) return NB_ERR_INVALID_ARGUMENT;
+    if (c == nullptr || (workspace == nullptr && workspace_bytes != 0) || (reinterpret_cast<size_t>(workspace) % sizeof(double)) != 0) return NB_ERR_INVALID_ARGUMENT;
     c->workspace       = workspace;
     c->workspace_bytes = workspace_bytes;
     return 0;

@@ -239,7 +239,7 @@ template <typename T, int R, int S> __global__ __launch_bounds__(64 * S) __attri
         vec rx = LT::splat(0), ry = LT::splat(0), rz = LT::splat(0);
         T   scale;  // what the reaction sums are still to be multiplied by
         if (tile_unit) {
-            vec none[R];
+            vec none[R] = {};  // (the unit loop never reads the masses of the bodies i)
 #pragma unroll 1
             for (int it = 0; it < 64 / UNR; ++it) {
 #pragma unroll
