@@ -26,10 +26,13 @@
 //     A second kernel adds a body's slots in a fixed order and integrates (integrateBodies, bodysystemcuda.cu:166-183).
 //     Workspace traffic: 12 B per tile visit and body = N^2 / (128 I) * 12 B per step (0.8 GB at 262 144 bodies, written once,
 //     read once: ~0.3 ms of a ~8 ms step).
-//   * Masses: sums are kept in units of the first body's mass m_ref, and a unit whose 64 bodies j and 64*I bodies i all have
-//     mass m_ref (every start-up configuration of the reference) runs without a mass multiply; any other unit carries
-//     m_j / m_ref along with the body j and multiplies by the masses of the bodies i (2 more v_pk_mul per pair).  Bodies
-//     beyond N (ragged last block) are zero-mass bodies at a real body's place: they pull nothing, and what they feel is dropped.
+//   * Masses: a unit whose 64 bodies j are ONE species (one mass) and whose 64*I bodies i are one species too -- every unit of an
+//     equal-mass system such as the reference's start-up configurations, and all but the boundary tiles of a galaxy file, whose
+//     species lie in contiguous blocks -- runs without a mass multiply: the wave's i-side sums are kept in units of the mass of
+//     the species it is working through (re-expressed once when that changes), the reaction sums are multiplied by the block's
+//     mass when they are stored.  Any other unit carries m_j / unit along with the body j and multiplies by the masses of the
+//     bodies i (2 more v_pk_mul per pair, one more rotation).  Bodies beyond N (ragged last block) are zero-mass bodies at a
+//     real body's place: they pull nothing, and what they feel is dropped.
 //
 //   * Several GPUs (nbody_comm.hip): the same kernel takes a RANGE of bodies i and either that range again (diag: the
 //     tournament within a rank's slice) or a range of bodies j (a rectangle of the pair matrix against another rank's slice,
@@ -61,13 +64,22 @@ __device__ __forceinline__ double rotate(double x) {
 }
 __device__ __forceinline__ v2f rotate(v2f x) { return v2f{rotate(x.x), rotate(x.y)}; }
 
+// lane 0's value, as a wave-uniform (scalar) value
+__device__ __forceinline__ float first_lane(float x) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, x))); }
+__device__ __forceinline__ double first_lane(double x) {
+    const unsigned long long b  = __builtin_bit_cast(unsigned long long, x);
+    const unsigned           lo = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(b & 0xffffffffull)));
+    const unsigned           hi = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(b >> 32)));
+    return __builtin_bit_cast(double, (static_cast<unsigned long long>(hi) << 32) | lo);
+}
+
 __device__ __forceinline__ float  both_halves(v2f a) { return a.x + a.y; }
 __device__ __forceinline__ double both_halves(double a) { return a; }
 
-template <typename T> __device__ __forceinline__ T pair_reference_mass(const T* old_pos) {
-    const T m = old_pos[3];
+// A mass the sums may be expressed in units of: 1/m is a well-behaved number (false for 0, NaN, infinities)
+template <typename T> __device__ __forceinline__ bool usable_unit(T m) {
     const T a = m < 0 ? -m : m;
-    return (a >= T(0x1p-60) && a <= T(0x1p60)) ? m : T(1);  // false for NaN too
+    return a >= T(0x1p-60) && a <= T(0x1p60);
 }
 
 // T: float|double   R: vectors per lane (I = R*W bodies i)   S: waves of a workgroup
@@ -97,15 +109,15 @@ template <typename T, int R, int S> __global__ __launch_bounds__(64 * S) __attri
     const unsigned a    = blockIdx.x / s.splits;  // the block whose bodies i this workgroup holds
     const unsigned c    = blockIdx.x % s.splits;
 
-    const T    m_ref     = pair_reference_mass(s.old_pos);
-    const T    inv_mref  = T(1) / m_ref;
-    const bits unit_bits = __builtin_bit_cast(bits, m_ref);
 
     // bodies i of this lane: block_base + k*64 + lane (coalesced across the wave); a body beyond the range sits on its last body with mass 0
     const unsigned block_base = s.i_begin + a * BLOCK;
     const unsigned i_end      = s.i_begin + s.i_count;
     vec            px[R], py[R], pz[R], ax[R], ay[R], az[R];
-    bool           all_unit = true;
+    // Is the block ONE species -- every body i real and of the same mass m_block?  (Wave-uniform answer: each wave holds the whole block.)
+    const T    m_block    = old_pos[block_base < i_end ? block_base : i_end - 1].w;  // (uniform address)
+    const bits block_bits = __builtin_bit_cast(bits, m_block);
+    bool       same       = true;
 #pragma unroll
     for (int k = 0; k < I; ++k) {
         const unsigned i = block_base + k * 64 + lane;
@@ -113,9 +125,9 @@ template <typename T, int R, int S> __global__ __launch_bounds__(64 * S) __attri
         LT::set(px[k / W], k % W, p.x);
         LT::set(py[k / W], k % W, p.y);
         LT::set(pz[k / W], k % W, p.z);
-        all_unit = all_unit && i < i_end && __builtin_bit_cast(bits, p.w) == unit_bits;
+        same = same && i < i_end && __builtin_bit_cast(bits, p.w) == block_bits;
     }
-    const bool block_unit = __builtin_amdgcn_ballot_w64(!all_unit) == 0;  // wave-uniform: every body i of the block is real and has mass m_ref
+    const bool block_uniform = __builtin_amdgcn_ballot_w64(!same) == 0 && usable_unit(m_block);
 #pragma unroll
     for (int r = 0; r < R; ++r) ax[r] = ay[r] = az[r] = LT::splat(0);
     vec eps2 = LT::splat(s.eps2);
@@ -148,15 +160,25 @@ template <typename T, int R, int S> __global__ __launch_bounds__(64 * S) __attri
 #pragma unroll
         for (int q = 0; q < 3 * I; ++q) second[q * 64] = 0;
     }
+    // The register sums are kept in units of `unit`: the mass of the species whose tiles the wave is working through (a tile of
+    // ONE species runs the loop without a mass multiply; when the species changes the sums are re-expressed once: 3R multiplies
+    // per change, a handful per step for a galaxy file).  The second-level sums and everything stored are in absolute units.
+    T unit = T(1);
     auto flush = [&]() {
 #pragma unroll
         for (int k = 0; k < I; ++k) {
-            second[(0 * I + k) * 64] += LT::get(ax[k / W], k % W);
-            second[(1 * I + k) * 64] += LT::get(ay[k / W], k % W);
-            second[(2 * I + k) * 64] += LT::get(az[k / W], k % W);
+            second[(0 * I + k) * 64] = __builtin_fma(LT::get(ax[k / W], k % W), unit, second[(0 * I + k) * 64]);
+            second[(1 * I + k) * 64] = __builtin_fma(LT::get(ay[k / W], k % W), unit, second[(1 * I + k) * 64]);
+            second[(2 * I + k) * 64] = __builtin_fma(LT::get(az[k / W], k % W), unit, second[(2 * I + k) * 64]);
         }
 #pragma unroll
         for (int r = 0; r < R; ++r) ax[r] = ay[r] = az[r] = LT::splat(0);
+    };
+    auto change_unit = [&](T to) {  // (wave-uniform)
+        const vec ratio = LT::splat(unit / to);
+#pragma unroll
+        for (int r = 0; r < R; ++r) ax[r] = ax[r] * ratio, ay[r] = ay[r] * ratio, az[r] = az[r] * ratio;
+        unit = to;
     };
 
     // ---- the units of this wave ------------------------------------------------------------------------------------------
@@ -188,7 +210,7 @@ template <typename T, int R, int S> __global__ __launch_bounds__(64 * S) __attri
         constexpr int RB = R < NB_PAIR_RB ? R : NB_PAIR_RB;  // vectors per stage block (more in flight at once spills at R = 4)
         const vec     bx = LT::splat(jx), by = LT::splat(jy), bz = LT::splat(jz);
         vec           mj = bx;
-        if constexpr (!UNIT) mj = LT::splat(jm);  // m_j / m_ref
+        if constexpr (!UNIT) mj = LT::splat(jm);  // m_j / unit
 #pragma unroll
         for (int h = 0; h < R; h += RB) {
             vec dx[RB], dy[RB], dz[RB], w[RB];
@@ -234,19 +256,25 @@ template <typename T, int R, int S> __global__ __launch_bounds__(64 * S) __attri
         const unsigned q     = u / TB;  // (diag: the block offset)
         const unsigned first = tile_first(u);
         const unsigned j     = first + lane;
-        const bool     tile_unit = block_unit && __builtin_amdgcn_ballot_w64(!(j < j_end && __builtin_bit_cast(bits, cur.w) == unit_bits)) == 0;
-        T   jx = cur.x, jy = cur.y, jz = cur.z, jm = cur.w * inv_mref;
+        // one species on both sides -- every body j of the tile real and of one usable mass, the block of bodies i likewise:
+        // no mass enters the loop; the i-side sums are in units of the tile's mass, the reaction sums in units of the block's
+        const T    m_tile       = first_lane(cur.w);
+        const bool tile_uniform = block_uniform && usable_unit(m_tile) &&
+                                  __builtin_amdgcn_ballot_w64(!(j < j_end && __builtin_bit_cast(bits, cur.w) == __builtin_bit_cast(bits, m_tile))) == 0;
+        T   jx = cur.x, jy = cur.y, jz = cur.z, jm = 0;
         vec rx = LT::splat(0), ry = LT::splat(0), rz = LT::splat(0);
         T   scale;  // what the reaction sums are still to be multiplied by
-        if (tile_unit) {
-            vec none[R] = {};  // (the unit loop never reads the masses of the bodies i)
+        if (tile_uniform) {
+            if (__builtin_bit_cast(bits, m_tile) != __builtin_bit_cast(bits, unit)) change_unit(m_tile);
+            vec none[R] = {};  // (this loop never reads the masses of the bodies i)
 #pragma unroll 1
             for (int it = 0; it < 64 / UNR; ++it) {
 #pragma unroll
                 for (int v = 0; v < UNR; ++v) step.template operator()<true>(jx, jy, jz, jm, rx, ry, rz, none);
             }
-            scale = m_ref;
+            scale = m_block;
         } else {
+            jm = cur.w / unit;  // mixed masses: m_j / unit travels with the body j
             vec mi[R];  // the masses of the bodies i: only this path holds them, and only while it runs
 #pragma unroll
             for (int k = 0; k < I; ++k) {
@@ -278,6 +306,11 @@ template <typename T, int R, int S> __global__ __launch_bounds__(64 * S) __attri
     }
     if (lane == 0) mine[slot] = 0xffffffffu;  // finished: never the one the others defer to
     __builtin_amdgcn_s_setprio(0);
+    {  // absolute units from here on
+        const vec to_absolute = LT::splat(unit);
+#pragma unroll
+        for (int r = 0; r < R; ++r) ax[r] = ax[r] * to_absolute, ay[r] = ay[r] * to_absolute, az[r] = az[r] * to_absolute;
+    }
     if constexpr (kTwoLevel) {
 #pragma unroll
         for (int k = 0; k < I; ++k) {
@@ -315,9 +348,9 @@ template <typename T, int R, int S> __global__ __launch_bounds__(64 * S) __attri
         const unsigned i = block_base + k * 64 + lane;
         if (i >= i_end) continue;
         const size_t at = i - s.self_origin;
-        self[at]                                         = LT::get(ax[k / W], k % W) * m_ref;
-        self[static_cast<size_t>(s.self_plane) + at]     = LT::get(ay[k / W], k % W) * m_ref;
-        self[2 * static_cast<size_t>(s.self_plane) + at] = LT::get(az[k / W], k % W) * m_ref;
+        self[at]                                         = LT::get(ax[k / W], k % W);
+        self[static_cast<size_t>(s.self_plane) + at]     = LT::get(ay[k / W], k % W);
+        self[2 * static_cast<size_t>(s.self_plane) + at] = LT::get(az[k / W], k % W);
     }
 }
 
