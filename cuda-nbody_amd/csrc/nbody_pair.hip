@@ -26,14 +26,13 @@
 //     A second kernel adds a body's slots in a fixed order and integrates (integrateBodies, bodysystemcuda.cu:166-183).
 //     Workspace traffic: 12 B per tile visit and body = N^2 / (128 I) * 12 B per step (0.8 GB at 262 144 bodies, written once,
 //     read once: ~0.3 ms of a ~8 ms step).
-//   * Masses: a unit whose 64 bodies j are ONE species (one mass) and whose 64*I bodies i are one species too -- every unit of an
-//     equal-mass system such as the reference's start-up configurations, and all but the boundary tiles of a galaxy file, whose
-//     species lie in contiguous blocks -- runs without a mass multiply: the wave's i-side sums are kept in units of the mass of
-//     the species it is working through (re-expressed once when that changes), the reaction sums are multiplied by the block's
-//     mass when they are stored.  Any other unit carries m_j / unit along with the body j and multiplies by the masses of the
-//     bodies i (2 more v_pk_mul per pair, one more rotation).  Bodies beyond N (ragged last block) are zero-mass bodies at a
-//     real body's place: they pull nothing, and what they feel is dropped.
-//
+//   * Masses: a tile whose 64 bodies j are ONE species (one mass) multiplies nothing on the i side -- the wave's i-side sums are
+//     kept in units of the mass of the species it is working through (re-expressed once when that changes); a block whose 64*I
+//     bodies i are one species multiplies nothing on the reaction side -- the block's mass is applied when the sums are stored.
+//     Every unit of an equal-mass system such as the reference's start-up configurations, and all but the border tiles of a
+//     galaxy file (species in contiguous blocks), run the loop without any mass multiply; mixed bodies j carry m_j / unit along
+//     (+1 v_pk_mul per pair, one more rotation), mixed bodies i multiply the reaction side (+1).  Bodies beyond N (ragged last
+//     block) are zero-mass bodies at a real body's place: they pull nothing, and what they feel is dropped.
 //   * Several GPUs (nbody_comm.hip): the same kernel takes a RANGE of bodies i and either that range again (diag: the
 //     tournament within a rank's slice) or a range of bodies j (a rectangle of the pair matrix against another rank's slice,
 //     every tile symmetric, reaction slot = the block of bodies i); pair_reduce folds a rectangle's reaction planes into the
@@ -204,11 +203,13 @@ template <typename T, int R, int S> __global__ __launch_bounds__(64 * S) __attri
 
     // one rotation step: the lane's bodies i against the body j it holds right now; then the body j and its sums move on.
     // Written stage by stage over the R vectors (all differences, all squared distances, ...): R independent chains.
-    auto step = [&]<bool UNIT>(T& jx, T& jy, T& jz, T& jm, vec& rx, vec& ry, vec& rz, const vec (&mi)[R]) {
+    // MJ: the bodies j of the tile differ in mass (m_j / unit travels with the body and multiplies the i side);
+    // MI: the bodies i of the block differ in mass (their masses multiply the reaction side)
+    auto step = [&]<bool MI, bool MJ>(T& jx, T& jy, T& jz, T& jm, vec& rx, vec& ry, vec& rz, const vec (&mi)[R]) {
         constexpr int RB = R < NB_PAIR_RB ? R : NB_PAIR_RB;  // vectors per stage block (more in flight at once spills at R = 4)
         const vec     bx = LT::splat(jx), by = LT::splat(jy), bz = LT::splat(jz);
         vec           mj = bx;
-        if constexpr (!UNIT) mj = LT::splat(jm);  // m_j / unit
+        if constexpr (MJ) mj = LT::splat(jm);  // m_j / unit
 #pragma unroll
         for (int h = 0; h < R; h += RB) {
             vec dx[RB], dy[RB], dz[RB], w[RB];
@@ -225,15 +226,23 @@ template <typename T, int R, int S> __global__ __launch_bounds__(64 * S) __attri
 #pragma unroll
             for (int r = 0; r < RB; ++r) {
                 vec wi = w[r], wj = w[r];
-                if constexpr (!UNIT) wi = mj * w[r], wj = mi[h + r] * w[r];
+                if constexpr (MJ) wi = mj * w[r];
+                if constexpr (MI) wj = mi[h + r] * w[r];
                 ax[h + r] = LT::fma(dx[r], wi, ax[h + r]), ay[h + r] = LT::fma(dy[r], wi, ay[h + r]), az[h + r] = LT::fma(dz[r], wi, az[h + r]);
                 rx = LT::fma(dx[r], wj, rx), ry = LT::fma(dy[r], wj, ry), rz = LT::fma(dz[r], wj, rz);
             }
         }
         // the body j and everything that belongs to it move on by one lane
         jx = rotate(jx), jy = rotate(jy), jz = rotate(jz);
-        if constexpr (!UNIT) jm = rotate(jm);
+        if constexpr (MJ) jm = rotate(jm);
         rx = rotate(rx), ry = rotate(ry), rz = rotate(rz);
+    };
+    auto sixty_four_steps = [&]<bool MI, bool MJ>(T& jx, T& jy, T& jz, T& jm, vec& rx, vec& ry, vec& rz, const vec (&mi)[R]) {
+#pragma unroll 1
+        for (int it = 0; it < 64 / UNR; ++it) {
+#pragma unroll
+            for (int v = 0; v < UNR; ++v) step.template operator()<MI, MJ>(jx, jy, jz, jm, rx, ry, rz, mi);
+        }
     };
 
     vec4 cur = g < n_units ? load_tile(g) : vec4{};
@@ -254,37 +263,28 @@ template <typename T, int R, int S> __global__ __launch_bounds__(64 * S) __attri
         const unsigned q     = u / TB;  // (diag: the block offset)
         const unsigned first = tile_first(u);
         const unsigned j     = first + lane;
-        // one species on both sides -- every body j of the tile real and of one usable mass, the block of bodies i likewise:
-        // no mass enters the loop; the i-side sums are in units of the tile's mass, the reaction sums in units of the block's
+        // Is the tile ONE species -- every body j real and of one usable mass?  Then no mass multiplies the i side: the wave's
+        // i-side sums are in units of the tile's mass.  Likewise the block: its mass multiplies the reaction sums when they are stored.
         const T    m_tile       = first_lane(cur.w);
-        const bool tile_uniform = block_uniform && usable_unit(m_tile) &&
-                                  __builtin_amdgcn_ballot_w64(!(j < j_end && __builtin_bit_cast(bits, cur.w) == __builtin_bit_cast(bits, m_tile))) == 0;
+        const bool tile_uniform = usable_unit(m_tile) && __builtin_amdgcn_ballot_w64(!(j < j_end && __builtin_bit_cast(bits, cur.w) == __builtin_bit_cast(bits, m_tile))) == 0;
         T   jx = cur.x, jy = cur.y, jz = cur.z, jm = 0;
         vec rx = LT::splat(0), ry = LT::splat(0), rz = LT::splat(0);
-        T   scale;  // what the reaction sums are still to be multiplied by
-        if (tile_uniform) {
-            if (__builtin_bit_cast(bits, m_tile) != __builtin_bit_cast(bits, unit)) change_unit(m_tile);
-            vec none[R] = {};  // (this loop never reads the masses of the bodies i)
-#pragma unroll 1
-            for (int it = 0; it < 64 / UNR; ++it) {
-#pragma unroll
-                for (int v = 0; v < UNR; ++v) step.template operator()<true>(jx, jy, jz, jm, rx, ry, rz, none);
-            }
-            scale = m_block;
+        if (tile_uniform && __builtin_bit_cast(bits, m_tile) != __builtin_bit_cast(bits, unit)) change_unit(m_tile);
+        if (!tile_uniform) jm = cur.w / unit;  // mixed masses: m_j / unit travels with the body j
+        const T scale = block_uniform ? m_block : T(1);  // what the reaction sums are still to be multiplied by
+        if (block_uniform) {
+            vec none[R] = {};  // (these loops never read the masses of the bodies i)
+            if (tile_uniform) sixty_four_steps.template operator()<false, false>(jx, jy, jz, jm, rx, ry, rz, none);
+            else sixty_four_steps.template operator()<false, true>(jx, jy, jz, jm, rx, ry, rz, none);
         } else {
-            jm = cur.w / unit;  // mixed masses: m_j / unit travels with the body j
-            vec mi[R];  // the masses of the bodies i: only this path holds them, and only while it runs
+            vec mi[R];  // the masses of the bodies i: only these paths hold them, and only while they run
 #pragma unroll
             for (int k = 0; k < I; ++k) {
                 const unsigned i = block_base + k * 64 + lane;
                 LT::set(mi[k / W], k % W, i < i_end ? old_pos[i].w : T(0));
             }
-#pragma unroll 1
-            for (int it = 0; it < 64 / UNR; ++it) {
-#pragma unroll
-                for (int v = 0; v < UNR; ++v) step.template operator()<false>(jx, jy, jz, jm, rx, ry, rz, mi);
-            }
-            scale = T(1);
+            if (tile_uniform) sixty_four_steps.template operator()<true, false>(jx, jy, jz, jm, rx, ry, rz, mi);
+            else sixty_four_steps.template operator()<true, true>(jx, jy, jz, jm, rx, ry, rz, mi);
         }
         // 64 steps on: every sum is back in the lane of its body j.  Keep the reaction only when the partner does not list the pair too.
         const bool     symmetric = diag ? (q != 0 && !(even && q == Q)) : (s.keep != 0);
