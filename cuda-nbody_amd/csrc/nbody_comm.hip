@@ -107,6 +107,9 @@ struct Comm {
     const void* in_flight = nullptr;       // the array whose tiles are (or were last) being exchanged
     void*       workspace = nullptr;       // caller-owned scratch memory (nb_comm_set_workspace)
     size_t      workspace_bytes = 0;
+    hipStream_t aux       = nullptr;       // pairwise step: every other rectangle runs here, so that the tails and launch gaps of
+    hipEvent_t  aux_begin = nullptr;       // one stream's kernels are filled by the other's (events: aux may start / aux is done)
+    hipEvent_t  aux_done  = nullptr;
     std::vector<hipEvent_t> react_ready;   // [world/2 + 1] pairwise step: "the reaction sums for partner s are in the send buffer" (compute stream)
     std::vector<hipEvent_t> react_arrived; // [world/2 + 1] ... "round s of the reaction exchange is done" (exchange stream)
     std::vector<Comm*> group;              // all local ranks of this communicator (just {this} with one process per GPU)
@@ -139,6 +142,10 @@ int make_resources(Comm* c) {
     if (err != hipSuccess) return static_cast<int>(err);
     err = hipEventCreateWithFlags(&c->ready, hipEventDisableTiming);
     if (err != hipSuccess) return static_cast<int>(err);
+    err = hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking);
+    if (err == hipSuccess) err = hipEventCreateWithFlags(&c->aux_begin, hipEventDisableTiming);
+    if (err == hipSuccess) err = hipEventCreateWithFlags(&c->aux_done, hipEventDisableTiming);
+    if (err != hipSuccess) return static_cast<int>(err);
     c->arrived.assign(static_cast<size_t>(c->world), nullptr);
     c->react_ready.assign(static_cast<size_t>(c->world / 2 + 1), nullptr);
     c->react_arrived.assign(static_cast<size_t>(c->world / 2 + 1), nullptr);
@@ -157,6 +164,9 @@ void free_resources(Comm* c) {
         for (auto e : *events)
             if (e) (void)hipEventDestroy(e);
     if (c->ready) (void)hipEventDestroy(c->ready);
+    if (c->aux_begin) (void)hipEventDestroy(c->aux_begin);
+    if (c->aux_done) (void)hipEventDestroy(c->aux_done);
+    if (c->aux) (void)hipStreamDestroy(c->aux);
     if (c->stream) (void)hipStreamDestroy(c->stream);
 }
 
@@ -283,7 +293,7 @@ template <typename T> PairShard plan_pair_shard(unsigned num_bodies, int G, int 
     p.self_at    = 0;
     p.react_d_at = p.self_at + (p.diag.splits + static_cast<size_t>(p.H) * p.rect.splits) * plane3;
     p.react_r_at = p.react_d_at + p.diag_slots * plane3;
-    p.send_at    = p.react_r_at + p.blocks * plane3;
+    p.send_at    = p.react_r_at + 2 * p.blocks * plane3;  // (two regions: the rectangles alternate between two streams)
     p.recv_at    = p.send_at + p.H * plane3;
     p.elements   = p.recv_at + p.H * plane3;
     p.applies    = true;
@@ -296,7 +306,8 @@ std::atomic<int> g_pair_shard_min{0};  // nb_set_pair_plan_override(.., min_bodi
 // the rectangle and the fold of its reaction sums into the send buffer.  `c` == nullptr: no communicator (nb_emulate_pair_rank_*:
 // kernel-time projection of a rank of a G-rank system on one GPU) -- no waits for tiles, no events.
 template <typename T>
-int pair_rank_tiles(Comm* c, unsigned r, int G, const PairShard& plan, T* work, T* new_pos, const T* old_pos, T* vel, unsigned num_bodies, T dt, T damping, T eps2, hipStream_t stream, bool waiting, nb::FinishArgs<T>& f) {
+int pair_rank_tiles(Comm* c, unsigned r, int G, const PairShard& plan, T* work, T* new_pos, const T* old_pos, T* vel, unsigned num_bodies, T dt, T damping, T eps2, hipStream_t stream, bool waiting, nb::FinishArgs<T>& f,
+                    hipStream_t aux, hipEvent_t aux_begin, hipEvent_t aux_done) {
     const unsigned ni     = plan.ni, own = r * ni;
     const size_t   plane3 = 3 * static_cast<size_t>(plan.plane);
     f = {};
@@ -313,15 +324,25 @@ int pair_rank_tiles(Comm* c, unsigned r, int G, const PairShard& plan, T* work, 
     // the diagonal: the rank's own slice against itself (its positions are local: nothing to wait for)
     a.react = work + plan.react_d_at, a.react_origin = own;
     a.i_begin = a.j_begin = own, a.i_count = a.j_count = ni, a.diag = 1, a.keep = 1, a.self_first = 0;
+    if (aux != nullptr) {  // the second stream joins in here: after everything the step's own stream has done so far
+        auto err = hipEventRecord(aux_begin, stream);
+        if (err == hipSuccess) err = hipStreamWaitEvent(aux, aux_begin, 0);
+        if (err != hipSuccess) return static_cast<int>(err);
+    }
     if (const auto err = nb::launch_pair_tile<T>(a, plan.diag, stream); err != hipSuccess) return static_cast<int>(err);
     f.self_set[f.n_self++] = {0u, plan.diag.splits, 0u, ni};
     // the rectangles against the partners r+1 .. r+H, each as its positions arrive
     for (unsigned s = 1; s <= plan.H; ++s) {
-        const unsigned p = (r + s) % static_cast<unsigned>(G);
+        const unsigned p    = (r + s) % static_cast<unsigned>(G);
+        // odd rectangles on the second stream (own region of reaction planes) once there are at least two: measured on one rank's
+        // kernels (tools/pair_rank_probe.py) 8 ranks 1.34 against 1.45 ms, 4 ranks 2.55 / 2.67; with one rectangle it only
+        // competes with the diagonal (2 ranks: 5.2 / 5.05)
+        const bool     other = aux != nullptr && plan.H >= 2 && (s & 1u) != 0;
+        hipStream_t    on   = other ? aux : stream;
         if (c != nullptr && waiting) {
-            if (const auto err = hipStreamWaitEvent(stream, c->arrived[p], 0); err != hipSuccess) return static_cast<int>(err);
+            if (const auto err = hipStreamWaitEvent(on, c->arrived[p], 0); err != hipSuccess) return static_cast<int>(err);
         }
-        a.diag = 0, a.keep = 1, a.react = work + plan.react_r_at;
+        a.diag = 0, a.keep = 1, a.react = work + plan.react_r_at + (other ? plan.blocks * plane3 : size_t{0});
         a.i_begin = own, a.i_count = ni, a.j_begin = p * ni, a.j_count = ni;
         if (plan.even && s == plan.H) {  // both partners list this pair of ranks: split the rectangle
             if (r < p) a.j_count = plan.half;
@@ -329,17 +350,22 @@ int pair_rank_tiles(Comm* c, unsigned r, int G, const PairShard& plan, T* work, 
         }
         a.react_origin = a.j_begin;
         a.self_first   = plan.diag.splits + (s - 1) * plan.rect.splits;
-        if (const auto err = nb::launch_pair_tile<T>(a, plan.rect, stream); err != hipSuccess) return static_cast<int>(err);
+        if (const auto err = nb::launch_pair_tile<T>(a, plan.rect, on); err != hipSuccess) return static_cast<int>(err);
         f.self_set[f.n_self++] = {a.self_first, plan.rect.splits, a.i_begin - own, a.i_count};
         const unsigned blocks_i = (a.i_count + plan.block - 1) / plan.block;
-        if (const auto err = nb::launch_pair_reduce<T>(a.react, plan.plane, blocks_i, work + plan.send_at + (s - 1) * plane3, plan.plane, a.j_count, stream); err != hipSuccess) return static_cast<int>(err);
+        if (const auto err = nb::launch_pair_reduce<T>(a.react, plan.plane, blocks_i, work + plan.send_at + (s - 1) * plane3, plan.plane, a.j_count, on); err != hipSuccess) return static_cast<int>(err);
         if (c != nullptr) {
-            if (const auto err = hipEventRecord(c->react_ready[s], stream); err != hipSuccess) return static_cast<int>(err);
+            if (const auto err = hipEventRecord(c->react_ready[s], on); err != hipSuccess) return static_cast<int>(err);
         }
         // what arrives in round s comes from rank r-s, which covered: all of this slice -- or, splitting the rectangle as the
         // lower rank, only the first half of its blocks
         const unsigned q = (r + static_cast<unsigned>(G) - s) % static_cast<unsigned>(G);
         f.recv_set[f.n_recv++] = {0u, (plan.even && s == plan.H && q < r) ? plan.half : ni};
+    }
+    if (aux != nullptr) {  // the finish kernel (on `stream`) needs the second stream's sums too
+        auto err = hipEventRecord(aux_done, aux);
+        if (err == hipSuccess) err = hipStreamWaitEvent(stream, aux_done, 0);
+        if (err != hipSuccess) return static_cast<int>(err);
     }
     return 0;
 }
@@ -356,7 +382,7 @@ int pair_sharded_step(const std::vector<Comm*>& locals, const PairShard& plan, T
         DeviceScope scope(c->device);
         const bool  waiting = c->in_flight == static_cast<const void*>(old_pos[k]);
         const int   rc = pair_rank_tiles<T>(c, static_cast<unsigned>(c->rank), G, plan, static_cast<T*>(c->workspace), new_pos[k], old_pos[k], vel[k], num_bodies, dt, damping, eps2,
-                                            reinterpret_cast<hipStream_t>(streams[k]), waiting, finish[k]);
+                                            reinterpret_cast<hipStream_t>(streams[k]), waiting, finish[k], c->aux, c->aux_begin, c->aux_done);
         if (rc != 0) return rc;
     }
     // the reaction exchange: round s = send to r+s what was summed for its bodies, receive from r-s; one RCCL group per round
@@ -489,7 +515,22 @@ template <typename T> int emulate_pair_rank(T* new_pos, const T* old_pos, T* vel
     if (!new_pos || !old_pos || !vel || new_pos == old_pos) return NB_ERR_INVALID_ARGUMENT;
     nb::FinishArgs<T> f{};
     hipStream_t       s  = reinterpret_cast<hipStream_t>(stream);
-    const int         rc = pair_rank_tiles<T>(nullptr, static_cast<unsigned>(rank), world, plan, static_cast<T*>(workspace), new_pos, old_pos, vel, num_bodies, dt, damping, eps2, s, false, f);
+    // the second stream of the step, as a communicator would own it (one per device, created on first use, never destroyed)
+    static std::mutex  guard;
+    static hipStream_t aux[64]   = {};
+    static hipEvent_t  begin[64] = {}, done[64] = {};
+    int                dev       = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return NB_ERR_INVALID_ARGUMENT;
+    {
+        std::lock_guard<std::mutex> lock(guard);
+        if (aux[dev] == nullptr && std::getenv("NBODY_PAIR_ONE_STREAM") == nullptr) {
+            NB_KEEP_RAND_STREAM;
+            if (hipStreamCreateWithFlags(&aux[dev], hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&begin[dev], hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&done[dev], hipEventDisableTiming) != hipSuccess)
+                return NB_ERR_UNSUPPORTED;
+        }
+    }
+    const int rc = pair_rank_tiles<T>(nullptr, static_cast<unsigned>(rank), world, plan, static_cast<T*>(workspace), new_pos, old_pos, vel, num_bodies, dt, damping, eps2, s, false, f, aux[dev], begin[dev], done[dev]);
     if (rc != 0) return rc;
     return static_cast<int>(nb::launch_pair_finish<T>(f, s));
 }
