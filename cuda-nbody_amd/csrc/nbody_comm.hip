@@ -11,8 +11,11 @@
 // STRICT keeps the CPU path's summation order (ascending j): tiles in rank order, each waiting for its own round,
 // bit-identical to one GPU.
 //
-// Two process models, one code path: one process per GPU (nb_comm_init_rank; a group of 1 local rank) or one process
-// driving several GPUs (nb_comm_init_all; every RCCL round is then one ncclGroup over the local ranks).
+// FAST with a workspace lent to every rank (round 3): each pair of bodies is evaluated once across the ranks too -- see
+// pair_sharded_step below; the position exchange stays as described, a second leg carries reaction sums to their owners.
+//
+// Process models, one code path: one process per GPU (nb_comm_init_rank; a group of 1 local rank) or one process
+// driving several GPUs (nb_comm_init_all; every RCCL round is then one ncclGroup over the local ranks); a thread per GPU works too.
 // RCCL is dlopen'ed on first use (librccl.so.1): a single-GPU run never pays for loading it, and inside a torch process
 // the copy torch already loaded is the one that gets bound (same SONAME).
 #include "../../include/nbody_hip.h"
