@@ -205,8 +205,16 @@ int exchange_tiles(const std::vector<Comm*>& locals, void* const* positions, uns
         if (err != hipSuccess) return static_cast<int>(err);
         c->in_flight = positions[k];
     }
-    for (int s = 1; s < G; ++s) {
-        int rc = lib->GroupStart();
+    // NBODY_EXCHANGE_ONE_GROUP=1: all G-1 rounds as ONE RCCL group -- one RCCL kernel per step instead of G-1, every xGMI link
+    // busy at once, all tiles arriving together (no per-tile pipelining).  A knob for the day this runs on several GPUs: a force
+    // kernel holds every CU for its whole run, so each separate round may have to wait for a workgroup slot.  Default: separate.
+    static const bool one_group = [] {
+        const char* v = std::getenv("NBODY_EXCHANGE_ONE_GROUP");
+        return v != nullptr && v[0] == '1';
+    }();
+    int rc = one_group ? lib->GroupStart() : 0;
+    for (int s = 1; s < G && rc == 0; ++s) {
+        if (!one_group) rc = lib->GroupStart();
         for (size_t k = 0; k < locals.size() && rc == 0; ++k) {
             Comm*      c    = locals[k];
             const int  dst  = (c->rank - s + G) % G, src = (c->rank + s) % G;
@@ -214,6 +222,7 @@ int exchange_tiles(const std::vector<Comm*>& locals, void* const* positions, uns
             rc              = lib->Send(base + static_cast<size_t>(c->rank) * slice_bodies * bytes_per_body, slice_values, nccl_type, dst, c->nccl, c->stream);
             if (rc == 0) rc = lib->Recv(base + static_cast<size_t>(src) * slice_bodies * bytes_per_body, slice_values, nccl_type, src, c->nccl, c->stream);
         }
+        if (one_group) continue;
         const int end = lib->GroupEnd();
         if (rc == 0) rc = end;
         if (rc != 0) return nccl_status(rc);
@@ -223,7 +232,19 @@ int exchange_tiles(const std::vector<Comm*>& locals, void* const* positions, uns
             if (err != hipSuccess) return static_cast<int>(err);
         }
     }
-    return 0;
+    if (one_group) {
+        const int end = lib->GroupEnd();
+        if (rc == 0) rc = end;
+        if (rc != 0) return nccl_status(rc);
+        for (Comm* c : locals) {
+            DeviceScope scope(c->device);
+            for (int s = 1; s < G; ++s) {
+                const auto err = hipEventRecord(c->arrived[static_cast<size_t>((c->rank + s) % G)], c->stream);
+                if (err != hipSuccess) return static_cast<int>(err);
+            }
+        }
+    }
+    return rc != 0 ? nccl_status(rc) : 0;
 }
 
 template <typename T> struct Api;

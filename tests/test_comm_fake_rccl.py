@@ -26,20 +26,21 @@ NCCL_SYMBOLS = ("ncclGetUniqueId", "ncclCommInitRank", "ncclCommInitAll", "ncclC
                 "ncclGroupEnd", "ncclGetErrorString")
 
 
-def _env():
+def _env(**extra):
     if not os.path.exists(FAKE_LIB):  # (normally built by __graft_entry__.build() and shipped with the tree)
         subprocess.run(["make", "-s", "-C", FAKE_DIR], check=True)
     env = dict(os.environ)
     env["NBODY_RCCL_LIB"] = FAKE_LIB
     env["FAKE_RCCL_TIMEOUT_S"] = "120"
+    env.update(extra)
     return env
 
 
-def _run(tmp_path, case, pos0, vel0, world, steps, mode, streams="streams", workspace=False):
+def _run(tmp_path, case, pos0, vel0, world, steps, mode, streams="streams", workspace=False, **env):
     src, dst = tmp_path / f"in_{case}.npz", tmp_path / f"out_{case}.npz"
     np.savez(src, pos=pos0, vel=vel0)
     r = subprocess.run([sys.executable, os.path.join(FAKE_DIR, "worker.py"), case, str(src), str(dst), str(world), str(steps), mode, streams, "ws" if workspace else "-"],
-                       env=_env(), capture_output=True, text=True, timeout=900)
+                       env=_env(**env), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     with np.load(dst, allow_pickle=False) as data:  # read everything now: the next run of the same case rewrites the file
         return {k: data[k] for k in data.files}
@@ -296,3 +297,22 @@ def test_config4_shape_eight_ranks_at_one_mi_bodies(tmp_path, oracle):
     np.testing.assert_allclose(got["pos_0"], got["single_pos"], rtol=0, atol=5e-5)
     vel = np.concatenate([got[f"vel_{k}"] for k in range(world)])
     np.testing.assert_allclose(vel, got["single_vel"], rtol=0, atol=1e-2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("workspace", [False, True])
+def test_position_exchange_as_one_group(tmp_path, oracle, workspace):
+    """NBODY_EXCHANGE_ONE_GROUP=1: the G-1 position rounds of a step as ONE RCCL group (a knob for real multi-GPU runs): the same
+    bits as with a group per round -- STRICT == the CPU path, FAST (one-sided tiles and pairwise across ranks) == the default."""
+    n, steps, world = 4096, 4, 4
+    pos0, vel0 = oracle.startup_state(n, np.float32)
+    ref_p, ref_v = pos0.copy(), vel0.copy()
+    oracle.update(ref_p, ref_v, np.float32(0.016), steps=steps)
+    strict = _run(tmp_path, "all", pos0, vel0, world, steps, "strict", workspace=workspace, NBODY_EXCHANGE_ONE_GROUP="1")
+    assert strict["pos_0"].tobytes() == ref_p.tobytes()
+    sends, recvs, gathers, groups, copies = strict["counters"]
+    assert sends == recvs == (world - 1) * world * steps and groups == steps  # one group per step
+    fast = _run(tmp_path, "all", pos0, vel0, world, steps, "fast", workspace=workspace, NBODY_EXCHANGE_ONE_GROUP="1")
+    default = _run(tmp_path, "all", pos0, vel0, world, steps, "fast", workspace=workspace)
+    for k in range(world):
+        assert fast[f"pos_{k}"].tobytes() == default["pos_0"].tobytes()
