@@ -184,3 +184,32 @@ def test_cli_numdevices_one_is_the_single_gpu_run(tmp_path):
     for bad in (["--devices=0,7"], ["--numdevices=1", "--hostmem"], ["--devices=x"]):
         r = subprocess.run([cli, "--benchmark", "--numbodies=1024", *bad], capture_output=True, text=True, timeout=300)
         assert r.returncode == 1, bad
+
+
+def test_real_rccl_refuses_two_ranks_on_one_device(pkg):
+    """The one thing the REAL RCCL can be asked on a one-GPU box: nb_comm_init_all(2, {0, 0}) must come back with RCCL's own
+    refusal (duplicate device: ncclInvalidUsage / ncclInvalidArgument) as an NB_ERR_RCCL_BASE code and a readable message --
+    not hang, not crash, no communicator left behind.  (With more than one rank per device the tests use the transport double,
+    tests/test_comm_fake_rccl.py.)"""
+    import ctypes
+    import subprocess
+    import sys
+
+    script = r'''
+import ctypes, sys
+sys.path.insert(0, %r)
+import __graft_entry__ as entry
+pkg = entry.load_package(); lib = pkg.lib()
+pkg.check(lib.nb_set_device(0))
+comms = (ctypes.c_void_p * 2)()
+rc = lib.nb_comm_init_all(comms, 2, (ctypes.c_int * 2)(0, 0))
+print("RC", rc, lib.nb_error_string(rc).decode(), comms[0], comms[1])
+''' % ROOT
+    env = dict(os.environ)
+    env.pop("NBODY_RCCL_LIB", None)
+    out = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    import re
+
+    m = re.search(r"RC (\d+) (RCCL: .+) (\S+) (\S+)$", out.stdout.strip())
+    assert m and 20000 < int(m.group(1)) < 20010 and m.group(3) == "None" and m.group(4) == "None", out.stdout
