@@ -69,7 +69,7 @@ def parse_args():
     ap.add_argument("--layout", choices=["pairwise", "one-sided"], default="pairwise",
                     help="FAST on one GPU: pairwise = nb_integrate_ws_* with a caller-owned workspace (every pair of bodies evaluated once and "
                          "applied to both, csrc/nbody_pair.hip); one-sided = nb_integrate_* (every directed interaction, as the reference kernel)")
-    ap.add_argument("--dump-state", type=str, default="", help="rank 0 writes its final positions (.npy) here (tests)")
+    ap.add_argument("--dump-state", type=str, default="", help="rank 0 writes its initial and final positions (.npz) here (tests)")
     ap.add_argument("--no-configs", action="store_true", help="skip the extra BASELINE configs timed after the headline measurement (N=1)")
     ap.add_argument("--launch-timeout", type=float, default=600.0,
                     help="plain `bench.py --gpus N`: seconds the launcher waits for the N ranks before ending them (see self_launch)")
@@ -286,6 +286,11 @@ def main():
     # copy by SONAME.  The other order puts two HIP runtimes in the process and the second sees no device.
     import torch
 
+    # The bodies come from the process-global libc rand() stream (the reference's randomise_bodies does), so they are drawn NOW:
+    # while this process has a single thread.  Later, torch.distributed's store and gloo threads are running and may draw from
+    # the same stream in between (seen once in round 3: two runs of one command that differed in a few bodies).
+    pos0, vel0 = make_bodies(n, dtype)
+
     pkg = entry.load_package()
     lib = pkg.lib()
     mode = pkg.NB_MODE_FAST if args.mode == "fast" else pkg.NB_MODE_STRICT
@@ -324,7 +329,6 @@ def main():
             rccl_group = torch_rccl_group()
     info = pkg.device_info(local_rank)
 
-    pos0, vel0 = make_bodies(n, dtype)
     params = pkg.NBodyParams()
     dt = dtype(np.float32(params.time_step))
     damping = dtype(np.float32(params.damping))
@@ -773,7 +777,7 @@ def main():
             final = capi_rank.pos[capi_rank.read] if capi_rank is not None else (system.positions().data_ptr() if system is not None else bufs[state["read"]].data_ptr())
             host = np.zeros(4 * n, dtype)
             pkg.check(lib.nb_d2h(host.ctypes.data_as(ctypes.c_void_p), final, host.nbytes, None), "nb_d2h")
-            np.save(args.dump_state, host)
+            np.savez(args.dump_state, final=host, initial=pos0)  # (the bodies the run started from, too: a test can tell a different start from a different step)
 
     # Diagnostics for N > 1: the exchange alone and the kernels of one step alone (exposed exchange = step - kernels).
     # Taken after the timed region, never part of `value`, and printed to STDERR after the JSON line is already out,
