@@ -242,3 +242,31 @@ def test_pairwise_inner_loops_keep_their_instruction_mix():
     assert all(m[6] <= 2 for m in mixes), mixes  # at most a stray hazard s_nop per four steps (296 instructions)
     tail = "\n".join(lines[end:end + 60])
     assert int(re.search(r"; NumVgprs: (\d+)", tail).group(1)) <= 128
+
+
+def test_pair_shard_plan_without_gpu(pkg):
+    """The multi-GPU pairwise plan is host logic too: nb_emulate_pair_rank_* with no workspace only answers how many bytes a
+    rank of a G-rank step needs -- (self sets + diagonal slots + two rectangle regions + send + receive planes) x 3 x the padded
+    slice -- or says that the pairwise step does not apply (slices under 2 048 bodies, a world of one, bodies that do not shard)."""
+    import ctypes
+
+    import numpy as np
+
+    lib = pkg.lib()
+
+    def need(n, world, rank=0, fn=lib.nb_emulate_pair_rank_f32, dt=np.float32(0.016)):
+        bytes_ = ctypes.c_size_t(0)
+        rc = fn(None, None, None, None, ctypes.byref(bytes_), n, world, rank, dt, dt, None)
+        return rc, bytes_.value
+
+    rc, b8 = need(262144, 8)
+    # 32 768 bodies per rank: R = 4 -> 64 blocks of 512, C = 8 for the diagonal and the rectangles, H = 4 partners, 31 diagonal slots
+    assert rc == 0 and b8 == ((8 + 4 * 8) + 31 + 2 * 64 + 4 + 4) * 3 * 32768 * 4
+    rc, b2 = need(262144, 2)
+    assert rc == 0 and b2 > b8
+    assert need(262144, 8, fn=lib.nb_emulate_pair_rank_f64, dt=0.016)[0] == 0
+    assert need(262144, 1)[0] == 10001          # a world of one is not a sharded step
+    assert need(262144, 8, rank=8)[0] == 10001
+    assert need(8192, 8)[0] == 10002            # 1 024 bodies per rank: too small a slice
+    assert need(262145, 8)[0] == 10002          # does not shard evenly
+    assert lib.nb_emulate_pair_rank_f32(None, None, None, None, None, 262144, 8, 0, np.float32(0.016), np.float32(1), None) == 10001
