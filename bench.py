@@ -185,19 +185,19 @@ FP64_ISSUE_CEILING_INTERACTIONS_PER_S = 1024 * 64 * 2.4e9 / 78.0
 def other_configs(pkg, lib, headline):
     """BASELINE.json configs besides the headline one, plus STRICT (the parity-exact mode) and, for FAST, both layouts
     (pairwise = nb_integrate_ws_* with a workspace, one-sided = nb_integrate_*), each as
-    {workload, bodies, dtype, mode, layout, steps, ms_per_step, interactions_per_s, frac}: 1 warm-up step, then K steps between two
+    {workload, bodies, dtype, mode, layout, steps, ms_per_step, frac}: 1 warm-up step, then K steps between two
     HIP events on the launch stream (the reference's GPU protocol, compute_cuda.cpp:183-195); frac against the same
     vector-FMA peaks as the headline (20 flop per fp32 interaction, 30 per fp64: compute.cpp:16-18)."""
     cases = [
-        ("configs[1]: 65 536 bodies, fp32, 1 GPU", 65536, False, "fast", 200),
-        ("configs[2]: 262 144 bodies, fp32, 1 GPU", 262144, False, "fast", 20),
-        ("configs[4]: 262 144 bodies, fp64, 1 GPU", 262144, True, "fast", 5),
-        ("configs[3]'s system on ONE GPU: 1 048 576 bodies, fp32", 1048576, False, "fast", 3),
-        ("STRICT (bit-identical to the CPU BodySystem path): 262 144 bodies, fp32", 262144, False, "strict", 5),
-        ("STRICT: 262 144 bodies, fp64", 262144, True, "strict", 3),
-        ("configs[0]'s system on the GPU: 1 024 bodies, fp32, 100 steps", 1024, False, "fast", 100),
-        ("configs[0]'s system on the GPU, STRICT: 1 024 bodies, fp32, 100 steps", 1024, False, "strict", 100),
-        ("16 384 bodies, fp32 (small-system class)", 16384, False, "fast", 200),
+        ("configs[1]", 65536, False, "fast", 200),
+        ("configs[2]", 262144, False, "fast", 20),
+        ("configs[4]", 262144, True, "fast", 5),
+        ("configs[3]'s system on ONE GPU", 1048576, False, "fast", 3),
+        ("STRICT = the CPU path's bits", 262144, False, "strict", 5),
+        ("STRICT", 262144, True, "strict", 3),
+        ("configs[0]'s system on the GPU", 1024, False, "fast", 100),
+        ("configs[0]'s system on the GPU", 1024, False, "strict", 100),
+        ("small system", 16384, False, "fast", 200),
     ]
     out = []
     for what, n, fp64, mode_name, steps in cases:
@@ -225,8 +225,9 @@ def other_configs(pkg, lib, headline):
             ms = e0.elapsed_ms(e1) / steps
             system.free()
             flops, peak = (30, FP64_VECTOR_PEAK_TFLOPS) if fp64 else (20, FP32_VECTOR_PEAK_TFLOPS)
-            out.append({"workload": what, "bodies": n, "dtype": "f64" if fp64 else "f32", "mode": mode_name, "layout": layout, "steps": steps, "ms_per_step": ms,
-                        "interactions_per_s": float(n) * n / (ms * 1e-3), "frac": flops * float(n) * n / (ms * 1e-3) / (peak * 1e12)})
+            # (kept short: the whole line should stay well under what a log tail holds; interactions/s = bodies^2 / ms_per_step)
+            out.append({"workload": what, "bodies": n, "dtype": "f64" if fp64 else "f32", "mode": mode_name, "layout": layout, "steps": steps,
+                        "ms_per_step": float(f"{ms:.5g}"), "frac": round(flops * float(n) * n / (ms * 1e-3) / (peak * 1e12), 4)})
     return out
 
 
@@ -238,8 +239,8 @@ def rank_projection(pkg, lib, n, dtype, dt, damping, single_ms):
     pos0, vel0 = make_bodies(n, dtype)
     bufs = [pkg.DeviceBuffer(pos0.nbytes) for _ in range(3)]
     bufs[0].upload(pos0), bufs[2].upload(vel0)
-    out = {"what": "kernel time of one rank of a G-rank pairwise step, alone on one GPU, no exchange: a PROJECTION of the compute side of strong scaling, "
-                   "not a multi-GPU measurement", "single_gpu_ms_per_step": single_ms, "ranks": {}}
+    out = {"what": "PROJECTION, not a multi-GPU measurement: kernel ms of ONE rank of a G-rank pairwise step, alone on one GPU, no exchange",
+           "single_gpu_ms_per_step": float(f"{single_ms:.5g}"), "ranks": {}}
     for G in (2, 4, 8):
         need = ctypes.c_size_t(0)
         if emulate(None, None, None, None, ctypes.byref(need), n, G, 0, dt, damping, None) != 0:
@@ -258,7 +259,7 @@ def rank_projection(pkg, lib, n, dtype, dt, damping, single_ms):
         e1.record(None)
         e1.synchronize()
         ms = e0.elapsed_ms(e1) / 10
-        out["ranks"][str(G)] = {"ms_per_step_kernels_only": ms, "projected_speedup_excluding_exchange": single_ms / ms, "workspace_bytes_per_rank": need.value}
+        out["ranks"][str(G)] = {"kernel_ms": float(f"{ms:.5g}"), "speedup_excl_exchange": round(single_ms / ms, 2)}
         work.free()
     for b in bufs:
         b.free()
@@ -752,9 +753,8 @@ def main():
                 "unit": "interactions/s",
                 "cores": 1,
                 "kind": "port",
-                "sample": f"force pass of BodySystemCPU::update (AVX-256 fp32 / scalar fp64 port, oracle/) for the first "
-                          f"{sample} bodies i against all {n} bodies j of the same workload = {sample * n:.3g} interactions; "
-                          f"1 thread is how the reference ships (OpenMP never enabled)",
+                "sample": f"force pass of BodySystemCPU::update (oracle/ port) for the first {sample} bodies i against all {n} bodies j = {sample * n:.3g} "
+                          f"interactions; 1 thread is how the reference ships",
                 "openmp": base["openmp"],
             }
         if world == 1 and not args.no_configs and not args.plan:

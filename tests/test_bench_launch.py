@@ -108,7 +108,7 @@ def test_default_line_carries_every_baseline_config():
     assert line["roofline"]["executed"]["frac"] < line["roofline"]["frac"]
     projection = line["multi_gpu_kernel_projection"]
     assert "PROJECTION" in projection["what"] and set(projection["ranks"]) == {"2", "4", "8"}
-    assert projection["ranks"]["8"]["ms_per_step_kernels_only"] < projection["ranks"]["2"]["ms_per_step_kernels_only"] < line["ms_per_step"]
+    assert projection["ranks"]["8"]["kernel_ms"] < projection["ranks"]["2"]["kernel_ms"] < line["ms_per_step"]
     for c in line["configs"]:
         assert c["ms_per_step"] > 0 and 0 < c["frac"] < 1.3  # (pairwise: the algorithmic count may pass the one-sided peak)
 
