@@ -300,7 +300,6 @@ def main():
 
     if args.exchange.startswith("host"):
         local_rank = 0  # every rank on the one GPU
-    over_gloo = args.exchange.startswith("host") or args.exchange == "staged"
     torch.cuda.set_device(local_rank)
     pkg.check(lib.nb_set_device(local_rank), "nb_set_device")
     dev = torch.device("cuda", local_rank)
