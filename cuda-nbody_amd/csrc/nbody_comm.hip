@@ -205,12 +205,14 @@ int exchange_tiles(const std::vector<Comm*>& locals, void* const* positions, uns
         if (err != hipSuccess) return static_cast<int>(err);
         c->in_flight = positions[k];
     }
-    // NBODY_EXCHANGE_ONE_GROUP=1: all G-1 rounds as ONE RCCL group -- one RCCL kernel per step instead of G-1, every xGMI link
-    // busy at once, all tiles arriving together (no per-tile pipelining).  A knob for the day this runs on several GPUs: a force
-    // kernel holds every CU for its whole run, so each separate round may have to wait for a workgroup slot.  Default: separate.
+    // All G-1 rounds of a step go out as ONE RCCL group (one RCCL kernel per step, every xGMI link busy at once, all tiles arriving
+    // together): a force kernel holds every CU for its whole run (two 512-thread workgroups per CU at 128 VGPRs), so an RCCL
+    // kernel that becomes ready in the middle of one waits for a workgroup slot -- a wait that G-1 separate rounds could pay G-1
+    // times per step.  NBODY_EXCHANGE_ONE_GROUP=0 issues a group per round instead (tile k's event then fires with round k):
+    // the A/B knob for the day this runs on several GPUs.  Same data, same bits either way (tested with the transport double).
     static const bool one_group = [] {
         const char* v = std::getenv("NBODY_EXCHANGE_ONE_GROUP");
-        return v != nullptr && v[0] == '1';
+        return v == nullptr || v[0] != '0';
     }();
     int rc = one_group ? lib->GroupStart() : 0;
     for (int s = 1; s < G && rc == 0; ++s) {

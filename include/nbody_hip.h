@@ -171,8 +171,9 @@ NB_API int nb_integrate_shard_f64(double* new_positions, const double* old_posit
  *  is single-GPU).  Rank r of G owns bodies [r*N/G, (r+1)*N/G) -- N must be a multiple of G; pad with zero-mass bodies
  *  as tipsy.cpp:111-119 does -- i.e. their velocities and their slice of every new position array; all arrays stay
  *  full-size.  The one exchange step is the all-gather of the new positions, issued as G-1 position TILES: in round s
- *  rank r sends its slice to r-s and receives the slice of r+s (one grouped RCCL send/recv pair per round on the
- *  communicator's own high-priority stream, an event per round).  nb_sharded_step_* = the kernels of the own slice,
+ *  rank r sends its slice to r-s and receives the slice of r+s (RCCL send/recv pairs on the communicator's own
+ *  high-priority stream, all rounds of a step in one RCCL group -- NBODY_EXCHANGE_ONE_GROUP=0: a group per round --, an
+ *  event per tile).  nb_sharded_step_* = the kernels of the own slice,
  *  then of each tile as it arrives (STRICT: ascending rank order, bit-identical to one GPU), integrate, and the start
  *  of the exchange of new_positions -- everything asynchronous; the caller ping-pongs the two position arrays exactly
  *  as with nb_integrate_*.  Process models: one process per GPU (nb_comm_unique_id on rank 0, ship the 128 bytes to

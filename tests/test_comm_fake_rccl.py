@@ -70,7 +70,7 @@ def test_init_all_four_ranks_on_one_gpu(tmp_path, oracle, dtype, tag, mode):
     got = _run(tmp_path, "all", pos0, vel0, world, steps, mode)
     assert list(got["rejected"]) == [10001, 10001, 10001]  # subset of the group / a rank twice / per-rank form on a multi-rank group
     sends, recvs, gathers, groups, copies = got["counters"]
-    assert sends == recvs == copies == (world - 1) * world * steps and groups == (world - 1) * steps and gathers == 0
+    assert sends == recvs == copies == (world - 1) * world * steps and groups == steps and gathers == 0  # (one group per step holds all G-1 rounds)
     ref_p, ref_v = pos0.copy(), vel0.copy()
     oracle.update(ref_p, ref_v, dtype(np.float32(0.016)), steps=steps)
     pos = [got[f"pos_{k}"] for k in range(world)]
@@ -110,7 +110,7 @@ def test_init_rank_one_thread_per_rank(tmp_path, oracle, mode):
     pos0, vel0 = oracle.startup_state(n, np.float32)
     got = _run(tmp_path, "threads", pos0, vel0, world, steps, mode)
     sends, recvs, gathers, groups, copies = got["counters"]
-    assert sends == recvs == copies == (world - 1) * world * steps and groups == (world - 1) * world * steps
+    assert sends == recvs == copies == (world - 1) * world * steps and groups == world * steps
     ref_p, ref_v = pos0.copy(), vel0.copy()
     oracle.update(ref_p, ref_v, np.float32(0.016), steps=steps)
     vel = np.concatenate([got[f"vel_{k}"] for k in range(world)])
@@ -211,7 +211,7 @@ def test_pairwise_step_across_ranks(tmp_path, oracle, world, dtype):
     got = _run(tmp_path, "all", pos0, vel0, world, steps, "fast", workspace=True)
     assert np.all(got["workspace_bytes"] > 0)
     sends, recvs, gathers, groups, copies = got["counters"]
-    assert sends == recvs == (world - 1 + world // 2) * world * steps and groups == (world - 1 + world // 2) * steps
+    assert sends == recvs == (world - 1 + world // 2) * world * steps and groups == (1 + world // 2) * steps
     ref_p, ref_v = pos0.copy(), vel0.copy()
     oracle.update(ref_p, ref_v, dtype(np.float32(0.016)), steps=steps)
     for k in range(1, world):
@@ -301,18 +301,19 @@ def test_config4_shape_eight_ranks_at_one_mi_bodies(tmp_path, oracle):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("workspace", [False, True])
-def test_position_exchange_as_one_group(tmp_path, oracle, workspace):
-    """NBODY_EXCHANGE_ONE_GROUP=1: the G-1 position rounds of a step as ONE RCCL group (a knob for real multi-GPU runs): the same
-    bits as with a group per round -- STRICT == the CPU path, FAST (one-sided tiles and pairwise across ranks) == the default."""
+def test_position_exchange_one_group_per_round(tmp_path, oracle, workspace):
+    """NBODY_EXCHANGE_ONE_GROUP=0: a group per round (tile k's event fires with round k) instead of the default one group per
+    step -- the A/B knob for real multi-GPU runs: the same bits -- STRICT == the CPU path, FAST (one-sided tiles and pairwise
+    across ranks) == the default."""
     n, steps, world = 4096, 4, 4
     pos0, vel0 = oracle.startup_state(n, np.float32)
     ref_p, ref_v = pos0.copy(), vel0.copy()
     oracle.update(ref_p, ref_v, np.float32(0.016), steps=steps)
-    strict = _run(tmp_path, "all", pos0, vel0, world, steps, "strict", workspace=workspace, NBODY_EXCHANGE_ONE_GROUP="1")
+    strict = _run(tmp_path, "all", pos0, vel0, world, steps, "strict", workspace=workspace, NBODY_EXCHANGE_ONE_GROUP="0")
     assert strict["pos_0"].tobytes() == ref_p.tobytes()
     sends, recvs, gathers, groups, copies = strict["counters"]
-    assert sends == recvs == (world - 1) * world * steps and groups == steps  # one group per step
-    fast = _run(tmp_path, "all", pos0, vel0, world, steps, "fast", workspace=workspace, NBODY_EXCHANGE_ONE_GROUP="1")
+    assert sends == recvs == (world - 1) * world * steps and groups == (world - 1) * steps  # a group per round
+    fast = _run(tmp_path, "all", pos0, vel0, world, steps, "fast", workspace=workspace, NBODY_EXCHANGE_ONE_GROUP="0")
     default = _run(tmp_path, "all", pos0, vel0, world, steps, "fast", workspace=workspace)
     for k in range(world):
         assert fast[f"pos_{k}"].tobytes() == default["pos_0"].tobytes()
