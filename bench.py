@@ -57,8 +57,8 @@ def parse_args():
     ap.add_argument("--plan", type=str, default="", help="I,S,TILE override for the fast kernel, e.g. 2,1,1024")
     ap.add_argument("--exchange", choices=["rccl", "torch", "allgather", "staged", "host", "host-tiles"], default="rccl",
                     help="rccl: the PRODUCT's multi-GPU path -- nb_comm_init_rank + nb_sharded_step_* of the C-ABI (csrc/nbody_comm.hip): the "
-                         "position all-gather issued as its G-1 tiles, one grouped RCCL send/recv pair per round on the communicator's side "
-                         "stream, the kernel of tile k waiting only on round k; torch.distributed then only does rendezvous, barrier and the "
+                         "position all-gather issued as its G-1 tiles, RCCL send/recv pairs on the communicator's side "
+                         "stream, the kernel of tile k waiting only on tile k's event; torch.distributed then only does rendezvous, barrier and the "
                          "time reduction (gloo).  torch: the same tile schedule re-implemented over torch.distributed "
                          "(cuda-nbody_amd/sharded.py, batch_isend_irecv) -- A/B and first fallback; allgather: one all_gather_into_tensor per "
                          "step (sharded.py); staged: no RCCL at all -- gloo, the slices gathered through host memory, each rank on its OWN GPU "

@@ -4,10 +4,11 @@
 // G owns the contiguous slice of bodies [r*N/G, (r+1)*N/G): their velocities and their slice of each new position
 // array; every array is full-size and indexed by global body id.  The one exchange step of the path is the all-gather of
 // the new positions, issued as its G-1 position TILES over RCCL (= xGMI inside a node): in round s = 1..G-1 every rank
-// sends its slice to rank r-s and receives the slice of rank r+s -- one grouped ncclSend/ncclRecv pair per round on the
-// communicator's own high-priority stream, an event after each round.  Accumulation is additive over j chunks, so a
-// step starts with the chunk that is already local (j in the rank's own slice) and then takes the tiles in arrival order,
-// the kernel of tile k waiting only for round k: the exchange of tile k+1 runs under the force compute of tile k.
+// sends its slice to rank r-s and receives the slice of rank r+s -- ncclSend/ncclRecv pairs on the communicator's own
+// high-priority stream, an event per tile (all rounds of a step in ONE RCCL group by default, a group per round with
+// NBODY_EXCHANGE_ONE_GROUP=0: see exchange_tiles).  Accumulation is additive over j chunks, so a step starts with the chunk
+// that is already local (j in the rank's own slice) and then takes the tiles in arrival order, the kernel of tile k waiting
+// only for tile k's event: the exchange runs under the force compute of the chunks already there.
 // STRICT keeps the CPU path's summation order (ascending j): tiles in rank order, each waiting for its own round,
 // bit-identical to one GPU.
 //
