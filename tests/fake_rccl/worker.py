@@ -87,6 +87,7 @@ def main():
         pkg.check(ws_bytes_fn(comm, n, mode, ctypes.byref(need)), "nb_comm_workspace_bytes")
         if need.value:
             buf = pkg.DeviceBuffer(need.value)
+            pkg.check(lib.nb_memset(buf.ptr, 0xFF, need.value, None), "nb_memset")  # NaN patterns: whatever is read must have been written
             workspaces.append(buf)
             pkg.check(lib.nb_comm_set_workspace(comm, buf.ptr, need.value), "nb_comm_set_workspace")
         return need.value

@@ -174,3 +174,38 @@ def test_pair_full_size_sampled_forces_and_momentum(gpu, oracle, n, dtype):
     assert err.max() < (1e-5 if dtype == np.float32 else 1e-10), err.max()
     total = np.abs(a.sum(axis=0)).max() / np.abs(a).sum(axis=0).max()
     assert total < (1e-6 if dtype == np.float32 else 1e-14), total
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("n,plan", [(600, (1, 4, 5)), (8256, (2, 8, 4)), (20000, (0, 0, 0)), (20000, (4, 4, 3)), (65536, (0, 0, 0)), (100032, (0, 0, 0)), (100032, (2, 16, 2))])
+def test_pair_reads_nothing_it_did_not_write(gpu, oracle, dtype, n, plan):
+    """The workspace carries nothing from launch to launch: a step over a workspace filled with NaN bit patterns gives the bits
+    of a step over a zeroed one (every slot the second kernel adds was written by the first in the same step, whatever the
+    plan, ragged sizes included) -- so a caller may hand over uninitialised memory, and share one workspace between systems."""
+    lib = gpu.lib()
+    f32 = dtype == np.float32
+    pos0, vel0 = oracle.startup_state(n, np.float32)
+    pos0, vel0 = pos0.astype(dtype), vel0.astype(dtype)
+    gpu.set_softening_squared(dtype(np.float32(0.1)) * dtype(np.float32(0.1)))
+    gpu.set_pair_plan_override(plan[0], plan[1], plan[2], 256 if any(plan) else 0)
+    try:
+        need = ctypes.c_size_t(0)
+        gpu.check((lib.nb_workspace_bytes_f32 if f32 else lib.nb_workspace_bytes_f64)(n, gpu.NB_MODE_FAST, ctypes.byref(need)))
+        assert need.value > 0
+        bufs = [gpu.DeviceBuffer(pos0.nbytes) for _ in range(3)]
+        work = gpu.DeviceBuffer(need.value)
+        step = lib.nb_integrate_ws_f32 if f32 else lib.nb_integrate_ws_f64
+        out = []
+        for fill in (0x00, 0xFF, 0x7F):  # zeros; NaN; NaN again (0x7f7f7f7f is a large finite fp32 -- as wrong as any when added)
+            bufs[0].upload(pos0), bufs[2].upload(vel0)
+            gpu.check(lib.nb_memset(work.ptr, fill, need.value, None), "nb_memset")
+            for k in range(2):
+                gpu.check(step(bufs[1 - k].ptr, bufs[k].ptr, bufs[2].ptr, dtype(np.float32(0.016)), dtype(1), n, 256, gpu.NB_MODE_FAST, work.ptr, need.value, None), "nb_integrate_ws")
+            out.append((bufs[0].download(np.zeros_like(pos0)).copy(), bufs[2].download(np.zeros_like(vel0)).copy()))
+        assert np.isfinite(out[1][0]).all() and np.isfinite(out[1][1]).all()
+        for p, v in out[1:]:
+            assert p.tobytes() == out[0][0].tobytes() and v.tobytes() == out[0][1].tobytes()
+        for b in bufs + [work]:
+            b.free()
+    finally:
+        gpu.set_pair_plan_override(0, 0, 0, 0)
