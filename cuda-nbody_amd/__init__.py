@@ -414,7 +414,7 @@ class Event:
 class ShardedRank:
     """One rank of the body-sharded system THROUGH THE C-ABI: nb_comm_init_rank + nb_sharded_step_* (csrc/nbody_comm.hip),
     i.e. the product's own multi-GPU path -- RCCL send/recv rounds of position tiles on the communicator's side stream,
-    the kernel of tile k waiting on round k.  One process (or thread) per GPU; `unique_id` is rank 0's
+    the kernel of tile k waiting on tile k's event.  One process (or thread) per GPU; `unique_id` is rank 0's
     ``comm_unique_id()`` shipped to the other ranks by any means (bench.py: the torch.distributed store over gloo).
 
     The caller owns the arrays, exactly as with nb_integrate_*: `positions` = the two full-size ping-pong arrays (device
