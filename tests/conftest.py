@@ -56,3 +56,25 @@ def golden_steps(g):
 
 def xyz(a):
     return a.reshape(-1, 4)[:, :3]
+
+
+def load_golden_compact(n, tag, oracle):
+    """shell_n{n}_{tag}_compact.npz (tests/golden/make_golden.py): the initial state is drawn by the oracle's randomise_bodies
+    and checked against the fixture's SHA-256; the later states hold x, y, z only (mass 1, velocity .w 0 throughout).
+    Returns a dict with full pos_0 / vel_0 / pos_k [/ vel_k] arrays of 4N values."""
+    import hashlib
+
+    raw = np.load(os.path.join(GOLDEN_DIR, f"shell_n{n}_{tag}_compact.npz"), allow_pickle=False)
+    dtype = np.float32 if tag == "f32" else np.float64
+    pos0, vel0 = oracle.startup_state(n, dtype)
+    assert hashlib.sha256(pos0.tobytes()).digest() == raw["sha256_pos_0"].tobytes(), "start-up positions differ from the fixture's"
+    assert hashlib.sha256(vel0.tobytes()).digest() == raw["sha256_vel_0"].tobytes(), "start-up velocities differ from the fixture's"
+    out = {"pos_0": pos0, "vel_0": vel0}
+    for key in raw.files:
+        if not key.endswith("_xyz"):
+            continue
+        full = np.zeros((n, 4), dtype)
+        full[:, :3] = raw[key]
+        full[:, 3] = 1 if key.startswith("pos_") else 0
+        out[key[:-4]] = full.reshape(-1)
+    return out

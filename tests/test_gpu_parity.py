@@ -23,9 +23,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DT = np.float32(0.016)
 
 
-def run_gpu(pkg, pos0, vel0, steps, mode, dt=DT, block_size=256, params=None):
+def run_gpu(pkg, pos0, vel0, steps, mode, dt=DT, block_size=256, params=None, workspace=False):
+    """`workspace=True`: the system owns the scratch memory nb_workspace_bytes_* asks for and steps through nb_integrate_ws_*
+    (FAST then takes the pairwise layout where it applies -- the headline kernel)"""
     n = pos0.size // 4
-    system = pkg.BodySystemHIP(n, block_size, params or pkg.NBodyParams(), pos0.dtype, pos0, vel0, mode=mode)
+    system = pkg.BodySystemHIP(n, block_size, params or pkg.NBodyParams(), pos0.dtype, pos0, vel0, mode=mode, workspace=workspace)
     for _ in range(steps):
         system.update(pos0.dtype.type(dt))
     out = system.get_position().copy(), system.get_velocity().copy()
@@ -431,7 +433,7 @@ def test_library_leaves_the_libc_rand_stream_alone(gpu, oracle):
 def test_full_size_strict_bitwise_on_a_sample(gpu, O, n, dtype):
     """BASELINE sizes (65 536 / 262 144 / 1 048 576 bodies fp32, 262 144 fp64): one STRICT step on the GPU, then
     2 048 sampled bodies (first / middle / last blocks) against the CPU path's arithmetic -- 0 ulp -- and the FAST
-    step against the STRICT one on ALL bodies."""
+    step, in both layouts (one-sided, and pairwise through nb_integrate_ws_*), against the STRICT one on ALL bodies."""
     omp = O.Oracle(openmp=True)
     omp.set_num_threads(min(16, os.cpu_count() or 1))
     pos0, vel0 = omp.startup_state(n, dtype)
@@ -442,30 +444,36 @@ def test_full_size_strict_bitwise_on_a_sample(gpu, O, n, dtype):
         want_p, want_v = omp.update_subset(pos0, vel0, i0, ni, DT)
         assert strict_pos[4 * i0:4 * (i0 + ni)].tobytes() == want_p.tobytes(), (n, i0)
         assert strict_vel[4 * i0:4 * (i0 + ni)].tobytes() == want_v.tobytes(), (n, i0)
-    fast_pos, fast_vel = run_gpu(gpu, pos0, vel0, 1, gpu.NB_MODE_FAST)
-    if n > 262144:
-        # At 1 Mi bodies the CPU path's own sequential fp32 sum over 1 Mi terms is the inaccurate side (it is off from an
-        # fp64 direct sum by up to ~6e-3), so FAST is held to the fp64 direct sum instead, on sampled bodies, through the
-        # accelerations themselves (nb_integrate_shard_* without FINALIZE).  Stated tolerance: 1e-5 relative (measured
-        # max 2e-6; the 5e-6 bar of test_fast_force_error_every_geometry is for N = 3 000).
-        assert dtype == np.float32
-        gpu.set_softening_squared(np.float32(0.1) * np.float32(0.1))
-        acc = gpu_accel(gpu, pos0, np.float32, 0, n, 0, n, gpu.NB_MODE_FAST).reshape(n, 4)
-        sample = np.arange(0, n, n // 64)[:64]
-        ref = np.concatenate([omp.accel_f64(pos0, int(i), 1) for i in sample])
-        err = np.linalg.norm(acc[sample, :3] - ref, axis=1) / np.linalg.norm(ref, axis=1)
-        assert err.max() < 1e-5, err.max()
-        # and the integrated step is that acceleration: v1 = (v0 + a dt) damping, p1 = p0 + v1 dt
-        v1 = xyz(vel0)[sample].astype(np.float64) + ref * float(DT)
-        scale = np.abs(v1).max()  # |a dt| ~ |v1| here: the force tolerance carries over to the step, relative to that scale
-        np.testing.assert_allclose(xyz(fast_vel)[sample], v1, rtol=0, atol=2e-5 * scale)
-        np.testing.assert_allclose(xyz(fast_pos)[sample], xyz(pos0)[sample].astype(np.float64) + v1 * float(DT), rtol=0, atol=2e-5 * scale * float(DT) + 1e-6)
-        return
-    # fp32: the gap is dominated by the CPU path's own sequential fp32 summation over N terms (error ~ sqrt(N) ulp:
-    # 1.5e-5 measured at 262 144 bodies), not by the FAST kernel, whose split sums are the more accurate ones
-    # (test_full_size_properties_fp32 holds FAST to an fp64 direct sum).
-    tol = 6e-8 * np.sqrt(n) if dtype == np.float32 else 1e-13
-    assert rel_err(fast_pos, strict_pos).max() < tol
+    # FAST both ways: the one-sided kernel (nb_integrate_*) and the pairwise layout (nb_integrate_ws_* with a workspace: the
+    # kernel the bench number comes from), each against the STRICT step on ALL bodies
+    for workspace in (False, True):
+        if workspace:
+            assert gpu.pair_plan(n, dtype).applies == 1
+        fast_pos, fast_vel = run_gpu(gpu, pos0, vel0, 1, gpu.NB_MODE_FAST, workspace=workspace)
+        if n > 262144:
+            # At 1 Mi bodies the CPU path's own sequential fp32 sum over 1 Mi terms is the inaccurate side (it is off from an
+            # fp64 direct sum by up to ~6e-3), so FAST is held to the fp64 direct sum instead, on sampled bodies: the
+            # acceleration a step applied is (v1 - v0) / dt for the one-sided kernel's shard form and both layouts' steps.
+            # Stated tolerance: 1e-5 relative (measured max 2e-6; the 5e-6 bar of test_fast_force_error_every_geometry is for N = 3 000).
+            assert dtype == np.float32
+            sample = np.arange(0, n, n // 64)[:64]
+            ref = np.concatenate([omp.accel_f64(pos0, int(i), 1) for i in sample])
+            if not workspace:
+                gpu.set_softening_squared(np.float32(0.1) * np.float32(0.1))
+                acc = gpu_accel(gpu, pos0, np.float32, 0, n, 0, n, gpu.NB_MODE_FAST).reshape(n, 4)
+                err = np.linalg.norm(acc[sample, :3] - ref, axis=1) / np.linalg.norm(ref, axis=1)
+                assert err.max() < 1e-5, err.max()
+            # and the integrated step is that acceleration: v1 = (v0 + a dt) damping, p1 = p0 + v1 dt
+            v1 = xyz(vel0)[sample].astype(np.float64) + ref * float(DT)
+            scale = np.abs(v1).max()  # |a dt| ~ |v1| here: the force tolerance carries over to the step, relative to that scale
+            np.testing.assert_allclose(xyz(fast_vel)[sample], v1, rtol=0, atol=2e-5 * scale)
+            np.testing.assert_allclose(xyz(fast_pos)[sample], xyz(pos0)[sample].astype(np.float64) + v1 * float(DT), rtol=0, atol=2e-5 * scale * float(DT) + 1e-6)
+            continue
+        # fp32: the gap is dominated by the CPU path's own sequential fp32 summation over N terms (error ~ sqrt(N) ulp:
+        # 1.5e-5 measured at 262 144 bodies), not by the FAST kernels, whose split sums are the more accurate ones
+        # (test_full_size_properties_fp32 holds FAST to an fp64 direct sum).
+        tol = 6e-8 * np.sqrt(n) if dtype == np.float32 else 1e-13
+        assert rel_err(fast_pos, strict_pos).max() < tol, workspace
     del dt, strict_vel
 
 

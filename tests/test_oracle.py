@@ -3,7 +3,7 @@ against the committed golden vectors, against an independent numpy restatement, 
 import numpy as np
 import pytest
 
-from conftest import golden_steps, load_golden
+from conftest import golden_steps, load_golden, load_golden_compact
 
 DT = np.float32(0.016)
 
@@ -45,6 +45,21 @@ def test_oracle_reproduces_golden(oracle, n, tag, dtype):
         done = s
         assert pos.tobytes() == g[f"pos_{s}"].tobytes(), f"positions differ at step {s}"
         assert vel.tobytes() == g[f"vel_{s}"].tobytes(), f"velocities differ at step {s}"
+
+
+@pytest.mark.parametrize("tag,dtype", [("f32", np.float32), ("f64", np.float64)])
+def test_oracle_reproduces_compact_golden_16384(oracle, tag, dtype):
+    """The fixture of a system large enough for the pairwise layout to apply by default (x, y, z of later states only;
+    start-up state by digest)."""
+    n = 16384
+    g = load_golden_compact(n, tag, oracle)
+    pos, vel = g["pos_0"].copy(), g["vel_0"].copy()
+    oracle.update(pos, vel, DT, steps=1)
+    assert pos.tobytes() == g["pos_1"].tobytes()
+    oracle.update(pos, vel, DT, steps=9)
+    assert pos.tobytes() == g["pos_10"].tobytes()
+    if "vel_10" in g:
+        assert vel.tobytes() == g["vel_10"].tobytes()
 
 
 def test_shell_geometry(oracle):
