@@ -244,6 +244,49 @@ def test_pairwise_inner_loops_keep_their_instruction_mix():
     assert int(re.search(r"; NumVgprs: (\d+)", tail).group(1)) <= 128
 
 
+def test_pairwise_headline_kernels_register_budget():
+    """The register budget of the two kernels the headline numbers come from -- pair_forces<float, 4, 8> (262 144 bodies fp32)
+    and pair_forces<double, 4, 16> (fp64): exactly 128 VGPRs and occupancy 4 (amdgpu_waves_per_eu(4, 4) honoured: two 512-thread
+    workgroups, or one of 1 024 threads, per CU), no AGPRs, no SGPR spills, and the VGPR spills that the per-tile prologue and
+    epilogue carry (53 / 42 registers today, 152 / 124 B of scratch per lane) neither grow nor reach the rotation loops: not one
+    scratch_* instruction between a depth-2 loop header and its back-edge, in any of the four loops of either kernel.  Today
+    the spills cost ~30 scratch accesses per 4 700-instruction tile; one compiler upgrade could move them into the loop."""
+    import subprocess
+
+    csrc = os.path.join(ROOT, "cuda-nbody_amd", "csrc")
+    subprocess.run(["make", "-s", "-C", csrc, "asm"], check=True, capture_output=True)
+    text = open(os.path.join(csrc, "nbody_pair.s")).read()
+    lines = text.split("\n")
+    for template, spill_limit, scratch_limit in (("IfLi4ELi8E", 53, 152), ("IdLi4ELi16E", 42, 124)):
+        start = next(i for i, l in enumerate(lines) if re.match(r"_ZN2nb\S*pair_forces%sE\S*:" % template, l))
+        end = next(i for i in range(start, len(lines)) if lines[i].startswith(".Lfunc_end"))
+        name = lines[start].split(":")[0]
+        loops = 0
+        for i in range(start, end):
+            if "Inner Loop Header: Depth=2" not in lines[i]:
+                continue
+            label = lines[i - 1].split(":")[0].strip()
+            stop = next(k for k in range(i, end) if "s_cbranch" in lines[k] and label in lines[k])
+            body = [l.strip() for l in lines[i + 1:stop] if l.strip() and not l.strip().startswith(";")]
+            assert not any(l.startswith(("scratch_", "buffer_load", "buffer_store")) for l in body), (template, label)
+            assert sum(1 for l in body if l.startswith("v_mov_b32_dpp") and "wave_ror:1" in l) > 0, (template, label)  # (it IS a rotation loop)
+            loops += 1
+        assert loops == 4, (template, loops)
+        # the tile prologue / epilogue may touch scratch; count what the whole kernel holds so that growth shows
+        scratch_ops = sum(1 for l in lines[start:end] if l.strip().startswith("scratch_"))
+        assert scratch_ops <= 140, (template, scratch_ops)
+        tail = "\n".join(lines[end:end + 60])
+        assert int(re.search(r"; NumVgprs: (\d+)", tail).group(1)) == 128, template
+        assert int(re.search(r"; NumAgprs: (\d+)", tail).group(1)) == 0, template
+        assert int(re.search(r"; Occupancy: (\d+)", tail).group(1)) == 4, template
+        assert int(re.search(r"; ScratchSize: (\d+)", tail).group(1)) <= scratch_limit, template
+        meta = re.search(r"  - \.agpr_count:(?:(?!  - \.agpr_count:).)*?\.name: +%s\n.*?\.wavefront_size: +\d+" % re.escape(name), text, re.S).group(0)
+        field = lambda key: int(re.search(r"\.%s: +(\d+)" % key, meta).group(1))  # noqa: E731
+        assert field("vgpr_count") == 128 and field("sgpr_spill_count") == 0, template
+        assert field("vgpr_spill_count") <= spill_limit, (template, field("vgpr_spill_count"))
+        assert field("private_segment_fixed_size") <= scratch_limit, template
+
+
 def test_pair_shard_plan_without_gpu(pkg):
     """The multi-GPU pairwise plan is host logic too: nb_emulate_pair_rank_* with no workspace only answers how many bytes a
     rank of a G-rank step needs -- (self sets + diagonal slots + two rectangle regions + send + receive planes) x 3 x the padded
