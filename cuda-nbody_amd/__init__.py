@@ -119,7 +119,6 @@ SIGNATURES = {
     "nb_integrate_ws_f64": (_ci, [_vp, _vp, _vp, _cd, _cd, _cu, _ci, _ci, _vp, _sz, _vp]),
     "nb_pair_plan_f32": (_ci, [_cu, _P(PairPlan)]),
     "nb_pair_plan_f64": (_ci, [_cu, _P(PairPlan)]),
-    "nb_set_pair_plan_override": (_ci, [_ci, _ci, _ci, _ci]),
     "nb_graph_launch": (_ci, [_vp, _vp]),
     "nb_graph_destroy": (_ci, [_vp]),
     "nb_comm_unique_id": (_ci, [_vp]),
@@ -128,11 +127,12 @@ SIGNATURES = {
     "nb_comm_destroy": (_ci, [_vp]),
     "nb_comm_info": (_ci, [_vp, _P(_ci), _P(_ci), _P(_ci)]),
     "nb_comm_set_workspace": (_ci, [_vp, _vp, _sz]),
+    "nb_comm_layout_f32": (_ci, [_vp, _cu, _ci, _P(_ci)]),
+    "nb_comm_layout_f64": (_ci, [_vp, _cu, _ci, _P(_ci)]),
+    "nb_comm_set_exchange_grouping": (_ci, [_vp, _ci]),
+    "nb_comm_get_exchange_grouping": (_ci, [_vp, _P(_ci)]),
     "nb_comm_workspace_bytes_f32": (_ci, [_vp, _cu, _ci, _P(_sz)]),
     "nb_comm_workspace_bytes_f64": (_ci, [_vp, _cu, _ci, _P(_sz)]),
-    "nb_comm_set_pair_min_slice": (_ci, [_ci]),
-    "nb_emulate_pair_rank_f32": (_ci, [_vp, _vp, _vp, _vp, _P(_sz), _cu, _ci, _ci, _cf, _cf, _vp]),
-    "nb_emulate_pair_rank_f64": (_ci, [_vp, _vp, _vp, _vp, _P(_sz), _cu, _ci, _ci, _cd, _cd, _vp]),
     "nb_sharded_step_f32": (_ci, [_vp, _vp, _vp, _vp, _vp, _cu, _cf, _cf, _ci, _ci, _vp]),
     "nb_sharded_step_f64": (_ci, [_vp, _vp, _vp, _vp, _vp, _cu, _cd, _cd, _ci, _ci, _vp]),
     "nb_sharded_step_all_f32": (_ci, [_P(_vp), _ci, _P(_vp), _P(_vp), _P(_vp), _P(_vp), _cu, _cf, _cf, _ci, _ci, _P(_vp)]),
@@ -145,7 +145,17 @@ SIGNATURES = {
     "nb_exchange_wait_all": (_ci, [_vp, _vp]),
     "nb_plan_f32": (_ci, [_cu, _cu, _P(LaunchPlan)]),
     "nb_plan_f64": (_ci, [_cu, _cu, _P(LaunchPlan)]),
+}
+
+# include/nbody_hip_tuning.h: process-global tuning / test hooks, not part of the drop-in boundary
+TUNING_SIGNATURES = {
     "nb_set_plan_override": (_ci, [_ci, _ci, _ci]),
+    "nb_set_pair_plan_override": (_ci, [_ci, _ci, _ci, _ci]),
+    "nb_comm_set_pair_min_slice": (_ci, [_ci]),
+    "nb_emulate_pair_rank_f32": (_ci, [_vp, _vp, _vp, _vp, _P(_sz), _cu, _ci, _ci, _cf, _cf, _vp]),
+    "nb_emulate_pair_rank_f64": (_ci, [_vp, _vp, _vp, _vp, _P(_sz), _cu, _ci, _ci, _cd, _cd, _vp]),
+    "nb_set_pair_probe_event": (_ci, [_vp]),
+    "nb_set_memory_budget": (_ci, [_sz]),
     "nb_lds_optin_count": (_ci, [_P(_ci)]),
 }
 
@@ -160,7 +170,7 @@ def lib() -> ctypes.CDLL:
             raise FileNotFoundError(f"{LIB_PATH} not found: build it with `make -C {os.path.join(HERE, 'csrc')}` "
                                     "(or __graft_entry__.build()); there is no CPU fallback")
         handle = ctypes.CDLL(LIB_PATH)
-        for name, (restype, argtypes) in SIGNATURES.items():
+        for name, (restype, argtypes) in {**SIGNATURES, **TUNING_SIGNATURES}.items():
             fn = getattr(handle, name)  # AttributeError if the symbol is not exported
             fn.restype, fn.argtypes = restype, argtypes
         _lib = handle
@@ -446,8 +456,33 @@ class ShardedRank:
         return need.value
 
     def set_workspace(self, workspace, nbytes: int) -> None:
-        """nb_comm_set_workspace: lend this rank the scratch memory of workspace_bytes() (used by a world of one)."""
+        """nb_comm_set_workspace: lend this rank the scratch memory of workspace_bytes().  With several ranks this is a COLLECTIVE
+        over the communicator (every rank calls it; a rank without memory passes None, 0): the ranks learn the smallest amount
+        lent anywhere, and the step is pairwise only if that suffices -- on every rank or on none."""
         check(lib().nb_comm_set_workspace(self.comm, workspace, nbytes), "nb_comm_set_workspace")
+
+    def pairwise(self) -> bool:
+        """nb_comm_layout_*: does nb_sharded_step_* of this communicator evaluate every pair once (the same answer on every rank)?"""
+        flag = _ci(0)
+        fn = lib().nb_comm_layout_f32 if self.dtype == np.float32 else lib().nb_comm_layout_f64
+        check(fn(self.comm, self.n, self.mode, ctypes.byref(flag)), "nb_comm_layout")
+        return bool(flag.value)
+
+    def set_exchange_grouping(self, one_group: bool) -> None:
+        """nb_comm_set_exchange_grouping: all G-1 position rounds of a step in one RCCL group (True, the default) or a group and
+        an event per round (False); every rank must choose the same."""
+        check(lib().nb_comm_set_exchange_grouping(self.comm, 1 if one_group else 0), "nb_comm_set_exchange_grouping")
+
+    def exchange_grouping(self) -> bool:
+        flag = _ci(0)
+        check(lib().nb_comm_get_exchange_grouping(self.comm, ctypes.byref(flag)), "nb_comm_get_exchange_grouping")
+        return bool(flag.value)
+
+    def info(self) -> dict:
+        """nb_comm_info: what the communicator itself says about this rank"""
+        r, w, d = _ci(-1), _ci(-1), _ci(-1)
+        check(lib().nb_comm_info(self.comm, ctypes.byref(r), ctypes.byref(w), ctypes.byref(d)), "nb_comm_info")
+        return {"rank": r.value, "world": w.value, "device": d.value}
 
     def update(self, delta_time, damping) -> None:
         """pos[1-read][own slice], vel[own slice] <- one step from pos[read]; then the tiles of pos[1-read] start moving."""

@@ -4,6 +4,7 @@
 // HIP runtime calls the reference makes through CUDA/thrust/cuda-api-wrappers.  No allocation, no
 // synchronisation and no host<->device traffic inside the integrate entry points (graph-capturable).
 #include "../../include/nbody_hip.h"
+#include "../../include/nbody_hip_tuning.h"
 
 #include "nbody_kernels.h"
 #include "rand_stream_guard.h"
@@ -24,6 +25,7 @@ std::atomic<double> g_softening_sq_f64{0.0};
 
 std::atomic<int> g_ovr_i{0}, g_ovr_s{0}, g_ovr_tile{0};
 std::atomic<int> g_pair_r{0}, g_pair_s{0}, g_pair_c{0}, g_pair_min{0};  // overrides of the pairwise plan (0 = automatic)
+std::atomic<void*> g_pair_probe{nullptr};                               // nb_set_pair_probe_event
 
 
 // The HIP runtime sets parts of itself up lazily, on the first call that needs them (the null stream, the first event,
@@ -31,6 +33,7 @@ std::atomic<int> g_pair_r{0}, g_pair_s{0}, g_pair_c{0}, g_pair_min{0};  // overr
 // device, under the guard, so that the launch path (kernel launches, event records, stream waits) can stay lock-free
 // without ever being the call that triggers a lazy initialisation.
 std::atomic<size_t> g_total_memory[64] = {};  // per device, filled by the one-time warm-up below (0: unknown)
+std::atomic<size_t> g_memory_budget{0};       // nb_set_memory_budget: what to assume instead (0: the device's own figure)
 
 int current_device_ready() {
     static std::atomic<int> cu_count[64] = {};
@@ -131,12 +134,8 @@ template <typename T> bool pair_applies(unsigned n, int mode, nb::PairPlan* plan
     *plan = nb::plan_pair<T>(n, cu_count_cached(), g_pair_r.load(), g_pair_s.load(), g_pair_c.load());
     // The workspace grows with N^2 (12.9 GB at 1 Mi bodies, 206 GB at 4 Mi): past a third of the device's memory the layout
     // does not apply (nb_workspace_bytes_* says 0 and the step is the one-sided kernel).
-    int dev = 0;
-    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
-        const size_t total_bytes = g_total_memory[dev].load();
-        if (total_bytes != 0 && plan->workspace_bytes > total_bytes / 3) return false;
-    }
-    return true;
+    const size_t total_bytes = nb::device_memory_budget();
+    return total_bytes == 0 || plan->workspace_bytes <= total_bytes / 3;
 }
 
 // nb_integrate_ws_*: the whole system in one step, FAST, with a caller-owned workspace -> the pairwise layout when it
@@ -147,11 +146,15 @@ int integrate_ws(T* new_pos, const T* old_pos, T* vel, T dt, T damping, T eps2, 
     if (workspace != nullptr && n != 0 && pair_applies<T>(n, mode, &plan) && workspace_bytes >= plan.workspace_bytes) {
         if (!new_pos || !old_pos || !vel || new_pos == old_pos) return NB_ERR_INVALID_ARGUMENT;
         if (!aligned_vec4<T>(old_pos) || !aligned_vec4<T>(new_pos) || !aligned_vec4<T>(vel) || (reinterpret_cast<std::uintptr_t>(workspace) % sizeof(T)) != 0) return NB_ERR_INVALID_ARGUMENT;
-        {   // nothing the launch writes may overlap the bodies it reads (old_pos is read-only for the whole launch)
+        {   // nothing the launch writes may overlap the bodies it reads (old_pos is read-only for the whole launch), and the four
+            // things it writes -- new positions, velocities, and the workspace in between -- are four separate ranges
             const auto lo = [](const void* q) { return reinterpret_cast<std::uintptr_t>(q); };
             const std::uintptr_t bytes = static_cast<std::uintptr_t>(n) * 4 * sizeof(T);
-            auto overlaps = [&](const void* q, std::uintptr_t len) { return lo(q) < lo(old_pos) + bytes && lo(old_pos) < lo(q) + len; };
-            if (overlaps(new_pos, bytes) || overlaps(vel, bytes) || overlaps(workspace, plan.workspace_bytes)) return NB_ERR_INVALID_ARGUMENT;
+            auto overlap = [&](const void* a, std::uintptr_t a_len, const void* b, std::uintptr_t b_len) { return lo(a) < lo(b) + b_len && lo(b) < lo(a) + a_len; };
+            if (overlap(new_pos, bytes, old_pos, bytes) || overlap(vel, bytes, old_pos, bytes) || overlap(new_pos, bytes, vel, bytes)) return NB_ERR_INVALID_ARGUMENT;
+            for (const void* body_array : {static_cast<const void*>(old_pos), static_cast<const void*>(new_pos), static_cast<const void*>(vel)}) {
+                if (overlap(workspace, plan.workspace_bytes, body_array, bytes)) return NB_ERR_INVALID_ARGUMENT;
+            }
         }
         nb::Shard<T> s{};
         s.new_pos = new_pos, s.old_pos = old_pos, s.vel = vel, s.acc = nullptr;
@@ -249,6 +252,14 @@ template <typename T> int plan_query(unsigned i_count, unsigned j_count, nb_laun
 }  // namespace
 
 namespace nb {
+size_t device_memory_budget() {
+    if (const size_t forced = g_memory_budget.load(); forced != 0) return forced;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    (void)current_device_ready();
+    return g_total_memory[dev].load();
+}
+hipEvent_t pair_probe_event() { return static_cast<hipEvent_t>(g_pair_probe.load(std::memory_order_relaxed)); }
 void pair_plan_overrides(int* vectors_per_lane, int* waves, int* splits) {
     *vectors_per_lane = g_pair_r.load(), *waves = g_pair_s.load(), *splits = g_pair_c.load();
 }
@@ -476,6 +487,16 @@ int nb_set_pair_plan_override(int vectors_per_lane, int waves_per_block, int spl
     g_pair_s.store(waves_per_block);
     g_pair_c.store(splits);
     g_pair_min.store(min_bodies);
+    return 0;
+}
+
+int nb_set_memory_budget(size_t bytes) {
+    g_memory_budget.store(bytes);
+    return 0;
+}
+
+int nb_set_pair_probe_event(nb_event_t event) {
+    g_pair_probe.store(event);
     return 0;
 }
 

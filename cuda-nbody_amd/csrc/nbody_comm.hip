@@ -20,6 +20,7 @@
 // RCCL is dlopen'ed on first use (librccl.so.1): a single-GPU run never pays for loading it, and inside a torch process
 // the copy torch already loaded is the one that gets bound (same SONAME).
 #include "../../include/nbody_hip.h"
+#include "../../include/nbody_hip_tuning.h"
 
 #include "nbody_kernels.h"
 #include "rand_stream_guard.h"
@@ -28,6 +29,7 @@
 
 #include <dlfcn.h>
 
+#include <algorithm>
 #include <atomic>
 #include <cstdlib>
 #include <cstring>
@@ -111,6 +113,9 @@ struct Comm {
     const void* in_flight = nullptr;       // the array whose tiles are (or were last) being exchanged
     void*       workspace = nullptr;       // caller-owned scratch memory (nb_comm_set_workspace)
     size_t      workspace_bytes = 0;
+    size_t      agreed_bytes    = 0;       // one process per rank: the SMALLEST amount any rank of the communicator was lent (set_workspace's exchange)
+    bool        one_group       = true;    // nb_comm_set_exchange_grouping: all G-1 position rounds of a step in one RCCL group
+    unsigned long long* notes   = nullptr; // [world][kNoteWords] device memory of the communicator: what set_workspace's ranks tell each other
     hipStream_t aux       = nullptr;       // pairwise step: every other rectangle runs here, so that the tails and launch gaps of
     hipEvent_t  aux_begin = nullptr;       // one stream's kernels are filled by the other's (events: aux may start / aux is done)
     hipEvent_t  aux_done  = nullptr;
@@ -118,6 +123,13 @@ struct Comm {
     std::vector<hipEvent_t> react_arrived; // [world/2 + 1] ... "round s of the reaction exchange is done" (exchange stream)
     std::vector<Comm*> group;              // all local ranks of this communicator (just {this} with one process per GPU)
 };
+
+constexpr int kNoteWords = 8;  // {workspace bytes, min slice, pair plan overrides R S C, spare}
+
+bool default_one_group() {  // NBODY_EXCHANGE_ONE_GROUP=0 flips the default of nb_comm_set_exchange_grouping
+    const char* v = std::getenv("NBODY_EXCHANGE_ONE_GROUP");
+    return v == nullptr || v[0] != '0';
+}
 
 inline Comm* as_comm(nb_comm_t c) { return static_cast<Comm*>(c); }
 inline int   nccl_status(int r) { return r == 0 ? 0 : NB_ERR_RCCL_BASE + r; }
@@ -150,6 +162,11 @@ int make_resources(Comm* c) {
     if (err == hipSuccess) err = hipEventCreateWithFlags(&c->aux_begin, hipEventDisableTiming);
     if (err == hipSuccess) err = hipEventCreateWithFlags(&c->aux_done, hipEventDisableTiming);
     if (err != hipSuccess) return static_cast<int>(err);
+    c->one_group = default_one_group();
+    if (c->world > 1) {
+        err = hipMalloc(reinterpret_cast<void**>(&c->notes), static_cast<size_t>(c->world) * kNoteWords * sizeof(unsigned long long));
+        if (err != hipSuccess) return static_cast<int>(err);
+    }
     c->arrived.assign(static_cast<size_t>(c->world), nullptr);
     c->react_ready.assign(static_cast<size_t>(c->world / 2 + 1), nullptr);
     c->react_arrived.assign(static_cast<size_t>(c->world / 2 + 1), nullptr);
@@ -167,6 +184,7 @@ void free_resources(Comm* c) {
     for (auto* events : {&c->arrived, &c->react_ready, &c->react_arrived})
         for (auto e : *events)
             if (e) (void)hipEventDestroy(e);
+    if (c->notes) (void)hipFree(c->notes);
     if (c->ready) (void)hipEventDestroy(c->ready);
     if (c->aux_begin) (void)hipEventDestroy(c->aux_begin);
     if (c->aux_done) (void)hipEventDestroy(c->aux_done);
@@ -209,12 +227,12 @@ int exchange_tiles(const std::vector<Comm*>& locals, void* const* positions, uns
     // All G-1 rounds of a step go out as ONE RCCL group (one RCCL kernel per step, every xGMI link busy at once, all tiles arriving
     // together): a force kernel holds every CU for its whole run (two 512-thread workgroups per CU at 128 VGPRs), so an RCCL
     // kernel that becomes ready in the middle of one waits for a workgroup slot -- a wait that G-1 separate rounds could pay G-1
-    // times per step.  NBODY_EXCHANGE_ONE_GROUP=0 issues a group per round instead (tile k's event then fires with round k):
-    // the A/B knob for the day this runs on several GPUs.  Same data, same bits either way (tested with the transport double).
-    static const bool one_group = [] {
-        const char* v = std::getenv("NBODY_EXCHANGE_ONE_GROUP");
-        return v == nullptr || v[0] != '0';
-    }();
+    // times per step.  nb_comm_set_exchange_grouping(comm, 0) issues a group per round instead (tile k's event then fires with
+    // round k): a per-communicator setting, so that one job can time both.  Same data, same bits either way (tested with the
+    // transport double); which one is faster has not been measured on several GPUs.
+    const bool one_group = locals.front()->one_group;
+    for (Comm* c : locals)
+        if (c->one_group != one_group) return NB_ERR_INVALID_ARGUMENT;  // the local ranks of a group must agree (all ranks must)
     int rc = one_group ? lib->GroupStart() : 0;
     for (int s = 1; s < G && rc == 0; ++s) {
         if (!one_group) rc = lib->GroupStart();
@@ -323,7 +341,10 @@ template <typename T> PairShard plan_pair_shard(unsigned num_bodies, int G, int 
     p.send_at    = p.react_r_at + 2 * p.blocks * plane3;  // (two regions: the rectangles alternate between two streams)
     p.recv_at    = p.send_at + p.H * plane3;
     p.elements   = p.recv_at + p.H * plane3;
-    p.applies    = true;
+    // as on one GPU: a workspace beyond a third of the device's memory is never asked for (it grows with the square of the slice:
+    // ~16 GB per rank at 1 Mi bodies over 2 ranks) -- the step is then the one-sided tile schedule
+    const size_t budget = nb::device_memory_budget();
+    p.applies           = budget == 0 || p.elements * sizeof(T) <= budget / 3;
     return p;
 }
 
@@ -449,6 +470,29 @@ int pair_sharded_step(const std::vector<Comm*>& locals, const PairShard& plan, T
     return 0;
 }
 
+// What every rank of the communicator is known to have been lent: one process driving all ranks sees them all; one process
+// per rank knows it from nb_comm_set_workspace's exchange (0 before that: the one-sided schedule).
+size_t lent_everywhere(const std::vector<Comm*>& locals) {
+    const Comm* first = locals.front();
+    if (static_cast<int>(first->group.size()) == first->world) {
+        size_t least = ~size_t{0};
+        for (const Comm* c : first->group) least = std::min(least, c->workspace != nullptr ? c->workspace_bytes : size_t{0});
+        return least;
+    }
+    size_t least = ~size_t{0};
+    for (const Comm* c : locals) least = std::min(least, c->workspace != nullptr ? std::min(c->agreed_bytes, c->workspace_bytes) : size_t{0});
+    return least;
+}
+
+template <typename T> bool step_is_pairwise(const std::vector<Comm*>& locals, unsigned num_bodies, int mode, PairShard* plan_out) {
+    const int G = locals.front()->world;
+    if (G < 2 || mode != NB_MODE_FAST) return false;
+    const PairShard plan = plan_pair_shard<T>(num_bodies, G, g_pair_shard_min.load());
+    if (!plan.applies || lent_everywhere(locals) < plan.elements * sizeof(T)) return false;
+    if (plan_out != nullptr) *plan_out = plan;
+    return true;
+}
+
 // One step for every local rank: kernels of the own slice and of each tile as it arrives, integrate, start the next exchange.
 template <typename T>
 int sharded_step(nb_comm_t const* comms, int n_local, T* const* new_pos, const T* const* old_pos, T* const* vel, T* const* acc, unsigned num_bodies, T dt, T damping, int block_size, int mode, const nb_stream_t* streams) {
@@ -465,11 +509,9 @@ int sharded_step(nb_comm_t const* comms, int n_local, T* const* new_pos, const T
     if (num_bodies == 0 || num_bodies % static_cast<unsigned>(G)) return NB_ERR_INVALID_ARGUMENT;  // pad with zero-mass bodies (as tipsy.cpp:111-119 does)
     const unsigned ni = num_bodies / static_cast<unsigned>(G);
     bool           done_pairwise = false;
-    if (G > 1 && mode == NB_MODE_FAST) {  // every local rank lent a large enough workspace: pairs once, across the ranks too
-        const PairShard plan = plan_pair_shard<T>(num_bodies, G, g_pair_shard_min.load());
-        bool            all  = plan.applies;
-        for (Comm* c : locals) all = all && c->workspace != nullptr && c->workspace_bytes >= plan.elements * sizeof(T);
-        if (all) {
+    {   // every rank of the COMMUNICATOR lent a large enough workspace (decided identically on every rank): pairs once, across the ranks too
+        PairShard plan;
+        if (step_is_pairwise<T>(locals, num_bodies, mode, &plan)) {
             T eps2 = 0;
             if constexpr (sizeof(T) == 4) {
                 float e = 0;
@@ -480,8 +522,14 @@ int sharded_step(nb_comm_t const* comms, int n_local, T* const* new_pos, const T
                 (void)nb_get_softening_sq_f64(&e);
                 eps2 = e;
             }
-            for (int k = 0; k < n_local; ++k) {  // the same argument rules as nb_integrate_shard_*
+            for (int k = 0; k < n_local; ++k) {  // the same argument rules as nb_integrate_ws_*: four separate ranges
                 if (new_pos[k] == nullptr || old_pos[k] == nullptr || vel[k] == nullptr || new_pos[k] == old_pos[k]) return NB_ERR_INVALID_ARGUMENT;
+                const auto lo = [](const void* q) { return reinterpret_cast<size_t>(q); };
+                const size_t body_bytes = static_cast<size_t>(num_bodies) * 4 * sizeof(T), work_bytes = plan.elements * sizeof(T);
+                const void*  work       = locals[static_cast<size_t>(k)]->workspace;
+                for (const void* body_array : {static_cast<const void*>(old_pos[k]), static_cast<const void*>(new_pos[k]), static_cast<const void*>(vel[k])}) {
+                    if (lo(work) < lo(body_array) + body_bytes && lo(body_array) < lo(work) + work_bytes) return NB_ERR_INVALID_ARGUMENT;
+                }
             }
             const int rc = pair_sharded_step<T>(locals, plan, new_pos, old_pos, vel, num_bodies, dt, damping, eps2, streams);
             if (rc != 0) return rc;
@@ -562,6 +610,18 @@ template <typename T> int emulate_pair_rank(T* new_pos, const T* old_pos, T* vel
     return static_cast<int>(nb::launch_pair_finish<T>(f, s));
 }
 
+template <typename T> int comm_layout(nb_comm_t comm, unsigned num_bodies, int mode, int* pairwise) {
+    Comm* c = as_comm(comm);
+    if (c == nullptr || pairwise == nullptr || num_bodies == 0) return NB_ERR_INVALID_ARGUMENT;
+    if (c->world == 1) {
+        size_t need = 0;
+        const int rc = sizeof(T) == 4 ? nb_workspace_bytes_f32(num_bodies, mode, &need) : nb_workspace_bytes_f64(num_bodies, mode, &need);
+        *pairwise    = (rc == 0 && need != 0 && c->workspace != nullptr && c->workspace_bytes >= need) ? 1 : 0;
+        return rc;
+    }
+    *pairwise = step_is_pairwise<T>(std::vector<Comm*>{c}, num_bodies, mode, nullptr) ? 1 : 0;
+    return 0;
+}
 }  // namespace
 
 extern "C" {
@@ -666,6 +726,63 @@ int nb_comm_set_workspace(nb_comm_t comm, void* workspace, size_t workspace_byte
     if (c == nullptr || (workspace == nullptr && workspace_bytes != 0) || (reinterpret_cast<size_t>(workspace) % sizeof(double)) != 0) return NB_ERR_INVALID_ARGUMENT;
     c->workspace       = workspace;
     c->workspace_bytes = workspace_bytes;
+    c->agreed_bytes    = workspace_bytes;
+    if (c->world == 1 || static_cast<int>(c->group.size()) == c->world) return 0;  // this process sees every rank: nothing to exchange
+    // One process per rank: the layout of a step must be the same on every rank of the communicator, so the ranks tell each other
+    // what they were lent (and the process-global plan overrides their plans depend on): G-1 send/recv rounds of one small note
+    // each on the exchange stream, in one RCCL group; every rank keeps the smallest amount.  A collective: it returns once every
+    // rank of the communicator has called it.
+    c->agreed_bytes = 0;  // (until the exchange below has succeeded: one-sided)
+    Rccl* lib = rccl();
+    if (lib == nullptr || c->notes == nullptr) return NB_ERR_UNSUPPORTED;
+    NB_KEEP_RAND_STREAM;
+    DeviceScope scope(c->device);
+    const int   G = c->world;
+    int         ovr_r = 0, ovr_s = 0, ovr_c = 0;
+    nb::pair_plan_overrides(&ovr_r, &ovr_s, &ovr_c);
+    unsigned long long mine[kNoteWords] = {static_cast<unsigned long long>(workspace_bytes), static_cast<unsigned long long>(g_pair_shard_min.load()), static_cast<unsigned long long>(ovr_r),
+                                           static_cast<unsigned long long>(ovr_s), static_cast<unsigned long long>(ovr_c), 0, 0, 0};
+    auto err = hipMemcpyAsync(c->notes + static_cast<size_t>(c->rank) * kNoteWords, mine, sizeof(mine), hipMemcpyHostToDevice, c->stream);
+    if (err == hipSuccess) err = hipStreamSynchronize(c->stream);  // (`mine` is pageable stack memory: the copy must be over before it goes away)
+    if (err != hipSuccess) return static_cast<int>(err);
+    int rc = lib->GroupStart();
+    for (int s = 1; s < G && rc == 0; ++s) {
+        const int dst = (c->rank - s + G) % G, src = (c->rank + s) % G;
+        rc              = lib->Send(c->notes + static_cast<size_t>(c->rank) * kNoteWords, kNoteWords * 2, ncclFloat32, dst, c->nccl, c->stream);  // (8 bytes = two 4-byte values)
+        if (rc == 0) rc = lib->Recv(c->notes + static_cast<size_t>(src) * kNoteWords, kNoteWords * 2, ncclFloat32, src, c->nccl, c->stream);
+    }
+    const int end = lib->GroupEnd();
+    if (rc == 0) rc = end;
+    if (rc != 0) return nccl_status(rc);
+    std::vector<unsigned long long> all(static_cast<size_t>(G) * kNoteWords);
+    err = hipMemcpyAsync(all.data(), c->notes, all.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream);
+    if (err == hipSuccess) err = hipStreamSynchronize(c->stream);
+    if (err != hipSuccess) return static_cast<int>(err);
+    unsigned long long least = ~0ull;
+    bool               same  = true;
+    for (int r = 0; r < G; ++r) {
+        const unsigned long long* note = all.data() + static_cast<size_t>(r) * kNoteWords;
+        least = std::min(least, note[0]);
+        for (int w = 1; w < 5; ++w) same = same && note[w] == mine[w];
+    }
+    if (!same) return NB_ERR_INVALID_ARGUMENT;  // (every rank sees the same notes, so every rank returns this)
+    c->agreed_bytes = static_cast<size_t>(least);
+    return 0;
+}
+
+int nb_comm_layout_f32(nb_comm_t comm, unsigned num_bodies, int mode, int* pairwise) { return comm_layout<float>(comm, num_bodies, mode, pairwise); }
+int nb_comm_layout_f64(nb_comm_t comm, unsigned num_bodies, int mode, int* pairwise) { return comm_layout<double>(comm, num_bodies, mode, pairwise); }
+
+int nb_comm_set_exchange_grouping(nb_comm_t comm, int one_group) {
+    Comm* c = as_comm(comm);
+    if (c == nullptr || (one_group != 0 && one_group != 1)) return NB_ERR_INVALID_ARGUMENT;
+    c->one_group = one_group != 0;
+    return 0;
+}
+int nb_comm_get_exchange_grouping(nb_comm_t comm, int* one_group) {
+    Comm* c = as_comm(comm);
+    if (c == nullptr || one_group == nullptr) return NB_ERR_INVALID_ARGUMENT;
+    *one_group = c->one_group ? 1 : 0;
     return 0;
 }
 

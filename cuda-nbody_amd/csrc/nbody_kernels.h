@@ -100,6 +100,13 @@ template <typename T> struct FinishArgs {
     T dt, damping;
 };
 
+// total memory of the current device, or what nb_set_memory_budget says instead; 0 = unknown (no device): no guard applies
+size_t device_memory_budget();
+
+// nb_set_pair_probe_event (tuning header): an event recorded between the forces kernel and the finish kernel of a one-GPU pairwise
+// step, so that a benchmark can time the two separately; nullptr = none (defined in nbody_capi.hip)
+hipEvent_t pair_probe_event();
+
 // nb_set_pair_plan_override: 0 = automatic (defined in nbody_capi.hip; the multi-GPU layer honours it for its tiles too)
 void pair_plan_overrides(int* vectors_per_lane, int* waves, int* splits);
 

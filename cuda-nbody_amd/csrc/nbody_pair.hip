@@ -549,6 +549,9 @@ template <typename T> hipError_t launch_pair(const Shard<T>& s, const PairPlan& 
     a.eps2 = s.eps2;
     const PairGeom g{p.vectors_per_lane, p.waves, p.splits};
     if (const auto err = launch_pair_tile<T>(a, g, stream, prepare_only); err != hipSuccess || prepare_only) return err;
+    if (hipEvent_t probe = pair_probe_event(); probe != nullptr) {
+        if (const auto err = hipEventRecord(probe, stream); err != hipSuccess) return err;
+    }
     FinishArgs<T> f{};
     f.old_pos = s.old_pos, f.new_pos = s.new_pos, f.vel = s.vel;
     f.self = a.self, f.react = a.react, f.recv = nullptr, f.extra = nullptr;

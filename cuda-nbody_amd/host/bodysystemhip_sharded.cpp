@@ -2,6 +2,8 @@
 
 #include "integrate_nbody_hip.hpp"
 
+#include <exception>
+
 #include <cassert>
 #include <stdexcept>
 #include <string>
@@ -101,26 +103,35 @@ template <std::floating_point T> auto BodySystemHIPSharded<T>::get_velocity() co
     return host_vel_;
 }
 
-// The library allocates nothing: each shard owns what nb_comm_workspace_bytes_* asks for in the current mode (0 bytes: none).
+// The library allocates nothing: each shard owns what nb_comm_workspace_bytes_* asks for in the current mode (0 bytes: none; the
+// library never asks for more than a third of a device's memory).  The layout of a step belongs to the communicator as a whole,
+// so when the allocation fails on ANY shard, ALL shards lend nothing and the step is the one-sided tile schedule (as
+// BodySystemHIPStored falls back to nb_integrate_* on one GPU).
 template <std::floating_point T> auto BodySystemHIPSharded<T>::ensure_workspaces() -> void {
     const int mode = nbody_hip::use_workspace() ? nbody_hip::integration_mode() : -2;
     if (mode == workspace_mode_) return;
     workspace_mode_ = mode;
-    for (std::size_t g = 0; g < shards_.size(); ++g) {
-        std::size_t need = 0;
-        if (mode >= 0) {
-            if constexpr (std::same_as<T, float>) {
-                hip_check(nb_comm_workspace_bytes_f32(comms_[g], this->nb_bodies_, mode, &need), "nb_comm_workspace_bytes_f32");
-            } else {
-                hip_check(nb_comm_workspace_bytes_f64(comms_[g], this->nb_bodies_, mode, &need), "nb_comm_workspace_bytes_f64");
-            }
+    std::vector<std::size_t> need(shards_.size(), 0);
+    bool                     lend = mode >= 0;
+    for (std::size_t g = 0; g < shards_.size() && lend; ++g) {
+        if constexpr (std::same_as<T, float>) {
+            hip_check(nb_comm_workspace_bytes_f32(comms_[g], this->nb_bodies_, mode, &need[g]), "nb_comm_workspace_bytes_f32");
+        } else {
+            hip_check(nb_comm_workspace_bytes_f64(comms_[g], this->nb_bodies_, mode, &need[g]), "nb_comm_workspace_bytes_f64");
         }
         CurrentDevice scope(shards_[g].device);
-        if (need > shards_[g].workspace.size()) {
+        if (need[g] > shards_[g].workspace.size()) {
             hip_check(nb_device_synchronize(), "nb_device_synchronize");  // nothing may still be using the old one
-            shards_[g].workspace = DeviceArray<unsigned char>(need);
+            try {
+                shards_[g].workspace = DeviceArray<unsigned char>(need[g]);
+            } catch (const std::exception&) {
+                lend = false;  // no memory for it on this device: nobody steps pairwise
+            }
         }
-        hip_check(nb_comm_set_workspace(comms_[g], need != 0 ? shards_[g].workspace.data() : nullptr, need), "nb_comm_set_workspace");
+    }
+    for (std::size_t g = 0; g < shards_.size(); ++g) {
+        const bool have = lend && need[g] != 0;
+        hip_check(nb_comm_set_workspace(comms_[g], have ? shards_[g].workspace.data() : nullptr, have ? need[g] : 0), "nb_comm_set_workspace");
     }
 }
 

@@ -138,7 +138,10 @@ NB_API int nb_integrate_f64(double* new_positions, const double* old_positions, 
  *  reference's -- the library allocates nothing: the caller asks nb_workspace_bytes_*(N, mode) once (0 = this N / mode has
  *  no use for a workspace), allocates that much device memory, and passes it to every step.  The contents need not be
  *  preserved or cleared between steps, and one workspace serves any number of systems of that size on one stream.
- *  With workspace == NULL, too few bytes, STRICT mode or a system too small to gain, nb_integrate_ws_* IS nb_integrate_*. */
+ *  With workspace == NULL, too few bytes, STRICT mode or a system too small to gain, nb_integrate_ws_* IS nb_integrate_*.
+ *  Which of the two a call takes is a function of (num_bodies, mode, workspace_bytes) alone: nb_pair_plan_* says whether the
+ *  pairwise layout applies to this N and how many bytes it needs (applies == 1 && workspace_bytes >= plan.workspace_bytes).
+ *  The workspace must not overlap any of the three body arrays (NB_ERR_INVALID_ARGUMENT). */
 NB_API int nb_workspace_bytes_f32(unsigned num_bodies, int mode, size_t* bytes);
 NB_API int nb_workspace_bytes_f64(unsigned num_bodies, int mode, size_t* bytes);
 NB_API int nb_integrate_ws_f32(float* new_positions, const float* old_positions, float* velocities,
@@ -172,7 +175,7 @@ NB_API int nb_integrate_shard_f64(double* new_positions, const double* old_posit
  *  as tipsy.cpp:111-119 does -- i.e. their velocities and their slice of every new position array; all arrays stay
  *  full-size.  The one exchange step is the all-gather of the new positions, issued as G-1 position TILES: in round s
  *  rank r sends its slice to r-s and receives the slice of r+s (RCCL send/recv pairs on the communicator's own
- *  high-priority stream, all rounds of a step in one RCCL group -- NBODY_EXCHANGE_ONE_GROUP=0: a group per round --, an
+ *  high-priority stream, all rounds of a step in one RCCL group or a group per round -- nb_comm_set_exchange_grouping --, an
  *  event per tile).  nb_sharded_step_* = the kernels of the own slice,
  *  then of each tile as it arrives (STRICT: ascending rank order, bit-identical to one GPU), integrate, and the start
  *  of the exchange of new_positions -- everything asynchronous; the caller ping-pongs the two position arrays exactly
@@ -190,20 +193,31 @@ NB_API int nb_comm_info(nb_comm_t comm, int* rank, int* world_size, int* device)
  * 0 = none needed).  FAST mode then evaluates every PAIR of bodies once, across the ranks too: a communicator of one rank
  * steps through nb_integrate_ws_*; with G ranks, rank r evaluates its own slice against itself and against the slices of
  * ranks r+1 .. r+G/2 pairwise, keeps its own bodies' sums and sends the reaction sums (N/G * 12 B per partner, one more
- * RCCL send/recv round per partner on the exchange stream) to their owners -- half the arithmetic per rank.  Every local
- * rank of a step must have been lent enough, or the step is the one-sided tile schedule.  STRICT never uses it. */
+ * RCCL send/recv round per partner on the exchange stream) to their owners -- half the arithmetic per rank.  STRICT never uses it.
+ *
+ * The layout of a step is a property of the COMMUNICATOR, never of one rank: a rank that stepped one-sidedly while its peers
+ * stepped pairwise would leave them inside unmatched send/recv rounds.  So with several ranks nb_comm_set_workspace is a
+ * COLLECTIVE over the communicator: every rank calls it (a rank without memory passes NULL, 0), the ranks exchange what they
+ * were lent, and every rank learns the smallest amount -- the step is pairwise if and only if that is enough for the plan
+ * (nb_comm_layout_* gives the answer; it is the same on every rank).  One process per GPU: the call blocks until every rank
+ * of the communicator has made it (it synchronises the communicator's exchange stream).  One process driving all ranks
+ * (nb_comm_init_all): call it once per rank in any order; nothing is exchanged.  Ranks whose process-global plan overrides
+ * (nbody_hip_tuning.h) differ get NB_ERR_INVALID_ARGUMENT from the call, all of them.  Before the first call the layout is
+ * one-sided.  A workspace larger than a third of the device's memory is never asked for (nb_comm_workspace_bytes_* says 0). */
 NB_API int nb_comm_workspace_bytes_f32(nb_comm_t comm, unsigned num_bodies, int mode, size_t* bytes);
 NB_API int nb_comm_workspace_bytes_f64(nb_comm_t comm, unsigned num_bodies, int mode, size_t* bytes);
 NB_API int nb_comm_set_workspace(nb_comm_t comm, void* workspace, size_t workspace_bytes);
-NB_API int nb_comm_set_pair_min_slice(int min_bodies_per_rank); /* 0 = automatic (2 048); tests run small slices pairwise */
-/* Tuning / projection hook (bench.py --emulate-gpus): exactly the kernels that rank `rank` of a `world_size`-rank pairwise step
- * launches, on the current device, with no communicator and no exchange (what the other ranks would send is whatever the
- * workspace holds: the positions written are meaningless, the kernel time is the point).  workspace == NULL: *workspace_bytes
- * is set to what the rank needs. */
-NB_API int nb_emulate_pair_rank_f32(float* new_positions, const float* old_positions, float* velocities, void* workspace, size_t* workspace_bytes,
-                                    unsigned num_bodies, int world_size, int rank, float delta_time, float damping, nb_stream_t stream);
-NB_API int nb_emulate_pair_rank_f64(double* new_positions, const double* old_positions, double* velocities, void* workspace, size_t* workspace_bytes,
-                                    unsigned num_bodies, int world_size, int rank, double delta_time, double damping, nb_stream_t stream);
+/* *pairwise = 1: nb_sharded_step_* of this communicator, for this system and mode, evaluates every pair once (see above);
+ * 0: the one-sided tile schedule.  The same answer on every rank. */
+NB_API int nb_comm_layout_f32(nb_comm_t comm, unsigned num_bodies, int mode, int* pairwise);
+NB_API int nb_comm_layout_f64(nb_comm_t comm, unsigned num_bodies, int mode, int* pairwise);
+/* How the G-1 position rounds of a step are issued, per communicator (every rank must choose the same): one_group = 1 (default;
+ * the environment variable NBODY_EXCHANGE_ONE_GROUP=0 flips the default): all rounds in ONE RCCL group -- one RCCL kernel per
+ * step, every tile's event fires when the whole exchange is done; one_group = 0: a group and an event per round -- the kernel
+ * of tile k can start while round k+1 is still moving.  Same data, same bits either way; which one is faster is unmeasured
+ * (no multi-GPU box so far).  nb_comm_get_exchange_grouping reports the current setting. */
+NB_API int nb_comm_set_exchange_grouping(nb_comm_t comm, int one_group);
+NB_API int nb_comm_get_exchange_grouping(nb_comm_t comm, int* one_group);
 NB_API int nb_sharded_step_f32(nb_comm_t comm, float* new_positions, const float* old_positions, float* velocities, float* acc,
                                unsigned num_bodies, float delta_time, float damping, int block_size, int mode, nb_stream_t stream);
 NB_API int nb_sharded_step_f64(nb_comm_t comm, double* new_positions, const double* old_positions, double* velocities, double* acc,
@@ -254,8 +268,6 @@ typedef struct nb_launch_plan {
 } nb_launch_plan_t;
 NB_API int nb_plan_f32(unsigned i_count, unsigned j_count, nb_launch_plan_t* plan);
 NB_API int nb_plan_f64(unsigned i_count, unsigned j_count, nb_launch_plan_t* plan);
-/* Override the automatic plan (0 = automatic) -- used by the tuning sweep in bench.py --sweep. */
-NB_API int nb_set_plan_override(int bodies_per_lane, int lanes_per_body, int tile_bodies);
 
 /* ... and of the pairwise layout behind nb_integrate_ws_* */
 typedef struct nb_pair_plan {
@@ -272,12 +284,8 @@ typedef struct nb_pair_plan {
 } nb_pair_plan_t;
 NB_API int nb_pair_plan_f32(unsigned num_bodies, nb_pair_plan_t* plan);
 NB_API int nb_pair_plan_f64(unsigned num_bodies, nb_pair_plan_t* plan);
-/* 0 = automatic; min_bodies: smallest system that takes the pairwise layout -- tuning sweeps (bench.py --pair-sweep). */
-NB_API int nb_set_pair_plan_override(int vectors_per_lane, int waves_per_block, int splits, int min_bodies);
-
-/* How many (kernel, device) pairs have been granted more than 64 KiB of dynamic LDS so far (the opt-in is made once per
- * kernel instantiation and device, on first use, and before any graph capture) -- tests. */
-NB_API int nb_lds_optin_count(int* count);
+/* (Process-global overrides of both plans, the kernel-time projection of one rank of a multi-GPU step and other lab-bench
+ * hooks live in nbody_hip_tuning.h: nothing a host needs to bind.) */
 
 NB_API const char* nb_version(void);
 

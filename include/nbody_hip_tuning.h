@@ -1,0 +1,54 @@
+/*
+ * nbody_hip_tuning.h -- the lab bench of libnbody_hip.so: plan overrides for tuning sweeps, the kernel-time projection of one
+ * rank of a multi-GPU step, a probe event between the two kernels of a pairwise step, counters for tests.
+ *
+ * NOT part of the drop-in boundary (that is nbody_hip.h: what a maintainer of the reference binds).  Everything declared here
+ * is PROCESS-GLOBAL state and NOT THREAD-SAFE against steps running concurrently: an override set while another thread is
+ * inside nb_integrate_* / nb_sharded_step_* changes that thread's launch geometry (results stay correct -- every geometry is
+ * tested -- but the step is no longer the one that was planned), and with one process per GPU the ranks of a communicator must
+ * set the same overrides (nb_comm_set_workspace checks it).  Used by tests/, bench.py's diagnostics and tools/.
+ */
+#ifndef NBODY_HIP_TUNING_H
+#define NBODY_HIP_TUNING_H
+
+#include "nbody_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Override the automatic plan of the one-sided FAST kernels (0 = automatic) -- tools/kernel_sweeps.py. */
+NB_API int nb_set_plan_override(int bodies_per_lane, int lanes_per_body, int tile_bodies);
+
+/* ... and of the pairwise layout (0 = automatic); min_bodies: smallest system that takes the pairwise layout (tests run it at
+ * the golden sizes with min_bodies = 1). */
+NB_API int nb_set_pair_plan_override(int vectors_per_lane, int waves_per_block, int splits, int min_bodies);
+
+/* Smallest slice (bodies per rank) for which a multi-GPU step goes pairwise across the ranks; 0 = automatic (2 048). */
+NB_API int nb_comm_set_pair_min_slice(int min_bodies_per_rank);
+
+/* Tuning / projection hook (bench.py --emulate-gpus): exactly the kernels that rank `rank` of a `world_size`-rank pairwise step
+ * launches, on the current device, with no communicator and no exchange (what the other ranks would send is whatever the
+ * workspace holds: the positions written are meaningless, the kernel time is the point).  workspace == NULL: *workspace_bytes
+ * is set to what the rank needs. */
+NB_API int nb_emulate_pair_rank_f32(float* new_positions, const float* old_positions, float* velocities, void* workspace, size_t* workspace_bytes,
+                                    unsigned num_bodies, int world_size, int rank, float delta_time, float damping, nb_stream_t stream);
+NB_API int nb_emulate_pair_rank_f64(double* new_positions, const double* old_positions, double* velocities, void* workspace, size_t* workspace_bytes,
+                                    unsigned num_bodies, int world_size, int rank, double delta_time, double damping, nb_stream_t stream);
+
+/* An event recorded between the forces kernel and the finish kernel of every ONE-GPU pairwise step from now on (NULL = none):
+ * bench.py times the two kernels of the headline step separately with it, after the timed region. */
+NB_API int nb_set_pair_probe_event(nb_event_t event);
+
+/* The device memory the library assumes when it decides whether a workspace is affordable (at most a third of it is ever asked
+ * for): 0 = the device's own total; tests of the guard set a small figure. */
+NB_API int nb_set_memory_budget(size_t bytes);
+
+/* How many (kernel, device) pairs have been granted more than 64 KiB of dynamic LDS so far (the opt-in is made once per
+ * kernel instantiation and device, on first use, and before any graph capture). */
+NB_API int nb_lds_optin_count(int* count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NBODY_HIP_TUNING_H */

@@ -6,6 +6,10 @@ library resolves RCCL, which happens once per process -- hence a process of its 
     python worker.py <case> <in.npz> <out.npz> [G] [steps] [mode] [streams] [ws]
 
 `ws`: every rank is lent the workspace nb_comm_workspace_bytes_* asks for (FAST then takes the pairwise step across the ranks).
+Environment: WORKER_ONE_GROUP=0|1 -> nb_comm_set_exchange_grouping on every communicator (unset: the library's default);
+WORKER_NO_WORKSPACE_RANK=k -> rank k lends nothing (nb_comm_set_workspace(comm, NULL, 0)): the layout must then be one-sided on
+EVERY rank.  The output holds `layout` (nb_comm_layout_* per rank) and `setup_counters` (what the transport had seen before the
+first step: nb_comm_set_workspace's exchange with one process -- here: thread -- per rank).
 
 Everything here goes through ctypes into libnbody_hip.so; nothing is computed in Python.  The parent compares the arrays
 written to <out.npz> with the CPU oracle / the golden fixtures.
@@ -78,19 +82,39 @@ def main():
     if with_workspace:
         pkg.check(lib.nb_comm_set_pair_min_slice(64), "nb_comm_set_pair_min_slice")  # (the test systems are small)
     ws_bytes_fn = lib.nb_comm_workspace_bytes_f32 if f32 else lib.nb_comm_workspace_bytes_f64
+    layout_fn = lib.nb_comm_layout_f32 if f32 else lib.nb_comm_layout_f64
     workspaces = []
+    one_group = os.environ.get("WORKER_ONE_GROUP")
+    no_workspace_rank = int(os.environ.get("WORKER_NO_WORKSPACE_RANK", "-1"))
 
-    def lend_workspace(comm):
+    def lend_workspace(comm, rank):
+        """every rank makes the call when workspaces are in play (with one process / thread per rank it is a collective)"""
+        if one_group is not None:
+            pkg.check(lib.nb_comm_set_exchange_grouping(comm, int(one_group)), "nb_comm_set_exchange_grouping")
+            now = ctypes.c_int(-1)
+            pkg.check(lib.nb_comm_get_exchange_grouping(comm, ctypes.byref(now)))
+            assert now.value == int(one_group)
         if not with_workspace:
             return 0
         need = ctypes.c_size_t(0)
         pkg.check(ws_bytes_fn(comm, n, mode, ctypes.byref(need)), "nb_comm_workspace_bytes")
-        if need.value:
+        if need.value and rank != no_workspace_rank:
             buf = pkg.DeviceBuffer(need.value)
             pkg.check(lib.nb_memset(buf.ptr, 0xFF, need.value, None), "nb_memset")  # NaN patterns: whatever is read must have been written
             workspaces.append(buf)
             pkg.check(lib.nb_comm_set_workspace(comm, buf.ptr, need.value), "nb_comm_set_workspace")
+        else:
+            pkg.check(lib.nb_comm_set_workspace(comm, None, 0), "nb_comm_set_workspace")
         return need.value
+
+    def layout_of(comm):
+        flag = ctypes.c_int(-1)
+        pkg.check(layout_fn(comm, n, mode, ctypes.byref(flag)), "nb_comm_layout")
+        return flag.value
+
+    def counter_row():
+        c = counters()
+        return np.array([c["sends"], c["recvs"], c["allgathers"], c["groups"], c["copies"]])
 
     step_all = lib.nb_sharded_step_all_f32 if f32 else lib.nb_sharded_step_all_f64
     step_one = lib.nb_sharded_step_f32 if f32 else lib.nb_sharded_step_f64
@@ -112,7 +136,9 @@ def main():
                             arr([r.bufs[3].ptr for r in ranks]), n, dt, one, 256, mode, arr([r.stream for r in ranks]))
         rc_single = step_one(comms[0], ranks[0].bufs[1].ptr, ranks[0].bufs[0].ptr, ranks[0].bufs[2].ptr, ranks[0].bufs[3].ptr, n, dt, one, 256, mode, ranks[0].stream)
         out["rejected"] = np.array([rc_subset, rc_twice, rc_single])
-        out["workspace_bytes"] = np.array([lend_workspace(c) for c in comms])
+        out["workspace_bytes"] = np.array([lend_workspace(c, k) for k, c in enumerate(comms)])
+        out["layout"] = np.array([layout_of(c) for c in comms])
+        out["setup_counters"] = counter_row()
         for _ in range(steps):
             rd = ranks[0].read
             pkg.check(step_all(comms, G, arr([r.bufs[1 - rd].ptr for r in ranks]), arr([r.bufs[rd].ptr for r in ranks]), arr([r.bufs[2].ptr for r in ranks]),
@@ -131,7 +157,8 @@ def main():
         # ranks meet inside the transport, as they would with one process per GPU
         uid = ctypes.create_string_buffer(128)
         pkg.check(lib.nb_comm_unique_id(uid), "nb_comm_unique_id")
-        results, errors = {}, []
+        results, errors, layouts, setup = {}, [], {}, {}
+        ready = threading.Barrier(G)
 
         def rank_main(k):
             try:
@@ -142,7 +169,12 @@ def main():
                 pkg.check(lib.nb_comm_info(comm, ctypes.byref(r), ctypes.byref(w), ctypes.byref(d)))
                 assert (r.value, w.value, d.value) == (k, G, 0)
                 if case == "threads":
-                    lend_workspace(comm)
+                    lend_workspace(comm, k)
+                    layouts[k] = layout_of(comm)
+                    ready.wait(timeout=120)  # every rank is through the set-up: what the transport has seen so far is set-up traffic
+                    if k == 0:
+                        setup["counters"] = counter_row()
+                    ready.wait(timeout=120)
                     me = Rank(pkg, pos0, vel0, own_streams)
                     for _ in range(steps):
                         pkg.check(step_one(comm, me.bufs[1 - me.read].ptr, me.bufs[me.read].ptr, me.bufs[2].ptr, me.bufs[3].ptr, n, dt, one, 256, mode, me.stream), "nb_sharded_step")
@@ -172,6 +204,7 @@ def main():
                 pkg.check(lib.nb_comm_destroy(comm), "nb_comm_destroy")
             except BaseException as exc:  # noqa: BLE001 -- reported by the main thread
                 errors.append((k, repr(exc)))
+                ready.abort()
 
         threads = [threading.Thread(target=rank_main, args=(k,)) for k in range(G)]
         for t in threads:
@@ -180,6 +213,9 @@ def main():
             t.join()
         if errors:
             raise SystemExit(f"rank threads failed: {errors}")
+        if case == "threads":
+            out["layout"] = np.array([layouts[k] for k in range(G)])
+            out["setup_counters"] = setup["counters"]
         for k in range(G):
             if case == "threads":
                 out[f"pos_{k}"], out[f"vel_{k}"] = results[k]
@@ -195,8 +231,7 @@ def main():
             single.update(dt)
         out["single_pos"], out["single_vel"] = single.get_position().copy(), single.get_velocity().copy()
         single.free()
-    c = counters()
-    out["counters"] = np.array([c["sends"], c["recvs"], c["allgathers"], c["groups"], c["copies"]])
+    out["counters"] = counter_row() - out.get("setup_counters", 0)  # the steps' own traffic
     np.savez(dst, **out)
 
 

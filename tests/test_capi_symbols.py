@@ -1,12 +1,13 @@
-"""CPU test: libnbody_hip.so loads and exports every symbol include/nbody_hip.h declares (no compute calls)."""
+"""CPU test: libnbody_hip.so loads and exports every symbol include/nbody_hip.h (the drop-in boundary) and
+include/nbody_hip_tuning.h (process-global tuning / test hooks) declare (no compute calls)."""
 import os
 import re
 
 from conftest import ROOT
 
 
-def declared_symbols():
-    text = open(os.path.join(ROOT, "include", "nbody_hip.h")).read()
+def declared_symbols(header="nbody_hip.h"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"NB_API\s+[\w\s\*]+?\b(nb_\w+)\s*\(", text)))
 
@@ -26,6 +27,22 @@ def test_library_exports_every_declared_symbol(pkg):
     assert not missing, missing
     # the ctypes signature table covers the whole header, nothing more
     assert sorted(pkg.SIGNATURES) == names
+
+
+def test_tuning_header_is_separate_and_exported(pkg):
+    """The lab bench (plan overrides, the one-rank projection hook, the probe event, the memory budget, the LDS opt-in counter)
+    lives in its own header: the boundary header declares none of it, the library exports all of it, and the binding's second
+    table covers it exactly."""
+    lib = pkg.lib()
+    tuning = declared_symbols("nbody_hip_tuning.h")
+    boundary = declared_symbols()
+    assert tuning and not set(tuning) & set(boundary)
+    for hook in ("nb_set_plan_override", "nb_set_pair_plan_override", "nb_comm_set_pair_min_slice", "nb_emulate_pair_rank_f32", "nb_lds_optin_count"):
+        assert hook in tuning and hook not in boundary
+    assert not [n for n in tuning if not hasattr(lib, n)]
+    assert sorted(pkg.TUNING_SIGNATURES) == tuning
+    text = open(os.path.join(ROOT, "include", "nbody_hip_tuning.h")).read()
+    assert "PROCESS-GLOBAL" in text and "NOT THREAD-SAFE" in text
 
 
 def test_host_side_argument_errors_need_no_gpu(pkg):
@@ -313,3 +330,41 @@ def test_pair_shard_plan_without_gpu(pkg):
     assert need(8192, 8)[0] == 10002            # 1 024 bodies per rank: too small a slice
     assert need(262145, 8)[0] == 10002          # does not shard evenly
     assert lib.nb_emulate_pair_rank_f32(None, None, None, None, None, 262144, 8, 0, np.float32(0.016), np.float32(1), None) == 10001
+
+
+def test_workspace_memory_guard_without_gpu(pkg):
+    """No workspace beyond a third of the device's memory is ever asked for, on one GPU and per rank of a multi-GPU step
+    (the multi-GPU plan had no such guard: ~16 GB per rank at 1 Mi bodies over 2 ranks).  nb_set_memory_budget
+    (tuning header) stands in for the device's memory figure: pure host logic."""
+    import ctypes
+
+    import numpy as np
+
+    lib = pkg.lib()
+
+    def single(n):
+        need = ctypes.c_size_t(1)
+        assert lib.nb_workspace_bytes_f32(n, pkg.NB_MODE_FAST, ctypes.byref(need)) == 0
+        return need.value
+
+    def rank(n, world):
+        need = ctypes.c_size_t(0)
+        rc = lib.nb_emulate_pair_rank_f32(None, None, None, None, ctypes.byref(need), n, world, 0, np.float32(0.016), np.float32(1), None)
+        return rc, need.value
+
+    try:
+        assert lib.nb_set_memory_budget(0) == 0
+        free_single, (rc, free_rank) = single(262144), rank(262144, 8)
+        assert free_single == 256 * 3 * 262144 * 4 and rc == 0 and free_rank > 0
+        assert lib.nb_set_memory_budget(3 * free_single) == 0          # exactly a third: still fine
+        assert single(262144) == free_single
+        assert lib.nb_set_memory_budget(3 * free_single - 1) == 0      # one byte less: the one-sided kernel (no workspace asked for)
+        assert single(262144) == 0 and pkg.pair_plan(262144).applies == 0
+        assert rank(262144, 8) == (0, free_rank)                        # (a rank of eight needs far less: 54 MiB)
+        assert lib.nb_set_memory_budget(3 * free_rank - 1) == 0
+        assert rank(262144, 8)[0] == 10002                              # NB_ERR_UNSUPPORTED: the step would be the one-sided tile schedule
+        # the figure ADVICE quotes: 1 Mi bodies over 2 ranks is ~16 GB per rank -- refused on a 32 GB device, accepted on a 288 GB one
+        assert lib.nb_set_memory_budget(32 << 30) == 0 and rank(1048576, 2)[0] == 10002
+        assert lib.nb_set_memory_budget(288 << 30) == 0 and rank(1048576, 2)[0] == 0
+    finally:
+        lib.nb_set_memory_budget(0)

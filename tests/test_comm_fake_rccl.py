@@ -236,6 +236,9 @@ def test_pairwise_step_across_ranks_one_thread_per_rank(tmp_path, oracle):
     got = _run(tmp_path, "threads", pos0, vel0, world, steps, "fast", workspace=True)
     sends, recvs, gathers, groups, copies = got["counters"]
     assert sends == recvs == (world - 1 + world // 2) * world * steps
+    # nb_comm_set_workspace was a collective here: every rank told every other what it was lent (one grouped round of notes each)
+    assert list(got["setup_counters"][:2]) == [(world - 1) * world] * 2 and got["setup_counters"][3] == world
+    assert list(got["layout"]) == [1] * world
     ref_p, ref_v = pos0.copy(), vel0.copy()
     oracle.update(ref_p, ref_v, np.float32(0.016), steps=steps)
     for k in range(world):
@@ -302,18 +305,43 @@ def test_config4_shape_eight_ranks_at_one_mi_bodies(tmp_path, oracle):
 @pytest.mark.gpu
 @pytest.mark.parametrize("workspace", [False, True])
 def test_position_exchange_one_group_per_round(tmp_path, oracle, workspace):
-    """NBODY_EXCHANGE_ONE_GROUP=0: a group per round (tile k's event fires with round k) instead of the default one group per
-    step -- the A/B knob for real multi-GPU runs: the same bits -- STRICT == the CPU path, FAST (one-sided tiles and pairwise
-    across ranks) == the default."""
+    """nb_comm_set_exchange_grouping(comm, 0): a group per round (tile k's event fires with round k) instead of the default one
+    group per step -- a per-communicator setting, so that one multi-GPU job can time both: the same bits -- STRICT == the CPU
+    path, FAST (one-sided tiles and pairwise across ranks) == the default.  The environment variable only sets the default."""
     n, steps, world = 4096, 4, 4
     pos0, vel0 = oracle.startup_state(n, np.float32)
     ref_p, ref_v = pos0.copy(), vel0.copy()
     oracle.update(ref_p, ref_v, np.float32(0.016), steps=steps)
-    strict = _run(tmp_path, "all", pos0, vel0, world, steps, "strict", workspace=workspace, NBODY_EXCHANGE_ONE_GROUP="0")
+    strict = _run(tmp_path, "all", pos0, vel0, world, steps, "strict", workspace=workspace, WORKER_ONE_GROUP="0")
     assert strict["pos_0"].tobytes() == ref_p.tobytes()
     sends, recvs, gathers, groups, copies = strict["counters"]
     assert sends == recvs == (world - 1) * world * steps and groups == (world - 1) * steps  # a group per round
-    fast = _run(tmp_path, "all", pos0, vel0, world, steps, "fast", workspace=workspace, NBODY_EXCHANGE_ONE_GROUP="0")
+    fast = _run(tmp_path, "all", pos0, vel0, world, steps, "fast", workspace=workspace, WORKER_ONE_GROUP="0")
     default = _run(tmp_path, "all", pos0, vel0, world, steps, "fast", workspace=workspace)
+    explicit = _run(tmp_path, "all", pos0, vel0, world, steps, "fast", workspace=workspace, WORKER_ONE_GROUP="1", NBODY_EXCHANGE_ONE_GROUP="0")  # the API outranks the variable
+    by_env = _run(tmp_path, "all", pos0, vel0, world, steps, "fast", workspace=workspace, NBODY_EXCHANGE_ONE_GROUP="0")  # ... which is the default only
+    assert explicit["counters"][3] == default["counters"][3] and by_env["counters"][3] == fast["counters"][3] != default["counters"][3]
     for k in range(world):
         assert fast[f"pos_{k}"].tobytes() == default["pos_0"].tobytes()
+        assert explicit[f"pos_{k}"].tobytes() == default["pos_0"].tobytes() and by_env[f"pos_{k}"].tobytes() == default["pos_0"].tobytes()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["threads", "all"])
+def test_layout_is_agreed_by_the_whole_communicator(tmp_path, oracle, case):
+    """a rank that was lent no workspace must not step one-sidedly while its peers step pairwise (they would sit in
+    unmatched reaction rounds).  Rank 2 of 4 passes (NULL, 0) to nb_comm_set_workspace: with a thread per rank the call is a
+    collective and every rank learns the smallest amount; with one thread for all ranks the library sees them all.  Either way
+    nb_comm_layout_* says one-sided on EVERY rank, the transport sees no reaction round, and the result is the bits of a run in
+    which nobody lent anything."""
+    n, steps, world = 4096, 3, 4
+    pos0, vel0 = oracle.startup_state(n, np.float32)
+    got = _run(tmp_path, case, pos0, vel0, world, steps, "fast", workspace=True, WORKER_NO_WORKSPACE_RANK="2")
+    assert list(got["layout"]) == [0] * world
+    sends, recvs, gathers, groups, copies = got["counters"]
+    assert sends == recvs == (world - 1) * world * steps  # position rounds only
+    plain = _run(tmp_path, case, pos0, vel0, world, steps, "fast", workspace=False)
+    for k in range(world):
+        assert got[f"pos_{k}"].tobytes() == plain["pos_0"].tobytes()
+    everyone = _run(tmp_path, case, pos0, vel0, world, steps, "fast", workspace=True)
+    assert list(everyone["layout"]) == [1] * world and everyone["pos_0"].tobytes() != plain["pos_0"].tobytes()

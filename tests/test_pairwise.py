@@ -142,6 +142,21 @@ def test_workspace_rules(gpu, oracle):
     # the workspace may not overlap the bodies the launch reads
     assert lib.nb_integrate_ws_f32(bufs[1].ptr, bufs[0].ptr, bufs[2].ptr, np.float32(0.016), np.float32(1), n, 256, gpu.NB_MODE_FAST, bufs[0].ptr, need.value, None) == 10001
     assert lib.nb_integrate_ws_f32(bufs[0].ptr, bufs[0].ptr, bufs[2].ptr, np.float32(0.016), np.float32(1), n, 256, gpu.NB_MODE_FAST, work.ptr, need.value, None) == 10001
+    # ... nor anything else the launch writes (pair_forces' reaction planes on the arrays pair_finish reads and writes):
+    # a workspace that starts inside the velocities or the new positions, a workspace that ENDS inside them, velocities on the new positions
+    big = gpu.DeviceBuffer(need.value + 2 * pos0.nbytes)  # [workspace-sized gap][one body array] : lets a workspace end inside an array
+    tail_array = ctypes.c_void_p(big.ptr.value + need.value - 4096)
+    args = (np.float32(0.016), np.float32(1), n, 256, gpu.NB_MODE_FAST)
+    assert lib.nb_integrate_ws_f32(bufs[1].ptr, bufs[0].ptr, bufs[2].ptr, *args, bufs[2].ptr, need.value, None) == 10001
+    assert lib.nb_integrate_ws_f32(bufs[1].ptr, bufs[0].ptr, bufs[2].ptr, *args, ctypes.c_void_p(bufs[1].ptr.value + 64), need.value, None) == 10001
+    assert lib.nb_integrate_ws_f32(bufs[1].ptr, bufs[0].ptr, tail_array, *args, big.ptr, need.value, None) == 10001
+    assert lib.nb_integrate_ws_f32(tail_array, bufs[0].ptr, bufs[2].ptr, *args, big.ptr, need.value, None) == 10001
+    assert lib.nb_integrate_ws_f32(bufs[1].ptr, bufs[0].ptr, bufs[1].ptr, *args, work.ptr, need.value, None) == 10001
+    # the same arrays with the workspace next to them (not inside) are fine
+    after = ctypes.c_void_p(big.ptr.value + need.value)
+    gpu.check(lib.nb_integrate_ws_f32(bufs[1].ptr, bufs[0].ptr, after, *args, big.ptr, need.value, None), "disjoint parts of one allocation")
+    gpu.check(lib.nb_device_synchronize())
+    big.free()
     for b in bufs + [work]:
         b.free()
 
