@@ -12,7 +12,10 @@ bodies shard across ranks with one RCCL all-gather of the new positions per step
 multi-GPU entry points (nb_comm_init_rank + nb_sharded_step_*, csrc/nbody_comm.hip); torch.distributed (gloo) only does the
 rendezvous, the barriers and the time reduction.  cuda-nbody_amd/sharded.py, the same schedule over torch.distributed, stays as
 `--exchange torch` for A/B and as the fallback.  At N=1 the line also carries "configs": the other BASELINE configs and STRICT,
-timed after the headline measurement.
+timed after the headline measurement; at N>1 it carries BASELINE configs[3] (1 048 576 bodies over the N ranks), "ranks_seen"
+(what every rank's communicator says about itself) and "diagnostics" (the same job timed with the other exchange grouping,
+one-sided, the exchange legs alone, the kernels alone) -- all taken after the timed region, under a watchdog that prints the
+line without them should they stall.  Tuning sweeps and one-rank projections live in tools/kernel_sweeps.py.
 
 Metric conventions are the reference's (src/nbody/compute.cpp:16-18,105-121): interactions/step = N^2
 (self-interaction counted), 20 flop per fp32 interaction, 30 per fp64.  Timing protocol: W untimed warm-up
@@ -30,6 +33,7 @@ import ctypes
 import json
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -53,8 +57,7 @@ def parse_args():
     ap.add_argument("--mode", choices=["fast", "strict"], default="fast")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-bodies", type=int, default=0, help="bodies i in the CPU sample (0 = auto, ~10 s)")
-    ap.add_argument("--sweep", action="store_true", help="time every fast-kernel geometry (tuning aid), N=1 only")
-    ap.add_argument("--plan", type=str, default="", help="I,S,TILE override for the fast kernel, e.g. 2,1,1024")
+    ap.add_argument("--plan", type=str, default="", help="I,S,TILE override for the one-sided fast kernel, e.g. 2,8,1024 (tuning; implies --layout one-sided)")
     ap.add_argument("--exchange", choices=["rccl", "torch", "allgather", "staged", "host", "host-tiles"], default="rccl",
                     help="rccl: the PRODUCT's multi-GPU path -- nb_comm_init_rank + nb_sharded_step_* of the C-ABI (csrc/nbody_comm.hip): the "
                          "position all-gather issued as its G-1 tiles, RCCL send/recv pairs on the communicator's side "
@@ -73,9 +76,11 @@ def parse_args():
     ap.add_argument("--no-configs", action="store_true", help="skip the extra BASELINE configs timed after the headline measurement (N=1)")
     ap.add_argument("--launch-timeout", type=float, default=600.0,
                     help="plain `bench.py --gpus N`: seconds the launcher waits for the N ranks before ending them (see self_launch)")
-    ap.add_argument("--emulate-gpus", type=int, default=0,
-                    help="on ONE GPU, run rank 0's kernel schedule of a G-rank strong-scaling job (no collective): "
-                         "projection aid, prints its own JSON and never the headline metric")
+    ap.add_argument("--rehearse-one-gpu", action="store_true",
+                    help="REHEARSAL of the N-rank C-ABI path on a one-GPU box: every rank uses device 0 and RCCL is replaced by the test double "
+                         "(NBODY_RCCL_LIB=tests/fake_rccl/libfake_rccl.so with FAKE_RCCL_IPC=1, set here when absent).  Never a performance number.")
+    ap.add_argument("--no-diagnostics", action="store_true", help="N>1: skip the A/B timings and BASELINE configs[3] after the timed region")
+    ap.add_argument("--diagnostics-timeout", type=float, default=240.0, help="N>1: seconds the post-headline measurements may take before the line is printed without them")
     return ap.parse_args()
 
 
@@ -182,12 +187,29 @@ FP32_ISSUE_CEILING_INTERACTIONS_PER_S = 1024 * 128 * 2.4e9 / 61.5
 FP64_ISSUE_CEILING_INTERACTIONS_PER_S = 1024 * 64 * 2.4e9 / 78.0
 
 
+def pair_evaluations(pair) -> float:
+    """pair evaluations per step of the pairwise layout: NB x (NB/2 + 1) block pairs of (64 I)^2"""
+    return float(pair.blocks) * (pair.blocks // 2 + 1) * pair.block_bodies * pair.block_bodies
+
+
+def fractions(n, fp64, layout, ms, pair=None):
+    """(frac, executed_frac) of the vector-FMA peak.  `frac`: ALGORITHMIC flop of the reference convention -- 20 (30) per directed
+    interaction, N^2 interactions (compute.cpp:16-18) -- over the time; it can pass 1 for the pairwise layout, which
+    evaluates each pair once.  `executed_frac`: the flop the kernels really issue -- 24 (36) per pair evaluation for the pairwise
+    layout, the algorithmic count for the one-sided and STRICT kernels (they do evaluate every directed interaction) -- i.e. how
+    busy the FMA pipes are; never above 1."""
+    flops, peak = (30, FP64_VECTOR_PEAK_TFLOPS) if fp64 else (20, FP32_VECTOR_PEAK_TFLOPS)
+    frac = flops * float(n) * n / (ms * 1e-3) / (peak * 1e12)
+    if layout != "pairwise" or pair is None:
+        return round(frac, 4), round(frac, 4)
+    return round(frac, 4), round((36 if fp64 else 24) * pair_evaluations(pair) / (ms * 1e-3) / (peak * 1e12), 4)
+
+
 def other_configs(pkg, lib, headline):
     """BASELINE.json configs besides the headline one, plus STRICT (the parity-exact mode) and, for FAST, both layouts
     (pairwise = nb_integrate_ws_* with a workspace, one-sided = nb_integrate_*), each as
-    {workload, bodies, dtype, mode, layout, steps, ms_per_step, frac}: 1 warm-up step, then K steps between two
-    HIP events on the launch stream (the reference's GPU protocol, compute_cuda.cpp:183-195); frac against the same
-    vector-FMA peaks as the headline (20 flop per fp32 interaction, 30 per fp64: compute.cpp:16-18)."""
+    {workload, bodies, dtype, mode, layout, steps, ms_per_step, frac, executed_frac}: 1 warm-up step, then K steps between two
+    HIP events on the launch stream (the reference's GPU protocol, compute_cuda.cpp:183-195); the fractions: see fractions()."""
     cases = [
         ("configs[1]", 65536, False, "fast", 200),
         ("configs[2]", 262144, False, "fast", 20),
@@ -224,10 +246,10 @@ def other_configs(pkg, lib, headline):
             e1.synchronize()
             ms = e0.elapsed_ms(e1) / steps
             system.free()
-            flops, peak = (30, FP64_VECTOR_PEAK_TFLOPS) if fp64 else (20, FP32_VECTOR_PEAK_TFLOPS)
+            frac, executed = fractions(n, fp64, layout, ms, pkg.pair_plan(n, dtype) if layout == "pairwise" else None)
             # (kept short: the whole line should stay well under what a log tail holds; interactions/s = bodies^2 / ms_per_step)
             out.append({"workload": what, "bodies": n, "dtype": "f64" if fp64 else "f32", "mode": mode_name, "layout": layout, "steps": steps,
-                        "ms_per_step": float(f"{ms:.5g}"), "frac": round(flops * float(n) * n / (ms * 1e-3) / (peak * 1e12), 4)})
+                        "ms_per_step": float(f"{ms:.5g}"), "frac": frac, "executed_frac": executed})
     return out
 
 
@@ -266,15 +288,73 @@ def rank_projection(pkg, lib, n, dtype, dt, damping, single_ms):
     return out
 
 
+def pair_kernel_split(pkg, lib, step, stream, reps=10):
+    """Average duration of the two kernels of the pairwise step, each on its own: pair_forces (the dominant kernel) and pair_finish,
+    from HIP events on the launch stream -- one before the step, one the library records BETWEEN the two launches
+    (nb_set_pair_probe_event, tuning header), one after.  Taken after the timed region."""
+    before, between, after = pkg.Event(), pkg.Event(), pkg.Event()
+    forces = finish = 0.0
+    pkg.check(lib.nb_set_pair_probe_event(between.h), "nb_set_pair_probe_event")
+    try:
+        for _ in range(reps):
+            before.record(stream)
+            step()
+            after.record(stream)
+            after.synchronize()
+            forces += before.elapsed_ms(between)
+            finish += between.elapsed_ms(after)
+    finally:
+        pkg.check(lib.nb_set_pair_probe_event(None), "nb_set_pair_probe_event")
+    return forces / reps, finish / reps
+
+
+def cpu_baseline(n, dtype, pos0, vel0, sample_bodies):
+    """The CPU path (oracle/: a port of BodySystemCPU<T>::update; test infrastructure, loaded here only) timed on this host:
+    a bounded sample of the headline workload, and BASELINE configs[0] exactly as stated -- 1 024 bodies, fp32, 100 steps, no
+    warm-up, steady clock around the loop (compute_cpu.cpp:72-88)."""
+    O = entry.load_oracle()
+    orc1 = O.Oracle()
+    pos_h, vel_h = orc1.startup_state(n, dtype)
+    # the workload above came from the product's randomise_bodies; the checker's must be the same bytes
+    assert pos_h.tobytes() == pos0.tobytes() and vel_h.tobytes() == vel0.tobytes(), "product and oracle start-up bodies differ"
+    sample = sample_bodies or max(8, min(n, int(2.0e10 // n) // 8 * 8))
+    base = {}
+    # OpenMP leg: the reference's fp32 loop forks INSIDE the j loop (bodysystemcpu.cpp:156-168), i.e. one fork/join per body j --
+    # it is slow by construction, so it gets a smaller sample and at most the box's CPU share (16 threads per GPU).
+    for key, omp, smp in (("one_thread", False, sample), ("openmp", True, max(8, sample // 16 // 8 * 8))):
+        orc = O.Oracle(openmp=omp)
+        if omp:
+            orc.set_num_threads(min(16, os.cpu_count() or 1))
+        ms = orc.benchmark_partial(pos_h, smp)
+        base[key] = {"value": smp * float(n) / (ms * 1e-3), "cores": orc.num_threads() if omp else 1, "ms": ms, "sample_bodies_i": smp}
+    p0, v0 = orc1.startup_state(1024, np.float32)
+    ms0 = orc1.benchmark(p0, v0, np.float32(0.016), 100)
+    return {
+        "value": base["one_thread"]["value"],
+        "unit": "interactions/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"force pass of BodySystemCPU::update (oracle/ port) for the first {sample} bodies i against all {n} bodies j = {sample * n:.3g} "
+                  f"interactions; 1 thread is how the reference ships",
+        "openmp": base["openmp"],
+        "config0": {"what": "BASELINE configs[0]: 1024 bodies, fp32, 100 steps of the CPU path, no warm-up (compute_cpu.cpp:72-88), 1 thread",
+                    "ms_total": float(f"{ms0:.5g}"), "interactions_per_s": 1024.0 * 1024.0 * 100 / (ms0 * 1e-3), "gflops": 20 * 1024.0 * 1024.0 * 100 / (ms0 * 1e-3) * 1e-9},
+    }
+
+
 def main():
     args = parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.rehearse_one_gpu:
+        # every rank on device 0, RCCL replaced by the cross-process test double: set before anything resolves RCCL (once per process)
+        os.environ.setdefault("NBODY_RCCL_LIB", os.path.join(ROOT, "tests", "fake_rccl", "libfake_rccl.so"))
+        os.environ.setdefault("FAKE_RCCL_IPC", "1")
     if world == 1 and args.gpus > 1 and "RANK" not in os.environ:
         # plain `python3 bench.py --gpus N`: start the N ranks ourselves, BEFORE anything in this process touches the GPU
         # (no torch import, no HIP call so far), relay their output and exit with their status.  Children, never exec.
-        raise SystemExit(self_launch(args.gpus, any(a.startswith("--exchange") for a in sys.argv[1:]), args.launch_timeout))
+        raise SystemExit(self_launch(args.gpus, any(a.startswith("--exchange") for a in sys.argv[1:]) or args.rehearse_one_gpu, args.launch_timeout))
     if args.gpus != world:
         args.gpus = world
 
@@ -291,6 +371,9 @@ def main():
     # while this process has a single thread.  Later, torch.distributed's store and gloo threads are running and may draw from
     # the same stream in between (seen once in round 3: two runs of one command that differed in a few bodies).
     pos0, vel0 = make_bodies(n, dtype)
+    big = None  # BASELINE configs[3]'s system, for the N > 1 line (drawn now for the same reason)
+    if world > 1 and not args.no_diagnostics and args.exchange == "rccl" and args.mode == "fast" and not args.fp64 and CONFIG3_BODIES % world == 0:
+        big = make_bodies(CONFIG3_BODIES if not args.rehearse_one_gpu else 65536, np.float32)
 
     pkg = entry.load_package()
     lib = pkg.lib()
@@ -298,7 +381,7 @@ def main():
     if args.plan:
         pkg.set_plan_override(*[int(x) for x in args.plan.split(",")])
 
-    if args.exchange.startswith("host"):
+    if args.exchange.startswith("host") or args.rehearse_one_gpu:
         local_rank = 0  # every rank on the one GPU
     torch.cuda.set_device(local_rank)
     pkg.check(lib.nb_set_device(local_rank), "nb_set_device")
@@ -343,28 +426,34 @@ def main():
     pos_t = torch.from_numpy(pos0.reshape(n, 4)).to(dev, tdtype)
     vel_t = torch.from_numpy(vel0.reshape(n, 4)).to(dev, tdtype)
     stream = torch.cuda.current_stream()
+    stream_ptr = ctypes.c_void_p(stream.cuda_stream)
 
-    # scratch memory of the pairwise layout: caller-owned (a torch tensor here), sized by the library, contents irrelevant
-    work_t, work_bytes = None, 0
-    if args.layout == "pairwise" and world == 1 and not args.sweep and not args.emulate_gpus and not args.plan:
-        work_bytes = pkg.workspace_bytes(n, dtype, mode)
-        if work_bytes:
-            work_t = torch.empty(work_bytes, dtype=torch.uint8, device=dev)
-    pairwise = work_t is not None  # (several ranks: decided below, once the communicator says what it can use)
+    def lend(nbytes):
+        """scratch memory of the pairwise layout: caller-owned (a torch tensor here), sized by the library, contents irrelevant.
+        An allocation failure is not an error: the rank then lends nothing (and, several ranks: nb_comm_set_workspace lets every
+        rank know, so that all of them step one-sidedly)."""
+        if not nbytes:
+            return None
+        try:
+            return torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        except RuntimeError as exc:  # (torch.OutOfMemoryError is one)
+            print(f"[bench rank {rank}] no memory for a {nbytes}-byte workspace ({exc!r}): stepping without one", file=sys.stderr, flush=True)
+            return None
+
+    want_pairwise = args.layout == "pairwise" and not args.plan
+    work_t = lend(pkg.workspace_bytes(n, dtype, mode)) if (want_pairwise and world == 1) else None
+    pairwise = work_t is not None  # (several ranks: decided below by the communicator)
+    work_bytes = work_t.numel() if work_t is not None else 0
     ws_fn = lib.nb_integrate_ws_f64 if args.fp64 else lib.nb_integrate_ws_f32
 
-    kernel_launches = [0]
-
     def launch(new_pos, old_pos, vel, acc, i0, ni, j0, nj, flags):
-        kernel_launches[0] += 1
         pkg.check(shard_fn(new_pos.data_ptr(), old_pos.data_ptr(), vel.data_ptr(), acc.data_ptr(), i0, ni, j0, nj, flags,
-                           dt, damping, 256, mode, ctypes.c_void_p(stream.cuda_stream)), "nb_integrate_shard")
+                           dt, damping, 256, mode, stream_ptr), "nb_integrate_shard")
 
     capi_rank = None  # --exchange rccl: this rank of the product's sharded system (nb_comm_init_rank + nb_sharded_step_*)
     system = None     # every other exchange: cuda-nbody_amd/sharded.py over torch.distributed
+    sharded = entry.load_package_module("sharded") if distributed else None
     if distributed:
-        sharded = entry.load_package_module("sharded")
-
         def everyone(ok: bool) -> bool:
             """collective decision over gloo: true only if `ok` on EVERY rank (a rank deciding on its own would leave the
             others inside mismatched collectives)"""
@@ -385,17 +474,21 @@ def main():
                 problem = problem or RuntimeError("rank 0 could not create the RCCL unique id")
             else:
                 try:
-                    capi_rank = pkg.ShardedRank(ids[0], world, rank, [b.data_ptr() for b in bufs], vel_t.data_ptr(), acc_t.data_ptr(), n, dtype, mode, 256,
-                                                ctypes.c_void_p(stream.cuda_stream))
+                    capi_rank = pkg.ShardedRank(ids[0], world, rank, [b.data_ptr() for b in bufs], vel_t.data_ptr(), acc_t.data_ptr(), n, dtype, mode, 256, stream_ptr)
+                except pkg.NBodyHipError as exc:
+                    problem = exc
+            if everyone(problem is None):
+                # The communicator is up on every rank.  Lend it the workspace: with several ranks nb_comm_set_workspace is a
+                # COLLECTIVE (every rank calls it, with nothing if it has nothing), after which the layout of a step -- pairwise
+                # across the ranks or one-sided tiles -- is the communicator's, the same on every rank.
+                try:
+                    if want_pairwise:
+                        work_t = lend(capi_rank.workspace_bytes())
+                        work_bytes = work_t.numel() if work_t is not None else 0
+                    capi_rank.set_workspace(work_t.data_ptr() if work_t is not None else None, work_bytes)
+                    pairwise = capi_rank.pairwise()
                     # bring the communicator up (channels, first-call set-up) outside any timed step, whatever --warmup says;
                     # every rank holds identical positions at this point, so exchanging them changes nothing
-                    if args.layout == "pairwise" and world > 1:  # pairs once across the ranks: reaction sums travel to their owners
-                        work_bytes = capi_rank.workspace_bytes()
-                        if work_bytes:
-                            work_t = torch.empty(work_bytes, dtype=torch.uint8, device=dev)
-                            pairwise = True
-                    if pairwise:
-                        capi_rank.set_workspace(work_t.data_ptr(), work_bytes)  # (a world of one: the single-GPU step with its workspace)
                     capi_rank.exchange_once(0)
                     torch.cuda.synchronize()
                 except pkg.NBodyHipError as exc:
@@ -405,13 +498,12 @@ def main():
                       "ALL ranks fall back to the tile schedule over torch.distributed", file=sys.stderr, flush=True)
                 if capi_rank is not None:
                     capi_rank.destroy()
-                capi_rank, exchange_fallback = None, True
+                capi_rank, exchange_fallback, pairwise = None, True, False
                 args.exchange = "torch"
                 rccl_group = torch_rccl_group()
 
         if capi_rank is not None:
             def step():
-                kernel_launches[0] += 1 if (pairwise and world == 1) else (world // 2 + 1 if pairwise else world)  # one per position tile / per diagonal + partner
                 capi_rank.update(dt, damping)
 
             finish = capi_rank.finish
@@ -457,10 +549,8 @@ def main():
 
         def step():
             r = state["read"]
-            if pairwise:
-                kernel_launches[0] += 1  # (one call = the forces kernel + the kernel that adds the reaction slots and integrates)
-                pkg.check(ws_fn(bufs[1 - r].data_ptr(), bufs[r].data_ptr(), vel_t.data_ptr(), dt, damping, n, 256, mode, work_t.data_ptr(), work_bytes,
-                                ctypes.c_void_p(stream.cuda_stream)), "nb_integrate_ws")
+            if pairwise:  # (one call = the forces kernel + the kernel that adds the reaction slots and integrates)
+                pkg.check(ws_fn(bufs[1 - r].data_ptr(), bufs[r].data_ptr(), vel_t.data_ptr(), dt, damping, n, 256, mode, work_t.data_ptr(), work_bytes, stream_ptr), "nb_integrate_ws")
             else:
                 launch(bufs[1 - r], bufs[r], vel_t, acc_t, 0, n, 0, n, pkg.NB_SHARD_FINALIZE)
             state["read"] = 1 - r
@@ -475,169 +565,42 @@ def main():
             dist.barrier()  # gloo: a host barrier between two device synchronisations
             torch.cuda.synchronize()
 
-    if args.emulate_gpus > 1 and world == 1 and args.sweep:
-        sharded = entry.load_package_module("sharded")
-        G = args.emulate_gpus
-        i0, ni = sharded.slice_of(G // 2, G, n)
-        sched = sharded.tile_schedule(G // 2, G, n, False) if args.exchange == "rccl" else sharded.chunk_schedule(i0, ni, n, False)
-        acc_t = torch.zeros_like(pos_t)
-        nxt = pos_t.clone()
-        rows = []
-        for I in ((1, 2, 4) if args.fp64 else (2, 4)):
-            for S in (4, 8, 16, 64):
-                for tile in (256, 512, 1024, 2048):
-                    if S == 64:
-                        if tile not in (512, 1024):
-                            continue
-                    elif tile < 64 * S or tile // (64 * S) not in (1, 2, 4):
-                        continue
-                    if lib.nb_set_plan_override(I, S, tile) != 0:
-                        continue
-                    def one_step():
-                        for k, (j0, nj, _) in enumerate(sched):
-                            flags = (pkg.NB_SHARD_ACC_IN if k else 0) | (pkg.NB_SHARD_FINALIZE if k == len(sched) - 1 else 0)
-                            launch(nxt, pos_t, vel_t, acc_t, i0, ni, j0, nj, flags)
-                    for _ in range(2):
-                        one_step()
-                    e0, e1 = pkg.Event(), pkg.Event()
-                    torch.cuda.synchronize()
-                    e0.record(ctypes.c_void_p(stream.cuda_stream))
-                    for _ in range(10):
-                        one_step()
-                    e1.record(ctypes.c_void_p(stream.cuda_stream))
-                    e1.synchronize()
-                    ms = e0.elapsed_ms(e1) / 10
-                    rows.append(dict(I=I, S=S, tile=tile, ms=round(ms, 4), speedup_vs_ideal=round((float(n) * n / G) / (ms * 1e-3) * 1e-12, 3)))
-                    print(json.dumps(rows[-1]), flush=True)
-        pkg.set_plan_override(0, 0, 0)
-        print("best:", json.dumps(min(rows, key=lambda r: r["ms"])))
-        return
-
-    if args.emulate_gpus > 1 and world == 1 and args.layout == "pairwise" and mode == pkg.NB_MODE_FAST:
-        # one rank's kernels of the pairwise step across G ranks (nb_emulate_pair_rank_*: diagonal, G/2 rectangles, folds, finish)
-        G = args.emulate_gpus
-        emulate = lib.nb_emulate_pair_rank_f64 if args.fp64 else lib.nb_emulate_pair_rank_f32
-        need = ctypes.c_size_t(0)
-        pkg.check(emulate(None, None, None, None, ctypes.byref(need), n, G, 0, dt, damping, None), "nb_emulate_pair_rank (size)")
-        work = torch.empty(need.value, dtype=torch.uint8, device=dev)
-        nxt, out = pos_t.clone(), []
-        for r in sorted({0, G // 2, G - 1}):
-            def one_step():
-                pkg.check(emulate(nxt.data_ptr(), pos_t.data_ptr(), vel_t.data_ptr(), work.data_ptr(), ctypes.byref(need), n, G, r, dt, damping,
-                                  ctypes.c_void_p(stream.cuda_stream)), "nb_emulate_pair_rank")
-            for _ in range(args.warmup):
-                one_step()
-            e0, e1 = pkg.Event(), pkg.Event()
-            torch.cuda.synchronize()
-            e0.record(ctypes.c_void_p(stream.cuda_stream))
-            for _ in range(args.steps):
-                one_step()
-            e1.record(ctypes.c_void_p(stream.cuda_stream))
-            e1.synchronize()
-            out.append({"rank": r, "ms_per_step_kernels_only": e0.elapsed_ms(e1) / args.steps, "launches_per_step": 2 * (G // 2) + 2})
-        worst = max(o["ms_per_step_kernels_only"] for o in out)
-        print(json.dumps({"emulated_gpus": G, "bodies": n, "schedule": "pairwise across ranks: diagonal + G/2 rectangles, reaction sums to their owners",
-                          "workspace_bytes_per_rank": need.value, "ranks": out, "projected_interactions_per_s_excluding_exchange": float(n) * n / (worst * 1e-3)}), flush=True)
-        return
-
-    if args.emulate_gpus > 1 and world == 1:
-        sharded = entry.load_package_module("sharded")
-        G = args.emulate_gpus
-        out = []
-        for r in sorted({0, G // 2, G - 1}):
-            i0, ni = sharded.slice_of(r, G, n)
-            if args.exchange == "rccl":  # the tile form: one kernel per position tile
-                sched = sharded.tile_schedule(r, G, n, mode == pkg.NB_MODE_STRICT)
-            else:
-                sched = sharded.chunk_schedule(i0, ni, n, mode == pkg.NB_MODE_STRICT)
-            acc_t = torch.zeros_like(pos_t)
-            nxt = pos_t.clone()
-
-            def one_step():
-                for k, (j0, nj, _) in enumerate(sched):
-                    flags = (pkg.NB_SHARD_ACC_IN if k else 0) | (pkg.NB_SHARD_FINALIZE if k == len(sched) - 1 else 0)
-                    launch(nxt, pos_t, vel_t, acc_t, i0, ni, j0, nj, flags)
-
-            for _ in range(args.warmup):
-                one_step()
-            e0, e1 = pkg.Event(), pkg.Event()
-            torch.cuda.synchronize()
-            e0.record(ctypes.c_void_p(stream.cuda_stream))
-            for _ in range(args.steps):
-                one_step()
-            e1.record(ctypes.c_void_p(stream.cuda_stream))
-            e1.synchronize()
-            ms = e0.elapsed_ms(e1) / args.steps
-            pl = pkg.plan(ni, n, dtype)
-            out.append({"rank": r, "ms_per_step_kernels_only": ms, "launches_per_step": len(sched),
-                        "plan": [pl.bodies_per_lane, pl.lanes_per_body, pl.tile_bodies, pl.grid_blocks]})
-        worst = max(o["ms_per_step_kernels_only"] for o in out)
-        print(json.dumps({"emulated_gpus": G, "bodies": n, "schedule": "tiles" if args.exchange == "rccl" else "own/below/above", "ranks": out,
-                          "projected_interactions_per_s_excluding_exchange": float(n) * n / (worst * 1e-3)}), flush=True)
-        return
-
-    if args.sweep and world == 1:
-        results = []
-        for I in ((1, 2, 4) if args.fp64 else (2, 4)):
-            for S in (4, 8, 16, 64):
-                for tile in (256, 512, 1024, 2048):
-                    blk = 256 if S == 64 else 64 * S
-                    if tile < blk or tile // blk not in (1, 2, 4):
-                        continue
-                    if S == 64 and (tile not in (512, 1024) or I > (2 if args.fp64 else 4)):
-                        continue
-                    pkg.set_plan_override(I, S, tile)
-                    for _ in range(2):
-                        step()
-                    e0, e1 = pkg.Event(), pkg.Event()
-                    torch.cuda.synchronize()
-                    e0.record(ctypes.c_void_p(stream.cuda_stream))
-                    for _ in range(5):
-                        step()
-                    e1.record(ctypes.c_void_p(stream.cuda_stream))
-                    e1.synchronize()
-                    ms = e0.elapsed_ms(e1) / 5
-                    results.append(dict(I=I, S=S, tile=tile, ms=round(ms, 4), ginter=round(n * n / ms * 1e-6, 1),
-                                        frac=round(flops_per * n * n / (ms * 1e-3) / (peak * 1e12), 4)))
-                    print(json.dumps(results[-1]), flush=True)
-        pkg.set_plan_override(0, 0, 0)
-        best = max(results, key=lambda r: r["ginter"])
-        print("best:", json.dumps(best))
-        return
-
+    # ------------------------------------------------------------------------------------------------ the timed region
     for _ in range(args.warmup):
         step()
     fence()
-    launches_before = kernel_launches[0]
     ev0, ev1 = pkg.Event(), pkg.Event()
     t0 = time.perf_counter()
-    ev0.record(ctypes.c_void_p(stream.cuda_stream))
+    ev0.record(stream_ptr)
     for _ in range(args.steps):
         step()
     finish()
-    ev1.record(ctypes.c_void_p(stream.cuda_stream))
+    ev1.record(stream_ptr)
     fence()
     elapsed = time.perf_counter() - t0
     ev1.synchronize()
-    kernel_ms_total = ev0.elapsed_ms(ev1)
-    launches = kernel_launches[0] - launches_before
+    stream_ms_per_step = ev0.elapsed_ms(ev1) / args.steps  # HIP events on the launch stream: this rank's step, kernels only at N = 1
 
     if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64)  # gloo
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # ------------------------------------------------------------------------------------------------ after it: the line
+    line = None
     if rank == 0:
-        interactions = float(n) * float(n) * args.steps
-        value = interactions / elapsed
-        # dominant kernel: per-launch duration from HIP events on the launch stream.  At N=1 the stream holds
-        # nothing but the K back-to-back launches, so events/K is the kernel's average duration (the rocprofv3
-        # --kernel-trace --stats average under profiles/ agrees).  For N>1 it is the rank-0 step time.
-        ms_per_launch = kernel_ms_total / max(launches, 1)
-        per_launch_interactions = float(n) * float(n) * args.steps / max(launches, 1) / world
-        achieved_tflops = flops_per * per_launch_interactions / (ms_per_launch * 1e-3) / 1e12
+        value = float(n) * float(n) * args.steps / elapsed
         plan = pkg.plan(n // world, n, dtype)
         pair = pkg.pair_plan(n, dtype) if (pairwise and world == 1) else None
+        layout_name = "pairwise" if pairwise else ("one-sided" if args.mode == "fast" else "strict")
+        # the dominant kernel's own duration: the pairwise step is two kernels (pair_forces, pair_finish), timed separately AFTER
+        # the timed region with an event the library records between them; every other single-GPU step is one kernel
+        forces_ms = finish_ms = None
+        if pair is not None and not distributed:
+            forces_ms, finish_ms = pair_kernel_split(pkg, lib, step, stream_ptr)
+        dominant_ms = forces_ms if forces_ms is not None else stream_ms_per_step
+        algorithmic_flops = flops_per * float(n) * float(n) / world  # per launch of the dominant kernel(s) of one rank's step
+        achieved_tflops = algorithmic_flops / (dominant_ms * 1e-3) / 1e12
         # HBM traffic cannot be counted from inside this process: it comes from the separate rocprofv3 --pmc passes
         # of this same command (tools/profile.sh -> tools/summarize_prof.py), committed under profiles/.
         traffic, traffic_src = None, None
@@ -660,6 +623,40 @@ def main():
                     traffic_src = os.path.relpath(found[-1], ROOT)
                 else:
                     traffic_src = f"{os.path.relpath(found[-1], ROOT)} was taken with another launch plan: re-run tools/profile.sh"
+        executed = None
+        if pair is not None:
+            evals = pair_evaluations(pair)
+            per = 36 if args.fp64 else 24
+            executed = {"pair_evaluations_per_launch": evals, "flops_per_pair_evaluation": per,
+                        "tflops": per * evals / (dominant_ms * 1e-3) / 1e12, "frac": per * evals / (dominant_ms * 1e-3) / 1e12 / peak}
+        roofline = {
+            "bound": "valu_fp32_fma" if not args.fp64 else "valu_fp64_fma",
+            "kernel": "pair_forces" if pair is not None else ("one rank's step (all its kernels and waits)" if distributed and world > 1 else "the step's one kernel"),
+            # ALGORITHMIC flop per launch -- 20 (30) x N^2, the reference's convention (compute.cpp:16-18) -- over the
+            # dominant kernel's average duration.  For the pairwise layout this is NOT a utilisation figure (each pair is evaluated
+            # once, so it can pass 1): `executed` holds the flop the kernel really issues and their fraction of the same peak.
+            "achieved": achieved_tflops,
+            "peak": peak,
+            "unit": "TFLOP/s",
+            "frac": achieved_tflops / peak,
+            "frac_counts": "algorithmic flop (reference convention) / peak; executed.frac = flop issued / peak",
+            "executed": executed,
+            "step_frac": flops_per * value / world / 1e12 / peak,  # the same count over the WHOLE step as the driver times it (value)
+            "traffic": traffic,  # HBM bytes per launch, rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes (tools/profile.sh)
+            "traffic_source": traffic_src,
+            "kernel_ms": dominant_ms,
+            "pair_forces_ms": forces_ms,
+            "pair_finish_ms": finish_ms,
+            "stream_ms_per_step": stream_ms_per_step,
+            # achieved / what the one-sided instruction mix can issue at best on the chip (see FP32_ISSUE_CEILING_...); STRICT and the
+            # pairwise layout execute other instruction mixes
+            "issue_ceiling_frac": None if (args.mode != "fast" or pairwise) else value / world / (FP64_ISSUE_CEILING_INTERACTIONS_PER_S if args.fp64 else FP32_ISSUE_CEILING_INTERACTIONS_PER_S),
+            "algorithmic_flops_per_launch": algorithmic_flops,
+            # positions + velocities in and out = 64 (128) bytes per body; what the pairwise layout moves through its
+            # workspace on top of that -- written once by pair_forces, read once by pair_finish -- is stated separately
+            "algorithmic_hbm_bytes_per_launch": (128 if args.fp64 else 64) * (n // world),
+            "workspace_rw_bytes_per_step": (2 * pair.workspace_bytes) if pair is not None else None,
+        }
         line = {
             "metric": "body-body interactions/s, all-pairs N-body step (reference convention N^2 per step)",
             "value": value,
@@ -685,14 +682,16 @@ def main():
                     "REHEARSAL: gloo, host-staged gather, ranks share one GPU" if args.exchange == "host" else
                     "FALLBACK (no RCCL): gloo all-gather of the slices through host memory, one GPU per rank" if args.exchange == "staged" else
                     "REHEARSAL: gloo send/recv rounds (tile schedule) staged through host memory, ranks share one GPU" if args.exchange == "host-tiles" else
-                    ("C-ABI (nb_comm_init_rank + nb_sharded_step_*, csrc/nbody_comm.hip), PAIRWISE across the ranks: each rank evaluates its own slice and "
-                     "the rectangles against ranks r+1 .. r+G/2 once per pair and sends the reaction sums (N/G x 12 B per partner) to their owners; "
-                     "positions all-gathered as G-1 RCCL send/recv tiles on the communicator's high-priority stream" if pairwise else
-                     "C-ABI (nb_comm_init_rank + nb_sharded_step_*, csrc/nbody_comm.hip): RCCL all-gather of the new positions per step, issued as "
-                     "G-1 position tiles (grouped ncclSend/ncclRecv rounds on the communicator's high-priority stream); the kernel of tile k waits "
-                     "only on round k, the own-slice chunk runs first") if capi_rank is not None else
+                    (("REHEARSAL on ONE GPU with the RCCL test double (never a performance number): " if args.rehearse_one_gpu else "") +
+                     ("C-ABI (nb_comm_init_rank + nb_sharded_step_*, csrc/nbody_comm.hip), PAIRWISE across the ranks: each rank evaluates its own slice and "
+                      "the rectangles against ranks r+1 .. r+G/2 once per pair and sends the reaction sums (N/G x 12 B per partner) to their owners; "
+                      "positions all-gathered as G-1 RCCL send/recv tiles on the communicator's high-priority stream" if pairwise else
+                      "C-ABI (nb_comm_init_rank + nb_sharded_step_*, csrc/nbody_comm.hip): RCCL all-gather of the new positions per step, issued as "
+                      "G-1 position tiles (grouped ncclSend/ncclRecv rounds on the communicator's high-priority stream); the kernel of tile k waits "
+                      "only on round k, the own-slice chunk runs first")) if capi_rank is not None else
                     "torch.distributed re-implementation (sharded.py) of the tile schedule: batch_isend_irecv rounds on RCCL's stream" if system.exchange == "tiles" else
                     "torch.distributed (sharded.py): RCCL all_gather_into_tensor of the new positions per step, overlapped with the own-slice j chunk"),
+                "exchange_grouping": None if (capi_rank is None or world == 1) else ("one RCCL group for all G-1 position rounds" if capi_rank.exchange_grouping() else "one RCCL group per position round"),
                 "layout": "pairwise (every pair of bodies evaluated once, reaction sums through a caller-owned workspace)" if pairwise else
                           "one-sided (every directed interaction evaluated, as bodysystemcuda.cu:125-146 does)",
                 "step_entry_point": ("nb_integrate_ws_*" if pairwise else "nb_integrate_shard_*") if not distributed else ("nb_sharded_step_*" if capi_rank is not None else "sharded.py -> nb_integrate_shard_*"),
@@ -702,65 +701,15 @@ def main():
             },
             "gflops": value * flops_per * 1e-9,
             "flops_per_interaction": flops_per,
-            "roofline": {
-                "bound": "valu_fp32_fma" if not args.fp64 else "valu_fp64_fma",
-                "achieved": achieved_tflops,
-                "peak": peak,
-                "unit": "TFLOP/s",
-                "frac": achieved_tflops / peak,
-                "traffic": traffic,  # HBM bytes per launch, rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes (tools/profile.sh)
-                "traffic_source": traffic_src,
-                # achieved / what this instruction mix can issue at best on the chip (see FP32_ISSUE_CEILING_...): how close
-                # the kernel is to ITS ceiling; `frac` above is against the nominal "20 flop" peak
-                # (the ceilings are those of the FAST instruction mix; STRICT executes other, exactly rounded, operations)
-                "issue_ceiling_frac": None if (args.mode != "fast" or pairwise) else value / world / (FP64_ISSUE_CEILING_INTERACTIONS_PER_S if args.fp64 else FP32_ISSUE_CEILING_INTERACTIONS_PER_S),
-                "issue_ceiling_interactions_per_s": None if (args.mode != "fast" or pairwise) else (FP64_ISSUE_CEILING_INTERACTIONS_PER_S if args.fp64 else FP32_ISSUE_CEILING_INTERACTIONS_PER_S),
-                "kernel_ms": ms_per_launch,
-                # pairwise layout: the step is two kernels (pair_forces, pair_finish) and evaluates each pair of bodies once; `achieved` and
-                # `frac` above count the ALGORITHMIC 20 (30) flop per directed interaction of the reference convention (compute.cpp:16-18),
-                # `executed` counts what the kernels really issue: 24 (36) flop per pair evaluation
-                "executed": None if pair is None else {
-                    "pair_evaluations_per_launch": float(pair.blocks) * (pair.blocks // 2 + 1) * pair.block_bodies * pair.block_bodies,
-                    "flops_per_pair_evaluation": 36 if args.fp64 else 24,
-                    "tflops": (36 if args.fp64 else 24) * float(pair.blocks) * (pair.blocks // 2 + 1) * pair.block_bodies * pair.block_bodies / (ms_per_launch * 1e-3) / 1e12,
-                    "frac": (36 if args.fp64 else 24) * float(pair.blocks) * (pair.blocks // 2 + 1) * pair.block_bodies * pair.block_bodies / (ms_per_launch * 1e-3) / 1e12 / peak},
-                "algorithmic_flops_per_launch": flops_per * per_launch_interactions,
-                # positions + velocities in and out; the pairwise layout also writes and reads its reaction slots once
-                "algorithmic_hbm_bytes_per_launch": (128 if args.fp64 else 64) * (n // world) + (2 * pair.workspace_bytes if pair is not None else 0),
-            },
+            "roofline": roofline,
         }
         if not args.no_cpu_baseline and world == 1:
-            O = entry.load_oracle()
-            orc1 = O.Oracle()
-            pos_h, vel_h = orc1.startup_state(n, dtype)
-            # the workload above came from the product's randomise_bodies; the checker's must be the same bytes
-            assert pos_h.tobytes() == pos0.tobytes() and vel_h.tobytes() == vel0.tobytes(), "product and oracle start-up bodies differ"
-            sample = args.cpu_sample_bodies or max(8, min(n, int(2.0e10 // n) // 8 * 8))
-            base = {}
-            # OpenMP leg: the reference's fp32 loop forks INSIDE the j loop (bodysystemcpu.cpp:156-168), i.e. one
-            # fork/join per body j -- it is slow by construction, so it gets a smaller sample and at most the
-            # box's CPU share (16 threads per GPU).
-            for key, omp, smp in (("one_thread", False, sample), ("openmp", True, max(8, sample // 16 // 8 * 8))):
-                orc = O.Oracle(openmp=omp)
-                if omp:
-                    orc.set_num_threads(min(16, os.cpu_count() or 1))
-                ms = orc.benchmark_partial(pos_h, smp)
-                base[key] = {"value": smp * float(n) / (ms * 1e-3), "cores": orc.num_threads() if omp else 1, "ms": ms,
-                             "sample_bodies_i": smp}
-            line["cpu_baseline"] = {
-                "value": base["one_thread"]["value"],
-                "unit": "interactions/s",
-                "cores": 1,
-                "kind": "port",
-                "sample": f"force pass of BodySystemCPU::update (oracle/ port) for the first {sample} bodies i against all {n} bodies j = {sample * n:.3g} "
-                          f"interactions; 1 thread is how the reference ships",
-                "openmp": base["openmp"],
-            }
+            line["cpu_baseline"] = cpu_baseline(n, dtype, pos0, vel0, args.cpu_sample_bodies)
         if world == 1 and not args.no_configs and not args.plan:
             # The other BASELINE configs and the parity-exact mode, timed AFTER the headline measurement (never inside it)
             # so that one driver-run line carries them all.  A failure here costs only this list, never the headline.
             try:
-                line["configs"] = other_configs(pkg, lib, (n, args.fp64, args.mode, "pairwise" if pairwise else ("one-sided" if args.mode == "fast" else "strict")))
+                line["configs"] = other_configs(pkg, lib, (n, args.fp64, args.mode, layout_name))
             except Exception as exc:  # noqa: BLE001
                 line["configs"] = [{"error": repr(exc)}]
             if pairwise:
@@ -770,60 +719,188 @@ def main():
                     line["multi_gpu_kernel_projection"] = rank_projection(pkg, lib, n, dtype, dt, damping, elapsed / args.steps * 1e3)
                 except Exception as exc:  # noqa: BLE001
                     line["multi_gpu_kernel_projection"] = {"error": repr(exc)}
-        print(json.dumps(line), flush=True)
-        if args.dump_state:
-            torch.cuda.synchronize()
-            final = capi_rank.pos[capi_rank.read] if capi_rank is not None else (system.positions().data_ptr() if system is not None else bufs[state["read"]].data_ptr())
-            host = np.zeros(4 * n, dtype)
-            pkg.check(lib.nb_d2h(host.ctypes.data_as(ctypes.c_void_p), final, host.nbytes, None), "nb_d2h")
-            np.savez(args.dump_state, final=host, initial=pos0)  # (the bodies the run started from, too: a test can tell a different start from a different step)
 
-    # Diagnostics for N > 1: the exchange alone and the kernels of one step alone (exposed exchange = step - kernels).
-    # Taken after the timed region, never part of `value`, and printed to STDERR after the JSON line is already out,
-    # so nothing here can cost the result.
-    diagnostics = None
+    if args.dump_state and rank == 0:
+        torch.cuda.synchronize()
+        final = capi_rank.pos[capi_rank.read] if capi_rank is not None else (system.positions().data_ptr() if system is not None else bufs[state["read"]].data_ptr())
+        host = np.zeros(4 * n, dtype)
+        pkg.check(lib.nb_d2h(host.ctypes.data_as(ctypes.c_void_p), final, host.nbytes, None), "nb_d2h")
+        np.savez(args.dump_state, final=host, initial=pos0)  # (the bodies the run started from, too: a test can tell a different start from a different step)
+
+    # ------------------------------------------------------------------------------------------------ N > 1: what explains the number
+    # Everything below runs AFTER the timed region and never touches `value`.  It is collective work on a path that has not met
+    # real multi-GPU hardware yet, so it runs under a watchdog: if it stalls, rank 0 prints the line with what it has and every
+    # rank leaves.  One JSON line either way.
+    printed = threading.Lock()
+
+    def emit(extra=None):
+        if rank == 0 and line is not None and printed.acquire(blocking=False):
+            if extra:
+                line.update(extra)
+            print(json.dumps(line), flush=True)
+
     if world > 1:
-        try:
-            fence()
-            t1 = time.perf_counter()
-            for _ in range(10):
-                if capi_rank is not None:
-                    capi_rank.exchange_once()
-                else:
-                    system.exchange_once(system.positions())
-            torch.cuda.synchronize()
-            exchange_ms = (time.perf_counter() - t1) / 10 * 1e3
-            fence()
-            if capi_rank is not None:
-                cur, nxt, d_vel, d_acc = bufs[capi_rank.read], bufs[1 - capi_rank.read], vel_t, acc_t
-                i0, ni = sharded.slice_of(rank, world, n)
-                schedule = sharded.tile_schedule(rank, world, n, mode == pkg.NB_MODE_STRICT)
-            else:
-                cur, nxt, d_vel, d_acc = system.pos[system.read], system.pos[1 - system.read], system.vel, system.acc
-                i0, ni, schedule = system.i0, system.ni, system.schedule
-            e0, e1 = pkg.Event(), pkg.Event()
-            e0.record(ctypes.c_void_p(stream.cuda_stream))
-            reps = max(2, min(args.steps, 10))
-            for _ in range(reps):
-                for k, (j0, nj, _) in enumerate(schedule):
-                    flags = (pkg.NB_SHARD_ACC_IN if k else 0) | (pkg.NB_SHARD_FINALIZE if k == len(schedule) - 1 else 0)
-                    launch(nxt, cur, d_vel, d_acc, i0, ni, j0, nj, flags)
-            e1.record(ctypes.c_void_p(stream.cuda_stream))
-            e1.synchronize()
-            diagnostics = {"exchange_alone_ms": exchange_ms, "kernels_alone_ms_per_step_rank0": e0.elapsed_ms(e1) / reps,
-                           "launches_per_step_rank0": len(schedule)}
-            fence()
-        except Exception as exc:  # diagnostics must never cost the headline line
-            diagnostics = {"error": repr(exc)}
+        def stalled():
+            emit({"diagnostics_incomplete": f"the post-headline measurements did not finish within {args.diagnostics_timeout:.0f} s"})
+            sys.stderr.write(f"[bench rank {rank}] post-headline measurements stalled: leaving\n")
+            sys.stderr.flush()
+            os._exit(0 if rank == 0 else 3)
 
-    if diagnostics is not None and rank == 0:
-        print("diagnostics: " + json.dumps(diagnostics), file=sys.stderr, flush=True)
+        watchdog = threading.Timer(args.diagnostics_timeout, stalled)
+        watchdog.daemon = True
+        watchdog.start()
+        extra = {}
+        try:
+            seen = [None] * world
+            dist.all_gather_object(seen, dict(capi_rank.info(), pairwise=capi_rank.pairwise(), one_group=capi_rank.exchange_grouping(), workspace_bytes=work_bytes,
+                                              cuda_device=torch.cuda.current_device()) if capi_rank is not None else {"rank": rank, "path": "sharded.py"})
+            extra["ranks_seen"] = seen
+            if not args.no_diagnostics:
+                extra["diagnostics"] = multi_gpu_diagnostics(pkg, lib, dist, torch, args, capi_rank, system, sharded, launch, fence, step, finish, lend, stream_ptr,
+                                                             rank, world, n, dtype, mode, dt, damping, bufs if capi_rank is not None else None,
+                                                             vel_t, acc_t if capi_rank is not None else None, work_t, work_bytes, big, dev)
+        except Exception as exc:  # noqa: BLE001 -- diagnostics must never cost the headline line
+            extra["diagnostics_error"] = repr(exc)
+        watchdog.cancel()
+        configs = extra.get("diagnostics", {}).pop("configs", None) if isinstance(extra.get("diagnostics"), dict) else None
+        if configs:
+            extra["configs"] = configs
+        emit(extra)
+    else:
+        emit()
 
     if capi_rank is not None:
         torch.cuda.synchronize()
         capi_rank.destroy()
     if distributed:
         dist.destroy_process_group()
+
+
+CONFIG3_BODIES = 1048576  # BASELINE.json configs[3]: 1 048 576 bodies over the GPUs of one node
+
+
+def multi_gpu_diagnostics(pkg, lib, dist, torch, args, capi_rank, system, sharded, launch, fence, step, finish, lend, stream_ptr, rank, world, n, dtype, mode, dt, damping,
+                          bufs, vel_t, acc_t, work_t, work_bytes, big, dev):
+    """The same job timed other ways, by every rank together (max over ranks, ms per step): the other exchange grouping, the
+    one-sided tile schedule, the exchange legs alone, the kernels alone; and BASELINE configs[3] through the same entry points.
+    Returns a dict for the JSON line."""
+    def timed(fn, reps):
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        finish()
+        fence()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(f"{float(t.item()) / reps * 1e3:.5g}")
+
+    def stream_timed(fn, reps):
+        """this rank's stream time (HIP events), max over ranks: for work that involves no other rank"""
+        fence()
+        e0, e1 = pkg.Event(), pkg.Event()
+        e0.record(stream_ptr)
+        for _ in range(reps):
+            fn()
+        e1.record(stream_ptr)
+        e1.synchronize()
+        t = torch.tensor([e0.elapsed_ms(e1) / reps], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        fence()
+        return float(f"{float(t.item()):.5g}")
+
+    reps = max(2, min(args.steps, 10))
+    out = {"what": "ms per step, max over ranks, taken after the timed region; not part of `value`", "reps": reps}
+    if capi_rank is None:
+        out["exchange_alone_ms"] = timed(lambda: system.exchange_once(system.positions()), reps)
+        i0, ni, schedule = system.i0, system.ni, system.schedule
+
+        def kernels():
+            for k, (j0, nj, _) in enumerate(schedule):
+                launch(system.pos[1 - system.read], system.pos[system.read], system.vel, system.acc, i0, ni, j0, nj, (pkg.NB_SHARD_ACC_IN if k else 0) | (pkg.NB_SHARD_FINALIZE if k == len(schedule) - 1 else 0))
+
+        out["one_sided_kernels_alone_ms"] = stream_timed(kernels, reps)
+        return out
+
+    was_one_group, was_pairwise = capi_rank.exchange_grouping(), capi_rank.pairwise()
+    label = lambda pw, og: ("pairwise" if pw else "one_sided") + ("_one_group" if og else "_group_per_round")  # noqa: E731
+    steps = {}
+    # (1) the step as timed in the headline, then with the other grouping of the position rounds
+    for og in (was_one_group, not was_one_group):
+        capi_rank.set_exchange_grouping(og)
+        steps[label(was_pairwise, og)] = timed(step, reps)
+    capi_rank.set_exchange_grouping(was_one_group)
+    # (2) the exchange legs on their own
+    out["position_exchange_alone_ms"] = {}
+    for og in (True, False):
+        capi_rank.set_exchange_grouping(og)
+        out["position_exchange_alone_ms"]["one_group" if og else "group_per_round"] = timed(lambda: capi_rank.exchange_once(), reps)
+    capi_rank.set_exchange_grouping(was_one_group)
+    if was_pairwise:
+        out["reaction_exchange_alone_ms"] = timed(capi_rank.reaction_exchange_once, reps)
+        # (3) this rank's kernels alone: exactly what it launches in a pairwise step, no exchange, no waits
+        emulate = lib.nb_emulate_pair_rank_f32 if np.dtype(dtype) == np.float32 else lib.nb_emulate_pair_rank_f64
+        need = ctypes.c_size_t(work_bytes)
+        r = capi_rank.read
+        out["pairwise_kernels_alone_ms"] = stream_timed(lambda: pkg.check(emulate(bufs[1 - r].data_ptr(), bufs[r].data_ptr(), vel_t.data_ptr(), work_t.data_ptr(), ctypes.byref(need), n, world, rank, dt, damping,
+                                                                                 stream_ptr), "nb_emulate_pair_rank"), reps)
+    i0, ni = sharded.slice_of(rank, world, n)
+    schedule = sharded.tile_schedule(rank, world, n, mode == pkg.NB_MODE_STRICT)
+
+    def tile_kernels():
+        r = capi_rank.read
+        for k, (j0, nj, _) in enumerate(schedule):
+            launch(bufs[1 - r], bufs[r], vel_t, acc_t, i0, ni, j0, nj, (pkg.NB_SHARD_ACC_IN if k else 0) | (pkg.NB_SHARD_FINALIZE if k == len(schedule) - 1 else 0))
+
+    out["one_sided_kernels_alone_ms"] = stream_timed(tile_kernels, reps)
+    # (4) the other layout: every rank takes its workspace back (the call is collective) -> the one-sided tile schedule
+    if was_pairwise:
+        capi_rank.set_workspace(None, 0)
+        assert not capi_rank.pairwise()
+        for og in (True, False):
+            capi_rank.set_exchange_grouping(og)
+            steps[label(False, og)] = timed(step, reps)
+        capi_rank.set_exchange_grouping(was_one_group)
+        capi_rank.set_workspace(work_t.data_ptr(), work_bytes)
+        assert capi_rank.pairwise()
+    out["step_ms"] = steps
+    out["headline_was"] = label(was_pairwise, was_one_group)
+    # (5) BASELINE configs[3]: 1 048 576 bodies over the ranks, same communicator, same entry points
+    if big is not None:
+        pos_b, vel_b = big
+        nb = pos_b.size // 4
+        p0 = torch.from_numpy(pos_b.reshape(nb, 4)).to(dev)
+        b_bufs, b_vel, b_acc = [p0, p0.clone()], torch.from_numpy(vel_b.reshape(nb, 4)).to(dev), torch.zeros_like(p0)
+        job = pkg.ShardedRank(None, world, rank, [b.data_ptr() for b in b_bufs], b_vel.data_ptr(), b_acc.data_ptr(), nb, np.float32, mode, 256, stream_ptr, comm=capi_rank.comm)
+        b_work = lend(job.workspace_bytes()) if was_pairwise else None
+        job.set_workspace(b_work.data_ptr() if b_work is not None else None, b_work.numel() if b_work is not None else 0)
+        job.exchange_once(0)
+
+        def big_fence():
+            job.finish()
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+
+        big_step = lambda: job.update(np.float32(dt), np.float32(damping))  # noqa: E731
+        big_step()
+        big_fence()
+        k = 3
+        t0 = time.perf_counter()
+        for _ in range(k):
+            big_step()
+        big_fence()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        ms = float(t.item()) / k * 1e3
+        out["configs"] = [{"workload": "configs[3]" if nb == CONFIG3_BODIES else f"configs[3]'s shape at {nb} bodies (rehearsal)", "bodies": nb, "n_gpus": world, "dtype": "f32", "mode": "fast",
+                           "layout": "pairwise across ranks" if job.pairwise() else "one-sided tiles", "steps": k, "ms_per_step": float(f"{ms:.5g}"),
+                           "interactions_per_s": float(nb) * nb / (ms * 1e-3), "frac": round(20 * float(nb) * nb / (ms * 1e-3) / world / (FP32_VECTOR_PEAK_TFLOPS * 1e12), 4),
+                           "workspace_bytes_per_rank": b_work.numel() if b_work is not None else 0}]
+        # hand the communicator back to the headline system
+        capi_rank.set_workspace(work_t.data_ptr() if work_t is not None else None, work_bytes)
+        job.destroy()
+    return out
 
 
 if __name__ == "__main__":

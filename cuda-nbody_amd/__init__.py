@@ -154,6 +154,8 @@ TUNING_SIGNATURES = {
     "nb_comm_set_pair_min_slice": (_ci, [_ci]),
     "nb_emulate_pair_rank_f32": (_ci, [_vp, _vp, _vp, _vp, _P(_sz), _cu, _ci, _ci, _cf, _cf, _vp]),
     "nb_emulate_pair_rank_f64": (_ci, [_vp, _vp, _vp, _vp, _P(_sz), _cu, _ci, _ci, _cd, _cd, _vp]),
+    "nb_comm_reaction_exchange_f32": (_ci, [_vp, _cu, _vp]),
+    "nb_comm_reaction_exchange_f64": (_ci, [_vp, _cu, _vp]),
     "nb_set_pair_probe_event": (_ci, [_vp]),
     "nb_set_memory_budget": (_ci, [_sz]),
     "nb_lds_optin_count": (_ci, [_P(_ci)]),
@@ -432,7 +434,9 @@ class ShardedRank:
     use of the same entry points (that class drives all local devices from one thread through the *_all form)."""
 
     def __init__(self, unique_id, world: int, rank: int, positions, velocities, acc, num_bodies: int, dtype=np.float32,
-                 mode: int = NB_MODE_FAST, block_size: int = 256, stream=None):
+                 mode: int = NB_MODE_FAST, block_size: int = 256, stream=None, comm=None):
+        """`comm`: an existing communicator to step ANOTHER system with (a communicator is not tied to a system size; the rank that
+        created it keeps the ownership) -- otherwise nb_comm_init_rank makes one from `unique_id`."""
         self.dtype = np.dtype(dtype)
         self.world, self.rank, self.n = int(world), int(rank), int(num_bodies)
         if self.n % self.world:
@@ -440,8 +444,12 @@ class ShardedRank:
         self.pos, self.vel, self.acc = [int(positions[0]), int(positions[1])], int(velocities), int(acc)
         self.mode, self.block_size, self.stream = mode, block_size, stream
         self.read = 0
-        self.comm = _vp()
-        check(lib().nb_comm_init_rank(ctypes.byref(self.comm), unique_id, self.world, self.rank), "nb_comm_init_rank")
+        self.owns_comm = comm is None
+        if comm is None:
+            self.comm = _vp()
+            check(lib().nb_comm_init_rank(ctypes.byref(self.comm), unique_id, self.world, self.rank), "nb_comm_init_rank")
+        else:
+            self.comm = comm
         f32 = self.dtype == np.float32
         self._step = lib().nb_sharded_step_f32 if f32 else lib().nb_sharded_step_f64
         self._tiles = lib().nb_exchange_tiles_f32 if f32 else lib().nb_exchange_tiles_f64
@@ -500,10 +508,15 @@ class ShardedRank:
         """Make the compute stream wait for every tile still in flight (asynchronous; synchronise the stream to block)."""
         check(lib().nb_exchange_wait_all(self.comm, self.stream), "nb_exchange_wait_all")
 
+    def reaction_exchange_once(self) -> None:
+        """nb_comm_reaction_exchange_* (tuning header): the reaction leg of a pairwise step alone; the stream waits for it."""
+        fn = lib().nb_comm_reaction_exchange_f32 if self.dtype == np.float32 else lib().nb_comm_reaction_exchange_f64
+        check(fn(self.comm, self.n, self.stream), "nb_comm_reaction_exchange")
+
     def destroy(self) -> None:
-        if self.comm:
+        if self.comm and self.owns_comm:
             lib().nb_comm_destroy(self.comm)
-            self.comm = _vp()
+        self.comm = _vp()
 
 
 def workspace_bytes(num_bodies: int, dtype=np.float32, mode: int = NB_MODE_FAST) -> int:

@@ -418,12 +418,43 @@ int pair_rank_tiles(Comm* c, unsigned r, int G, const PairShard& plan, T* work, 
     return 0;
 }
 
-template <typename T>
-int pair_sharded_step(const std::vector<Comm*>& locals, const PairShard& plan, T* const* new_pos, const T* const* old_pos, T* const* vel, unsigned num_bodies, T dt, T damping, T eps2, const nb_stream_t* streams) {
+// The reaction leg of a pairwise step: round s = send to rank r+s what was summed for its bodies, receive from r-s what it
+// summed for ours; one RCCL group per round on the exchange stream, round s waiting for react_ready[s] (the fold of rectangle s)
+// and signalling react_arrived[s].
+template <typename T> int reaction_exchange(const std::vector<Comm*>& locals, const PairShard& plan) {
     Rccl* lib = rccl();
     if (lib == nullptr) return NB_ERR_UNSUPPORTED;
-    const int      G      = locals.front()->world;
-    const size_t   plane3 = 3 * static_cast<size_t>(plan.plane);
+    const int    G      = locals.front()->world;
+    const size_t plane3 = 3 * static_cast<size_t>(plan.plane);
+    NB_KEEP_RAND_STREAM;
+    for (unsigned s = 1; s <= plan.H; ++s) {
+        for (Comm* c : locals) {
+            DeviceScope scope(c->device);
+            if (const auto err = hipStreamWaitEvent(c->stream, c->react_ready[s], 0); err != hipSuccess) return static_cast<int>(err);
+        }
+        int rc = lib->GroupStart();
+        for (size_t k = 0; k < locals.size() && rc == 0; ++k) {
+            Comm*     c    = locals[k];
+            T* const  work = static_cast<T*>(c->workspace);
+            const int to = (c->rank + static_cast<int>(s)) % G, from = (c->rank - static_cast<int>(s) + G) % G;
+            rc              = lib->Send(work + plan.send_at + (s - 1) * plane3, plane3, Api<T>::nccl_type, to, c->nccl, c->stream);
+            if (rc == 0) rc = lib->Recv(work + plan.recv_at + (s - 1) * plane3, plane3, Api<T>::nccl_type, from, c->nccl, c->stream);
+        }
+        const int end = lib->GroupEnd();
+        if (rc == 0) rc = end;
+        if (rc != 0) return nccl_status(rc);
+        for (Comm* c : locals) {
+            DeviceScope scope(c->device);
+            if (const auto err = hipEventRecord(c->react_arrived[s], c->stream); err != hipSuccess) return static_cast<int>(err);
+        }
+    }
+    return 0;
+}
+
+template <typename T>
+int pair_sharded_step(const std::vector<Comm*>& locals, const PairShard& plan, T* const* new_pos, const T* const* old_pos, T* const* vel, unsigned num_bodies, T dt, T damping, T eps2, const nb_stream_t* streams) {
+    if (rccl() == nullptr) return NB_ERR_UNSUPPORTED;
+    const int G = locals.front()->world;
     std::vector<nb::FinishArgs<T>> finish(locals.size());
     for (size_t k = 0; k < locals.size(); ++k) {
         Comm*       c = locals[k];
@@ -433,31 +464,7 @@ int pair_sharded_step(const std::vector<Comm*>& locals, const PairShard& plan, T
                                             reinterpret_cast<hipStream_t>(streams[k]), waiting, finish[k], c->aux, c->aux_begin, c->aux_done);
         if (rc != 0) return rc;
     }
-    // the reaction exchange: round s = send to r+s what was summed for its bodies, receive from r-s; one RCCL group per round
-    {
-        NB_KEEP_RAND_STREAM;
-        for (unsigned s = 1; s <= plan.H; ++s) {
-            for (Comm* c : locals) {
-                DeviceScope scope(c->device);
-                if (const auto err = hipStreamWaitEvent(c->stream, c->react_ready[s], 0); err != hipSuccess) return static_cast<int>(err);
-            }
-            int rc = lib->GroupStart();
-            for (size_t k = 0; k < locals.size() && rc == 0; ++k) {
-                Comm*     c    = locals[k];
-                T* const  work = static_cast<T*>(c->workspace);
-                const int to = (c->rank + static_cast<int>(s)) % G, from = (c->rank - static_cast<int>(s) + G) % G;
-                rc              = lib->Send(work + plan.send_at + (s - 1) * plane3, plane3, Api<T>::nccl_type, to, c->nccl, c->stream);
-                if (rc == 0) rc = lib->Recv(work + plan.recv_at + (s - 1) * plane3, plane3, Api<T>::nccl_type, from, c->nccl, c->stream);
-            }
-            const int end = lib->GroupEnd();
-            if (rc == 0) rc = end;
-            if (rc != 0) return nccl_status(rc);
-            for (Comm* c : locals) {
-                DeviceScope scope(c->device);
-                if (const auto err = hipEventRecord(c->react_arrived[s], c->stream); err != hipSuccess) return static_cast<int>(err);
-            }
-        }
-    }
+    if (const int rc = reaction_exchange<T>(locals, plan); rc != 0) return rc;
     for (size_t k = 0; k < locals.size(); ++k) {
         Comm*       c = locals[k];
         DeviceScope scope(c->device);
@@ -608,6 +615,25 @@ template <typename T> int emulate_pair_rank(T* new_pos, const T* old_pos, T* vel
     const int rc = pair_rank_tiles<T>(nullptr, static_cast<unsigned>(rank), world, plan, static_cast<T*>(workspace), new_pos, old_pos, vel, num_bodies, dt, damping, eps2, s, false, f, aux[dev], begin[dev], done[dev]);
     if (rc != 0) return rc;
     return static_cast<int>(nb::launch_pair_finish<T>(f, s));
+}
+
+// Tuning hook: the reaction leg alone (what a pairwise step adds to the exchange), on whatever the workspace holds.
+template <typename T> int reaction_exchange_only(nb_comm_t comm, unsigned num_bodies, nb_stream_t stream) {
+    Comm* c = as_comm(comm);
+    if (c == nullptr || c->group.size() != 1) return NB_ERR_INVALID_ARGUMENT;
+    std::vector<Comm*> locals{c};
+    PairShard          plan;
+    if (!step_is_pairwise<T>(locals, num_bodies, NB_MODE_FAST, &plan)) return NB_ERR_UNSUPPORTED;
+    DeviceScope scope(c->device);
+    hipStream_t on = reinterpret_cast<hipStream_t>(stream);
+    for (unsigned s = 1; s <= plan.H; ++s) {
+        if (const auto err = hipEventRecord(c->react_ready[s], on); err != hipSuccess) return static_cast<int>(err);
+    }
+    if (const int rc = reaction_exchange<T>(locals, plan); rc != 0) return rc;
+    for (unsigned s = 1; s <= plan.H; ++s) {
+        if (const auto err = hipStreamWaitEvent(on, c->react_arrived[s], 0); err != hipSuccess) return static_cast<int>(err);
+    }
+    return 0;
 }
 
 template <typename T> int comm_layout(nb_comm_t comm, unsigned num_bodies, int mode, int* pairwise) {
@@ -800,6 +826,8 @@ int nb_emulate_pair_rank_f64(double* new_positions, const double* old_positions,
     (void)nb_get_softening_sq_f64(&eps2);
     return emulate_pair_rank<double>(new_positions, old_positions, velocities, workspace, workspace_bytes, num_bodies, world_size, rank, dt, damping, eps2, stream);
 }
+int nb_comm_reaction_exchange_f32(nb_comm_t comm, unsigned num_bodies, nb_stream_t stream) { return reaction_exchange_only<float>(comm, num_bodies, stream); }
+int nb_comm_reaction_exchange_f64(nb_comm_t comm, unsigned num_bodies, nb_stream_t stream) { return reaction_exchange_only<double>(comm, num_bodies, stream); }
 int nb_comm_set_pair_min_slice(int min_bodies_per_rank) {
     if (min_bodies_per_rank < 0) return NB_ERR_INVALID_ARGUMENT;
     g_pair_shard_min.store(min_bodies_per_rank);

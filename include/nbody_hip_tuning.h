@@ -36,6 +36,12 @@ NB_API int nb_emulate_pair_rank_f32(float* new_positions, const float* old_posit
 NB_API int nb_emulate_pair_rank_f64(double* new_positions, const double* old_positions, double* velocities, void* workspace, size_t* workspace_bytes,
                                     unsigned num_bodies, int world_size, int rank, double delta_time, double damping, nb_stream_t stream);
 
+/* The reaction leg of a pairwise multi-GPU step on its own (one process per rank; the communicator's layout must be pairwise for
+ * this system): the G/2 send/recv rounds of N/G x 12 B that carry reaction sums to their owners, on whatever the workspace holds
+ * -- bench.py's diagnostics time it to say what the second exchange leg costs.  A collective like the step itself. */
+NB_API int nb_comm_reaction_exchange_f32(nb_comm_t comm, unsigned num_bodies, nb_stream_t stream);
+NB_API int nb_comm_reaction_exchange_f64(nb_comm_t comm, unsigned num_bodies, nb_stream_t stream);
+
 /* An event recorded between the forces kernel and the finish kernel of every ONE-GPU pairwise step from now on (NULL = none):
  * bench.py times the two kernels of the headline step separately with it, after the timed region. */
 NB_API int nb_set_pair_probe_event(nb_event_t event);

@@ -15,8 +15,19 @@
 // (ncclCommInitRank model) waits for the peer threads exactly as with the real library.  A counterpart that does not
 // show up within FAKE_RCCL_TIMEOUT_S (default 60 s) is reported as ncclInternalError rather than hanging the test.
 //
+// ACROSS PROCESSES (round 4; FAKE_RCCL_IPC=1 in the environment of every rank): one process per rank, as bench.py and
+// `torch.distributed.run` start them, all on the one GPU.  The ranks then meet through files under /dev/shm named after the
+// unique id: a send is "synchronise the stream, copy the buffer to the host, publish it as <id>_<src>_<dst>_<sequence>"; a
+// receive waits for that file (FAKE_RCCL_TIMEOUT_S), copies it to the device and removes it.  Everything happens inside
+// ncclGroupEnd / the ungrouped call, sends before receives, so no order of arrival can deadlock.  Host-synchronous on purpose:
+// it rehearses the CODE PATH of an N-process job (ids, groups, rounds, who waits for what), never its timing.
+//
 // Build: tests/fake_rccl/Makefile -> tests/fake_rccl/libfake_rccl.so.
 #include <hip/hip_runtime_api.h>
+
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <atomic>
@@ -29,9 +40,13 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <string>
+#include <thread>
 #include <vector>
 
 #define FAKE_API extern "C" __attribute__((visibility("default")))
+
+struct ncclComm;
 
 namespace {
 
@@ -47,6 +62,7 @@ struct Op {
     hipStream_t stream  = nullptr;
     bool        done    = false;
     int         status  = kSuccess;
+    struct ::ncclComm* ipc_comm = nullptr;  // FAKE_RCCL_IPC: the communicator of a cross-process operation (no World)
 };
 
 struct Gather {
@@ -77,6 +93,11 @@ struct ncclComm {
     World* world  = nullptr;
     int    rank   = 0;
     int    device = 0;
+    // across processes (FAKE_RCCL_IPC=1): no shared World -- the key of the unique id names the files the ranks meet through
+    bool                  ipc  = false;
+    int                   size = 1;
+    uint64_t              key  = 0;
+    std::vector<uint64_t> sent, received;  // per peer: messages so far (the sequence number a send/receive pair agrees on)
 };
 using ncclComm_t = ncclComm*;
 struct ncclUniqueId {
@@ -186,7 +207,85 @@ void match_all(World& world) {
     world.changed.notify_all();
 }
 
+// ---- across processes: messages as files under /dev/shm ---------------------------------------------------------------------
+bool ipc_mode() {
+    const char* v = std::getenv("FAKE_RCCL_IPC");
+    return v != nullptr && v[0] == '1';
+}
+
+std::string ipc_name(uint64_t key, int src, int dst, uint64_t sequence) {
+    return "/dev/shm/fake_rccl_" + std::to_string(key) + "_" + std::to_string(src) + "_" + std::to_string(dst) + "_" + std::to_string(sequence);
+}
+
+int ipc_send(const Op& op) {
+    ncclComm& c = *op.ipc_comm;
+    OnDevice  scope(op.device);
+    if (hipStreamSynchronize(op.stream) != hipSuccess) return kUnhandledCudaError;  // what the send reads has been produced
+    std::vector<char> host(op.bytes);
+    if (op.bytes != 0 && hipMemcpy(host.data(), op.buffer, op.bytes, hipMemcpyDeviceToHost) != hipSuccess) return kUnhandledCudaError;
+    const std::string name = ipc_name(c.key, c.rank, op.peer, c.sent[static_cast<size_t>(op.peer)]++), tmp = name + ".tmp";
+    const int         fd   = ::open(tmp.c_str(), O_CREAT | O_WRONLY | O_TRUNC, 0600);
+    if (fd < 0) return kSystemError;
+    size_t done = 0;
+    while (done < host.size()) {
+        const ssize_t w = ::write(fd, host.data() + done, host.size() - done);
+        if (w <= 0) {
+            ::close(fd);
+            return kSystemError;
+        }
+        done += static_cast<size_t>(w);
+    }
+    ::close(fd);
+    return ::rename(tmp.c_str(), name.c_str()) == 0 ? kSuccess : kSystemError;  // published atomically: a reader never sees half a message
+}
+
+int ipc_recv(const Op& op) {
+    ncclComm&         c    = *op.ipc_comm;
+    const std::string name = ipc_name(c.key, op.peer, c.rank, c.received[static_cast<size_t>(op.peer)]++);
+    const auto        deadline = std::chrono::steady_clock::now() + std::chrono::duration<double>(timeout_seconds());
+    int               fd   = -1;
+    while ((fd = ::open(name.c_str(), O_RDONLY)) < 0) {
+        if (std::chrono::steady_clock::now() > deadline) return kInternalError;  // the counterpart never came
+        std::this_thread::sleep_for(std::chrono::microseconds(200));
+    }
+    struct stat st {};
+    if (::fstat(fd, &st) != 0 || static_cast<size_t>(st.st_size) != op.bytes) {
+        ::close(fd);
+        ::unlink(name.c_str());
+        return kInvalidArgument;  // the two sides disagree about the size of the message
+    }
+    std::vector<char> host(op.bytes);
+    size_t            done = 0;
+    while (done < host.size()) {
+        const ssize_t r = ::read(fd, host.data() + done, host.size() - done);
+        if (r <= 0) break;
+        done += static_cast<size_t>(r);
+    }
+    ::close(fd);
+    ::unlink(name.c_str());
+    if (done != host.size()) return kSystemError;
+    OnDevice scope(op.device);
+    if (hipStreamSynchronize(op.stream) != hipSuccess) return kUnhandledCudaError;  // earlier readers of the buffer on this stream are done
+    if (op.bytes != 0 && hipMemcpy(op.buffer, host.data(), op.bytes, hipMemcpyHostToDevice) != hipSuccess) return kUnhandledCudaError;
+    g_copies.fetch_add(1);
+    return kSuccess;
+}
+
+int ipc_post_and_wait(std::vector<std::pair<World*, std::shared_ptr<Op>>>& ops) {
+    int status = kSuccess;
+    for (const bool sends : {true, false}) {  // every send of the group first: whatever order the ranks arrive in, nobody waits for a message not yet written
+        for (auto& [world, op] : ops) {
+            if (op->is_send != sends) continue;
+            const int rc = sends ? ipc_send(*op) : ipc_recv(*op);
+            if (rc != kSuccess && status == kSuccess) status = rc;
+        }
+    }
+    ops.clear();
+    return status;
+}
+
 int post_and_wait(std::vector<std::pair<World*, std::shared_ptr<Op>>>& ops) {
+    if (!ops.empty() && ops.front().second->ipc_comm != nullptr) return ipc_post_and_wait(ops);
     // post everything first (a single thread driving all ranks has every counterpart in this very list), then wait
     std::vector<World*> worlds;
     for (auto& [world, op] : ops) {
@@ -218,11 +317,12 @@ int post_and_wait(std::vector<std::pair<World*, std::shared_ptr<Op>>>& ops) {
 }
 
 int enqueue(bool is_send, void* buffer, size_t count, int type, int peer, ncclComm_t comm, hipStream_t stream) {
-    if (comm == nullptr || comm->world == nullptr || peer < 0 || peer >= comm->world->size || type_bytes(type) == 0) return kInvalidArgument;
+    if (comm == nullptr || (comm->world == nullptr && !comm->ipc) || peer < 0 || peer >= (comm->ipc ? comm->size : comm->world->size) || type_bytes(type) == 0) return kInvalidArgument;
     if (buffer == nullptr && count != 0) return kInvalidArgument;
     auto op     = std::make_shared<Op>();
     op->is_send = is_send, op->rank = comm->rank, op->peer = peer, op->device = comm->device;
     op->buffer = buffer, op->bytes = count * type_bytes(type), op->stream = stream;
+    op->ipc_comm = comm->ipc ? comm : nullptr;
     (is_send ? g_sends : g_recvs).fetch_add(1);
     t_group_ops.emplace_back(comm->world, std::move(op));
     if (t_group_depth > 0) return kSuccess;
@@ -267,13 +367,30 @@ FAKE_API int ncclGetUniqueId(ncclUniqueId* id) {
     if (id == nullptr) return kInvalidArgument;
     std::memset(id->internal, 0, sizeof(id->internal));
     std::memcpy(id->internal, "FAKERCCL", 8);
-    const uint64_t key = g_next_id.fetch_add(1);
+    uint64_t key = g_next_id.fetch_add(1);
+    if (ipc_mode()) {  // across processes the key must be unique on the machine, not in the process
+        key = (static_cast<uint64_t>(::getpid()) << 32) ^ static_cast<uint64_t>(std::chrono::steady_clock::now().time_since_epoch().count()) ^ (key << 56);
+        if (key == 0) key = 1;
+        id->internal[16] = 'I';
+    }
     std::memcpy(id->internal + 8, &key, sizeof(key));
     return kSuccess;
 }
 
 FAKE_API int ncclCommInitRank(ncclComm_t* comm, int nranks, ncclUniqueId id, int rank) {
     if (comm == nullptr || nranks < 1 || rank < 0 || rank >= nranks) return kInvalidArgument;
+    if (id.internal[16] == 'I' && std::memcmp(id.internal, "FAKERCCL", 8) == 0) {  // one process per rank: no shared World
+        auto* c = new ncclComm;
+        c->ipc = true, c->size = nranks, c->rank = rank;
+        std::memcpy(&c->key, id.internal + 8, sizeof(c->key));
+        c->sent.assign(static_cast<size_t>(nranks), 0), c->received.assign(static_cast<size_t>(nranks), 0);
+        if (hipGetDevice(&c->device) != hipSuccess) {
+            delete c;
+            return kUnhandledCudaError;
+        }
+        *comm = c;
+        return kSuccess;
+    }
     World* world = world_of_id(id, nranks);
     if (world == nullptr) return kInvalidArgument;
     auto* c  = new ncclComm;
@@ -310,7 +427,7 @@ FAKE_API int ncclCommInitAll(ncclComm_t* comms, int ndev, const int* devlist) {
 
 FAKE_API int ncclCommDestroy(ncclComm_t comm) {
     if (comm == nullptr) return kInvalidArgument;
-    leave(comm->world);
+    if (!comm->ipc) leave(comm->world);
     delete comm;
     return kSuccess;
 }
@@ -338,6 +455,24 @@ FAKE_API int ncclRecv(void* recvbuff, size_t count, int datatype, int peer, nccl
 // recvbuff of every rank = the ranks' sendbuffs in rank order (in place when sendbuff == recvbuff + rank * bytes).
 // The last rank to arrive issues every copy; each stream then waits until all copies that read or write its buffers are done.
 FAKE_API int ncclAllGather(const void* sendbuff, void* recvbuff, size_t sendcount, int datatype, ncclComm_t comm, hipStream_t stream) {
+    if (comm != nullptr && comm->ipc) {  // across processes: the collective as its send/recv pairs
+        if (type_bytes(datatype) == 0 || sendbuff == nullptr || recvbuff == nullptr) return kInvalidArgument;
+        g_gathers.fetch_add(1);
+        const size_t bytes = sendcount * type_bytes(datatype);
+        char*        own   = static_cast<char*>(recvbuff) + static_cast<size_t>(comm->rank) * bytes;
+        if (own != sendbuff && bytes != 0 && hipMemcpyAsync(own, sendbuff, bytes, hipMemcpyDeviceToDevice, stream) != hipSuccess) return kUnhandledCudaError;
+        ++t_group_depth;
+        int rc = kSuccess;
+        for (int p = 0; p < comm->size && rc == kSuccess; ++p) {
+            if (p == comm->rank) continue;
+            rc = enqueue(true, const_cast<void*>(sendbuff), sendcount, datatype, p, comm, stream);
+            if (rc == kSuccess) rc = enqueue(false, static_cast<char*>(recvbuff) + static_cast<size_t>(p) * bytes, sendcount, datatype, p, comm, stream);
+        }
+        --t_group_depth;
+        if (t_group_depth > 0) return rc;
+        const int end = post_and_wait(t_group_ops);
+        return rc != kSuccess ? rc : end;
+    }
     if (comm == nullptr || comm->world == nullptr || type_bytes(datatype) == 0 || sendbuff == nullptr || recvbuff == nullptr) return kInvalidArgument;
     World&                       world = *comm->world;
     std::unique_lock<std::mutex> lock(world.mutex);

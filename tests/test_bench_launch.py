@@ -105,25 +105,65 @@ def test_default_line_carries_every_baseline_config():
             (1024, "f32", "fast", "one-sided"), (1024, "f32", "strict", "strict"), (262144, "f32", "fast", "one-sided")} <= got
     assert (262144, "f32", "fast", "pairwise") not in got  # that one IS the headline
     assert line["config"]["step_entry_point"] == "nb_integrate_ws_*" and line["config"]["kernel_plan"]["layout"] == "pairwise"
-    assert line["roofline"]["executed"]["frac"] < line["roofline"]["frac"]
+    roof = line["roofline"]
+    assert roof["executed"]["frac"] < roof["frac"] and roof["executed"]["frac"] < 1
+    # the dominant kernel is timed on its own (an event between the two launches of a step); the two kernels add up to the step
+    assert roof["kernel"] == "pair_forces" and roof["kernel_ms"] == roof["pair_forces_ms"] > 10 * roof["pair_finish_ms"] > 0
+    assert abs(roof["pair_forces_ms"] + roof["pair_finish_ms"] - roof["stream_ms_per_step"]) < 0.05 * roof["stream_ms_per_step"]
+    assert roof["step_frac"] <= roof["frac"]
+    # algorithmic HBM bytes are the bodies in and out; the workspace traffic is stated next to them
+    assert roof["algorithmic_hbm_bytes_per_launch"] == 64 * 262144
+    assert roof["workspace_rw_bytes_per_step"] == 2 * line["config"]["kernel_plan"]["workspace_bytes"]
     projection = line["multi_gpu_kernel_projection"]
     assert "PROJECTION" in projection["what"] and set(projection["ranks"]) == {"2", "4", "8"}
     assert projection["ranks"]["8"]["kernel_ms"] < projection["ranks"]["2"]["kernel_ms"] < line["ms_per_step"]
     for c in line["configs"]:
         assert c["ms_per_step"] > 0 and 0 < c["frac"] < 1.3  # (pairwise: the algorithmic count may pass the one-sided peak)
+        assert 0 < c["executed_frac"] < 1  # ... which is why the flop really issued stand next to it, and never pass 1
+        assert (c["executed_frac"] < c["frac"]) == (c["layout"] == "pairwise")
+    f64 = next(c for c in line["configs"] if (c["bodies"], c["dtype"], c["layout"]) == (262144, "f64", "pairwise"))
+    assert f64["executed_frac"] < 0.8
 
 
 @pytest.mark.gpu
 def test_emulated_rank_of_a_pairwise_multi_gpu_step():
-    """`bench.py --emulate-gpus 8`: one rank's kernels of the pairwise step across 8 ranks (nb_emulate_pair_rank_*), timed on the
-    one GPU -- the compute side of the strong-scaling projection; and the one-sided tile schedule for comparison."""
-    out = run_bench("--emulate-gpus", "8", "--steps", "5", "--warmup", "1", "--no-cpu-baseline")
-    assert out.returncode == 0, out.stderr[-3000:]
-    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    """`tools/kernel_sweeps.py --emulate-gpus 8`: one rank's kernels of the pairwise step across 8 ranks (nb_emulate_pair_rank_*),
+    timed on the one GPU -- the compute side of the strong-scaling projection; and the one-sided tile schedule for comparison."""
+    def sweep(*flags):
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "kernel_sweeps.py"), "--emulate-gpus", "8", "--steps", "5", "--warmup", "1", *flags],
+                             capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-3000:]
+        return json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+
+    line = sweep()
     assert line["emulated_gpus"] == 8 and "pairwise" in line["schedule"] and len(line["ranks"]) == 3
     pair_ms = max(r["ms_per_step_kernels_only"] for r in line["ranks"])
-    out = run_bench("--emulate-gpus", "8", "--steps", "5", "--warmup", "1", "--no-cpu-baseline", "--layout", "one-sided")
-    assert out.returncode == 0, out.stderr[-3000:]
-    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
-    one_ms = max(r["ms_per_step_kernels_only"] for r in line["ranks"])
+    one_ms = max(r["ms_per_step_kernels_only"] for r in sweep("--layout", "one-sided")["ranks"])
     assert 0 < pair_ms < one_ms
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ranks", [2, 4])
+def test_n_rank_line_rehearsed_on_one_gpu_through_the_capi(ranks):
+    """`bench.py --gpus N --rehearse-one-gpu`: N PROCESSES (as the driver starts them), each through the product's own multi-GPU
+    entry points -- nb_comm_unique_id on rank 0 and its broadcast, nb_comm_init_rank, the collective nb_comm_set_workspace,
+    nb_sharded_step_* -- with RCCL replaced by the cross-process test double, all on the one GPU.  Never a performance number;
+    what it shows is that the N > 1 line comes out whole: the layout the communicator agreed on, what every rank's communicator
+    says about itself, the A/B timings of the diagnostics (both exchange groupings x both layouts, the exchange legs alone, the
+    kernels alone) and BASELINE configs[3]'s shape through the same communicator."""
+    out = run_bench("--gpus", str(ranks), "--rehearse-one-gpu", "--steps", "3", "--warmup", "1", "--bodies", "16384", "--no-cpu-baseline")
+    assert out.returncode == 0, out.stderr[-4000:]
+    line = _metric_line(out.stdout)
+    assert line["n_gpus"] == ranks and line["exchange_fallback"] is False and line["value"] > 0
+    assert line["config"]["step_entry_point"] == "nb_sharded_step_*" and "REHEARSAL" in line["config"]["exchange"] and "PAIRWISE" in line["config"]["exchange"]
+    assert line["config"]["exchange_grouping"].startswith("one RCCL group for all")
+    seen = line["ranks_seen"]
+    assert [r["rank"] for r in seen] == list(range(ranks)) and all(r["world"] == ranks and r["pairwise"] and r["one_group"] and r["workspace_bytes"] > 0 for r in seen)
+    diag = line["diagnostics"]
+    assert set(diag["step_ms"]) == {"pairwise_one_group", "pairwise_group_per_round", "one_sided_one_group", "one_sided_group_per_round"} and diag["headline_was"] == "pairwise_one_group"
+    assert all(v > 0 for v in diag["step_ms"].values())
+    assert set(diag["position_exchange_alone_ms"]) == {"one_group", "group_per_round"} and diag["reaction_exchange_alone_ms"] > 0
+    assert 0 < diag["pairwise_kernels_alone_ms"] and 0 < diag["one_sided_kernels_alone_ms"]
+    (big,) = line["configs"]
+    assert big["bodies"] == 65536 and big["n_gpus"] == ranks and big["layout"] == "pairwise across ranks" and big["ms_per_step"] > 0 and big["workspace_bytes_per_rank"] > 0
+    assert "diagnostics_incomplete" not in line and "diagnostics_error" not in line
