@@ -586,6 +586,13 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    if args.dump_state and rank == 0:  # (the state after exactly warmup + steps steps: before anything below steps the system further)
+        torch.cuda.synchronize()
+        final = capi_rank.pos[capi_rank.read] if capi_rank is not None else (system.positions().data_ptr() if system is not None else bufs[state["read"]].data_ptr())
+        host = np.zeros(4 * n, dtype)
+        pkg.check(lib.nb_d2h(host.ctypes.data_as(ctypes.c_void_p), final, host.nbytes, None), "nb_d2h")
+        np.savez(args.dump_state, final=host, initial=pos0)  # (the bodies the run started from, too: a test can tell a different start from a different step)
+
     # ------------------------------------------------------------------------------------------------ after it: the line
     line = None
     if rank == 0:
@@ -719,13 +726,6 @@ def main():
                     line["multi_gpu_kernel_projection"] = rank_projection(pkg, lib, n, dtype, dt, damping, elapsed / args.steps * 1e3)
                 except Exception as exc:  # noqa: BLE001
                     line["multi_gpu_kernel_projection"] = {"error": repr(exc)}
-
-    if args.dump_state and rank == 0:
-        torch.cuda.synchronize()
-        final = capi_rank.pos[capi_rank.read] if capi_rank is not None else (system.positions().data_ptr() if system is not None else bufs[state["read"]].data_ptr())
-        host = np.zeros(4 * n, dtype)
-        pkg.check(lib.nb_d2h(host.ctypes.data_as(ctypes.c_void_p), final, host.nbytes, None), "nb_d2h")
-        np.savez(args.dump_state, final=host, initial=pos0)  # (the bodies the run started from, too: a test can tell a different start from a different step)
 
     # ------------------------------------------------------------------------------------------------ N > 1: what explains the number
     # Everything below runs AFTER the timed region and never touches `value`.  It is collective work on a path that has not met
