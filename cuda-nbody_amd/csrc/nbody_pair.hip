@@ -43,6 +43,15 @@
 
 #include <algorithm>
 
+#ifdef NB_PAIR_STAMPS
+// Diagnostic build only (tools/build_pair_variant.sh stamps "-DNB_PAIR_STAMPS", read by tools/pair_stamps.py): per wave of the LAST
+// pair_forces launch, {start, entry of the unit loop, its exit} in s_memtime ticks + where the hardware put the wave.
+__device__ unsigned long long nb_pair_stamps[8192 * 6];
+extern "C" __attribute__((visibility("default"))) int nb_debug_read_pair_stamps(void* host, size_t bytes) {
+    return static_cast<int>(hipMemcpyFromSymbol(host, HIP_SYMBOL(nb_pair_stamps), bytes, 0, hipMemcpyDeviceToHost));
+}
+#endif
+
 namespace nb {
 namespace {
 
@@ -98,6 +107,9 @@ template <typename T, int R, int S> __global__ __launch_bounds__(64 * S) __attri
     constexpr int UNR   = NB_PAIR_UNR;  // steps per trip of the rotation loop
 
     extern __shared__ __attribute__((aligned(32))) unsigned char smem_raw[];
+#ifdef NB_PAIR_STAMPS
+    const unsigned long long stamp_start = __builtin_amdgcn_s_memtime();
+#endif
 
     const vec4* __restrict__ old_pos = reinterpret_cast<const vec4*>(s.old_pos);
     const int      tid  = threadIdx.x;
@@ -245,6 +257,9 @@ template <typename T, int R, int S> __global__ __launch_bounds__(64 * S) __attri
         }
     };
 
+#ifdef NB_PAIR_STAMPS
+    const unsigned long long stamp_loop = __builtin_amdgcn_s_memtime();
+#endif
     vec4 cur = g < n_units ? load_tile(g) : vec4{};
     for (unsigned u = g; u < n_units; u += G) {
         const vec4 next = (u + G) < n_units ? load_tile(u + G) : cur;  // in flight across the 64 steps below
@@ -304,6 +319,20 @@ template <typename T, int R, int S> __global__ __launch_bounds__(64 * S) __attri
     }
     if (lane == 0) mine[slot] = 0xffffffffu;  // finished: never the one the others defer to
     __builtin_amdgcn_s_setprio(0);
+#ifdef NB_PAIR_STAMPS
+    {
+        const unsigned long long stamp_done = __builtin_amdgcn_s_memtime();
+        const unsigned           hw         = static_cast<unsigned>(__builtin_amdgcn_s_getreg((15 << 11) | (0 << 6) | 4));   // HW_ID[15:0]
+        const unsigned           xcc        = static_cast<unsigned>(__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20));   // XCC_ID
+        const unsigned           w          = blockIdx.x * S + static_cast<unsigned>(wave);
+        if (lane == 0 && w < 8192) {
+            nb_pair_stamps[w * 6 + 0] = stamp_start, nb_pair_stamps[w * 6 + 1] = stamp_loop, nb_pair_stamps[w * 6 + 2] = stamp_done;
+            nb_pair_stamps[w * 6 + 3] = (static_cast<unsigned long long>(xcc) << 32) | hw;
+            nb_pair_stamps[w * 6 + 4] = (static_cast<unsigned long long>(wave) << 32) | done;
+            nb_pair_stamps[w * 6 + 5] = (static_cast<unsigned long long>(simd) << 32) | slot;
+        }
+    }
+#endif
     {  // absolute units from here on
         const vec to_absolute = LT::splat(unit);
 #pragma unroll
