@@ -10,6 +10,9 @@
 //        added into the home lane through the complementary rotation (v_add_f32_dpp row_ror:16-k)
 //   H  : positions read through DPP sources, reaction sums rotate (6 v_mov_b32_dpp)
 //   ONE: the one-sided loop on the same data layout (body j per lane, no reaction) -- the wave-split kernel's loop
+//   L  : (round 4) nothing rotates on the vector ALU: the 64 bodies j of a tile sit in a per-wave LDS buffer (twice, so that no
+//        index wraps); at step k lane l reads body l+k (one ds_read_b128, requested a step ahead) and adds its packed reaction
+//        term, halves summed (3 v_add_f32), into the body's LDS sums (3 ds_add_f32, no return) -- 9 DPP moves less per step
 // Reports true shader cycles (s_memtime) per rotation step and per DIRECTED interaction, per SIMD.
 //
 //   hipcc -O3 --offload-arch=gfx950 tools/sym_microbench.hip -o tools/sym_microbench && tools/sym_microbench
@@ -36,7 +39,7 @@ struct Out {
     float              check;
 };
 
-enum { kB = 0, kA = 1, kH = 2, kOne = 3, kBW = 4 };  // kBW: as B but a full 64-lane rotation (DPP wave_ror:1)
+enum { kB = 0, kA = 1, kH = 2, kOne = 3, kBW = 4, kL = 5, kL6 = 6 };  // kBW: as B but a full 64-lane rotation (DPP wave_ror:1); kL6: L with 6 ds_add (no v_add)
 
 template <int R> struct State {
     v2f   px[R], py[R], pz[R], ax[R], ay[R], az[R];
@@ -102,6 +105,32 @@ template <int R, int K> __device__ __forceinline__ void step_a(State<R>& s) {
     }
 }
 
+// variant L: the body j comes from LDS (already in `j`), the reaction term goes to LDS
+template <int R, bool SIX> __device__ __forceinline__ void step_l(State<R>& s, const float4 j, float* react /* this lane's slot at step k: &sums[lane + k] */) {
+    const v2f bx = v2f{j.x, j.x}, by = v2f{j.y, j.y}, bz = v2f{j.z, j.z};
+    v2f       tx, ty, tz;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const v2f dx = bx - s.px[r], dy = by - s.py[r], dz = bz - s.pz[r];
+        v2f       d2 = fma2(dx, dx, s.eps2);
+        d2           = fma2(dy, dy, d2);
+        d2           = fma2(dz, dz, d2);
+        const v2f w  = inv3_of(d2);
+        s.ax[r] = fma2(dx, w, s.ax[r]), s.ay[r] = fma2(dy, w, s.ay[r]), s.az[r] = fma2(dz, w, s.az[r]);
+        if (r == 0) tx = dx * w, ty = dy * w, tz = dz * w;
+        else tx = fma2(dx, w, tx), ty = fma2(dy, w, ty), tz = fma2(dz, w, tz);
+    }
+    if constexpr (SIX) {
+        __hip_atomic_fetch_add(react, tx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT), __hip_atomic_fetch_add(react, tx.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        __hip_atomic_fetch_add(react + 128, ty.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT), __hip_atomic_fetch_add(react + 128, ty.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        __hip_atomic_fetch_add(react + 256, tz.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT), __hip_atomic_fetch_add(react + 256, tz.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    } else {
+        __hip_atomic_fetch_add(react, tx.x + tx.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        __hip_atomic_fetch_add(react + 128, ty.x + ty.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        __hip_atomic_fetch_add(react + 256, tz.x + tz.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    }
+}
+
 // the one-sided loop on this data layout
 template <int R> __device__ __forceinline__ void step_one(State<R>& s) {
     const v2f bx = v2f{s.jx, s.jx}, by = v2f{s.jy, s.jy}, bz = v2f{s.jz, s.jz};
@@ -142,6 +171,41 @@ template <int VARIANT, int R> __global__ __launch_bounds__(1024) void bench(Out*
     s.eps2 = v2f{0.01f, 0.01f};
     s.rx = s.ry = s.rz = v2f{0, 0};
     s.sx = s.sy = s.sz = 0;
+    if constexpr (VARIANT == kL || VARIANT == kL6) {
+        // per wave: 128 bodies (the tile twice) and 3 x 128 reaction sums
+        __shared__ float4 tile_pos[16][128];
+        __shared__ float  tile_sum[16][3 * 128];
+        const int wave = threadIdx.x >> 6;
+        float4* const pos = tile_pos[wave];
+        float* const  sum = tile_sum[wave];
+        const unsigned long long t0 = __builtin_readcyclecounter();
+        float kept = 0;
+#pragma unroll 1
+        for (int tile = 0; tile < rounds / 4; ++tile) {
+            const float4 mine = bodies[(tile * 64 + lane) & 4095];
+            pos[lane] = mine, pos[lane + 64] = mine;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) sum[c * 128 + lane] = 0, sum[c * 128 + lane + 64] = 0;
+            float4 j = pos[lane];
+#pragma unroll 1
+            for (int k0 = 0; k0 < 64; k0 += 8) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const float4 next = pos[lane + k0 + q + 1 < 128 ? lane + k0 + q + 1 : 127];  // (requested a step ahead)
+                    step_l<R, VARIANT == kL6>(s, j, sum + lane + k0 + q);
+                    j = next;
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) kept += sum[c * 128 + lane] + sum[c * 128 + lane + 64];
+        }
+        const unsigned long long t1 = __builtin_readcyclecounter();
+        float check = kept;
+#pragma unroll
+        for (int r = 0; r < R; ++r) check += s.ax[r].x + s.ax[r].y + s.ay[r].x + s.ay[r].y + s.az[r].x + s.az[r].y;
+        if (lane == 0) out[blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64] = Out{t1 - t0, check};
+        return;
+    }
     const unsigned long long t0 = __builtin_readcyclecounter();
 #pragma unroll 1
     for (int k = 0; k < rounds; ++k) {
@@ -200,6 +264,12 @@ int main(int argc, char**) {
     hipMemcpy(bodies, host.data(), sizeof(float4) * 4096, hipMemcpyHostToDevice);
     if (argc > 1) {  // quick mode (for rocprofv3 --pmc): the production candidate only, long run
         run<kBW, 4>("pairwise B, wave_ror:1 (64-lane rotation)", bodies, out, 1024);
+        run<kL, 4>("pairwise L (j from LDS, sums to LDS, 3 adds)", bodies, out, 1024);
+        run<kL6, 4>("pairwise L6 (j from LDS, 6 ds_add)", bodies, out, 1024);
+        run<kBW, 2>("pairwise B, wave_ror:1 (64-lane rotation)", bodies, out, 1024);
+        run<kL, 2>("pairwise L (j from LDS, sums to LDS, 3 adds)", bodies, out, 1024);
+        run<kBW, 4>("pairwise B, wave_ror:1 (64-lane rotation)", bodies, out, 512);
+        run<kL, 4>("pairwise L (j from LDS, sums to LDS, 3 adds)", bodies, out, 512);
         run<kOne, 1>("one-sided, body j per lane", bodies, out, 1024);
         return 0;
     }
