@@ -1,0 +1,22 @@
+#!/bin/bash
+# tools/gpu_evidence.sh [OUT] -- the evidence run of a round, sent to the GPU box as ONE gpurun call:
+#     gpurun --timeout 1100 -- 'bash tools/gpu_evidence.sh gpurun_out/r4'
+# (1) the GPU test suite, (2) smoke, (3) the default bench line and the one-sided one, (4) rocprofv3 kernel trace + the separate
+# PMC passes (tools/profile.sh) of every BASELINE size through the bench command itself.  Afterwards, here:
+#     python tools/summarize_prof.py gpurun_out/r4/f32 profiles/round4_n262144_f32_pairwise pair_forces      (and so on per size)
+# Steps are joined so that a GPU step that fails or times out stops the run (never start GPU work after a timeout).
+set -o pipefail
+OUT=${1:-gpurun_out/evidence}
+mkdir -p $OUT
+timeout -k 10 900 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.txt 2>&1; rc=$?; tail -3 $OUT/pytest_gpu.txt; [ $rc -eq 0 ] || exit $rc
+timeout -k 10 120 python __graft_entry__.py smoke > $OUT/smoke.txt 2>&1 || { tail -5 $OUT/smoke.txt; exit 1; }
+timeout -k 10 300 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err || { tail -5 $OUT/bench.err; exit 1; }
+echo "bench ok: $(cut -c1-200 $OUT/bench.json)"
+timeout -k 10 300 python3 bench.py --layout one-sided --no-configs --no-cpu-baseline > $OUT/bench_one_sided.json 2> $OUT/bench_one_sided.err || exit 1
+run_prof() { PROF_OUT=$OUT/$1 timeout -k 10 600 bash tools/profile.sh "${@:2}" > $OUT/$1.log 2>&1 && echo "$1 ok" || { echo "$1 FAILED"; tail -5 $OUT/$1.log; return 1; }; }
+run_prof f32 --steps 20 --warmup 3 &&
+run_prof n65536 --steps 200 --warmup 10 --bodies 65536 &&
+run_prof n16384 --steps 400 --warmup 20 --bodies 16384 &&
+run_prof f64 --steps 8 --warmup 2 --fp64 &&
+run_prof n1m --steps 4 --warmup 1 --bodies 1048576 &&
+run_prof strict --steps 8 --warmup 2 --mode strict
