@@ -65,7 +65,7 @@ class DeviceInfo(ctypes.Structure):
 class PairPlan(ctypes.Structure):
     _fields_ = [("applies", ctypes.c_int), ("bodies_per_lane", ctypes.c_int), ("waves_per_block", ctypes.c_int), ("splits", ctypes.c_uint),
                 ("blocks", ctypes.c_uint), ("block_bodies", ctypes.c_uint), ("reaction_slots", ctypes.c_uint), ("grid_blocks", ctypes.c_uint),
-                ("lds_bytes", ctypes.c_uint), ("workspace_bytes", ctypes.c_size_t)]
+                ("lds_bytes", ctypes.c_uint), ("workspace_bytes", ctypes.c_size_t), ("slices", ctypes.c_uint)]
 
 
 class LaunchPlan(ctypes.Structure):
@@ -115,6 +115,8 @@ SIGNATURES = {
     "nb_graph_create_ws_f64": (_ci, [_P(_vp), _vp, _vp, _vp, _cd, _cd, _cu, _ci, _ci, _cu, _vp, _sz]),
     "nb_workspace_bytes_f32": (_ci, [_cu, _ci, _P(_sz)]),
     "nb_workspace_bytes_f64": (_ci, [_cu, _ci, _P(_sz)]),
+    "nb_workspace_bytes_capped_f32": (_ci, [_cu, _ci, _sz, _P(_sz)]),
+    "nb_workspace_bytes_capped_f64": (_ci, [_cu, _ci, _sz, _P(_sz)]),
     "nb_integrate_ws_f32": (_ci, [_vp, _vp, _vp, _cf, _cf, _cu, _ci, _ci, _vp, _sz, _vp]),
     "nb_integrate_ws_f64": (_ci, [_vp, _vp, _vp, _cd, _cd, _cu, _ci, _ci, _vp, _sz, _vp]),
     "nb_pair_plan_f32": (_ci, [_cu, _P(PairPlan)]),
@@ -151,6 +153,7 @@ SIGNATURES = {
 TUNING_SIGNATURES = {
     "nb_set_plan_override": (_ci, [_ci, _ci, _ci]),
     "nb_set_pair_plan_override": (_ci, [_ci, _ci, _ci, _ci]),
+    "nb_set_pair_slices_override": (_ci, [_ci]),
     "nb_comm_set_pair_min_slice": (_ci, [_ci]),
     "nb_emulate_pair_rank_f32": (_ci, [_vp, _vp, _vp, _vp, _P(_sz), _cu, _ci, _ci, _cf, _cf, _vp]),
     "nb_emulate_pair_rank_f64": (_ci, [_vp, _vp, _vp, _vp, _P(_sz), _cu, _ci, _ci, _cd, _cd, _vp]),
@@ -213,6 +216,10 @@ def pair_plan(num_bodies: int, dtype=np.float32) -> PairPlan:
 
 def set_pair_plan_override(vectors_per_lane: int = 0, waves_per_block: int = 0, splits: int = 0, min_bodies: int = 0) -> None:
     check(lib().nb_set_pair_plan_override(vectors_per_lane, waves_per_block, splits, min_bodies), "nb_set_pair_plan_override")
+
+
+def set_pair_slices_override(slices: int = 0) -> None:
+    check(lib().nb_set_pair_slices_override(slices), "nb_set_pair_slices_override")
 
 
 def set_plan_override(bodies_per_lane: int = 0, lanes_per_body: int = 0, tile_bodies: int = 0) -> None:
@@ -282,7 +289,7 @@ class BodySystemHIP:
 
     def __init__(self, nb_bodies: int, block_size: int = 256, params: NBodyParams | None = None, dtype=np.float32,
                  positions: np.ndarray | None = None, velocities: np.ndarray | None = None, mode: int = NB_MODE_FAST,
-                 workspace: bool = False):
+                 workspace: bool = False, workspace_cap: int | None = None):
         """`workspace=True`: own the scratch memory nb_workspace_bytes_* asks for and step through nb_integrate_ws_* (FAST mode
         then takes the pairwise layout where it applies), as BodySystemHIPStored does in the C++ host."""
         self.dtype = np.dtype(dtype)
@@ -301,12 +308,10 @@ class BodySystemHIP:
         self._host_vel = np.zeros(4 * self.nb_bodies, dtype=self.dtype)
         self._workspace, self._workspace_bytes = None, 0
         if workspace:
-            need = _sz(0)
-            fn = lib().nb_workspace_bytes_f32 if self.dtype == np.float32 else lib().nb_workspace_bytes_f64
-            check(fn(self.nb_bodies, self.mode, ctypes.byref(need)), "nb_workspace_bytes")
-            if need.value:
-                self._workspace, self._workspace_bytes = _vp(), need.value
-                check(lib().nb_alloc(ctypes.byref(self._workspace), need.value), "nb_alloc(workspace)")
+            need = workspace_bytes(self.nb_bodies, self.dtype, self.mode, workspace_cap)  # (`workspace_cap`: spend at most that many bytes)
+            if need:
+                self._workspace, self._workspace_bytes = _vp(), need
+                check(lib().nb_alloc(ctypes.byref(self._workspace), need), "nb_alloc(workspace)")
         self._set_softening(params.softening)
         if positions is not None:
             self.set_position(positions)
@@ -519,11 +524,14 @@ class ShardedRank:
         self.comm = _vp()
 
 
-def workspace_bytes(num_bodies: int, dtype=np.float32, mode: int = NB_MODE_FAST) -> int:
-    """nb_workspace_bytes_*: scratch memory nb_integrate_ws_* wants for this system (0 = none)."""
+def workspace_bytes(num_bodies: int, dtype=np.float32, mode: int = NB_MODE_FAST, max_bytes: int | None = None) -> int:
+    """nb_workspace_bytes_* (max_bytes: nb_workspace_bytes_capped_*): scratch memory nb_integrate_ws_* wants for this system (0 = none)."""
     need = _sz(0)
-    fn = lib().nb_workspace_bytes_f32 if np.dtype(dtype) == np.float32 else lib().nb_workspace_bytes_f64
-    check(fn(num_bodies, mode, ctypes.byref(need)), "nb_workspace_bytes")
+    f32 = np.dtype(dtype) == np.float32
+    if max_bytes is None:
+        check((lib().nb_workspace_bytes_f32 if f32 else lib().nb_workspace_bytes_f64)(num_bodies, mode, ctypes.byref(need)), "nb_workspace_bytes")
+    else:
+        check((lib().nb_workspace_bytes_capped_f32 if f32 else lib().nb_workspace_bytes_capped_f64)(num_bodies, mode, max_bytes, ctypes.byref(need)), "nb_workspace_bytes_capped")
     return need.value
 
 

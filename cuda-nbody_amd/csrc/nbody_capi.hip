@@ -9,6 +9,7 @@
 #include "nbody_kernels.h"
 #include "rand_stream_guard.h"
 
+#include <algorithm>
 #include <atomic>
 #include <utility>
 #include <cstdint>
@@ -26,6 +27,7 @@ std::atomic<double> g_softening_sq_f64{0.0};
 std::atomic<int> g_ovr_i{0}, g_ovr_s{0}, g_ovr_tile{0};
 std::atomic<int> g_pair_r{0}, g_pair_s{0}, g_pair_c{0}, g_pair_min{0};  // overrides of the pairwise plan (0 = automatic)
 std::atomic<void*> g_pair_probe{nullptr};                               // nb_set_pair_probe_event
+std::atomic<int>   g_pair_slices{0};                                    // nb_set_pair_slices_override (0 = automatic)
 
 
 // The HIP runtime sets parts of itself up lazily, on the first call that needs them (the null stream, the first event,
@@ -128,22 +130,48 @@ struct StepGraph {
 // fp64 4 096 bodies 24.3 / 18.9 us, 6 144 bodies 38.5 / 40.8 us)
 template <typename T> constexpr unsigned kPairMinBodies = sizeof(T) == 4 ? 8193u : 6144u;
 
-template <typename T> bool pair_applies(unsigned n, int mode, nb::PairPlan* plan) {
-    const int floor_bodies = g_pair_min.load();
-    if (mode != NB_MODE_FAST || n < (floor_bodies > 0 ? static_cast<unsigned>(floor_bodies) : kPairMinBodies<T>)) return false;
-    *plan = nb::plan_pair<T>(n, cu_count_cached(), g_pair_r.load(), g_pair_s.load(), g_pair_c.load());
-    // The workspace grows with N^2 (12.9 GB at 1 Mi bodies, 206 GB at 4 Mi): past a third of the device's memory the layout
-    // does not apply (nb_workspace_bytes_* says 0 and the step is the one-sided kernel).
-    const size_t total_bytes = nb::device_memory_budget();
-    return total_bytes == 0 || plan->workspace_bytes <= total_bytes / 3;
+// Which form of the pairwise layout a system of n bodies takes when `have` bytes of workspace are on offer: the single tournament
+// (slices == 1) if its workspace fits, else the tournament cut into the FEWEST slices (2 .. 15) whose workspace fits -- fewer
+// slices = fewer, larger launches and less folding.  "Fits" = within `have` and within a third of the device's memory (the
+// workspace grows with N^2: 12.9 GB at 1 Mi bodies, 206 GB at 4 Mi in one tournament; 7 GB at 4 Mi in eight slices).
+struct PairChoice {
+    unsigned        slices = 0;  // 0: the pairwise layout does not apply (the step is the one-sided kernel)
+    nb::PairPlan    plan{};      // slices == 1
+    nb::PairSlicing sliced{};    // slices >= 2
+    size_t          bytes = 0;
+};
+
+template <typename T> PairChoice choose_pair_layout(unsigned n, int mode, size_t have) {
+    PairChoice c;
+    const int  floor_bodies = g_pair_min.load();
+    if (mode != NB_MODE_FAST || n == 0 || n < (floor_bodies > 0 ? static_cast<unsigned>(floor_bodies) : kPairMinBodies<T>)) return c;
+    const size_t budget = nb::device_memory_budget();
+    const size_t limit  = budget == 0 ? have : std::min(have, budget / 3);
+    const int    forced = g_pair_slices.load();
+    const int    r = g_pair_r.load(), w = g_pair_s.load(), g = g_pair_c.load();
+    if (forced <= 1) {
+        c.plan = nb::plan_pair<T>(n, cu_count_cached(), r, w, g);
+        if (c.plan.workspace_bytes <= limit) {
+            c.slices = 1, c.bytes = c.plan.workspace_bytes;
+            return c;
+        }
+        if (forced == 1) return c;
+    }
+    for (unsigned k = forced > 1 ? static_cast<unsigned>(forced) : 2u; k <= (forced > 1 ? static_cast<unsigned>(forced) : 15u); ++k) {
+        const nb::PairSlicing sl = nb::plan_pair_sliced<T>(n, k, r, w, g);
+        if (sl.slices < 2 || sl.workspace_bytes > limit) continue;
+        c.slices = sl.slices, c.sliced = sl, c.bytes = sl.workspace_bytes;
+        return c;
+    }
+    return c;
 }
 
 // nb_integrate_ws_*: the whole system in one step, FAST, with a caller-owned workspace -> the pairwise layout when it
 // applies and the workspace is large enough; in every other case exactly what nb_integrate_* does.
 template <typename T>
 int integrate_ws(T* new_pos, const T* old_pos, T* vel, T dt, T damping, T eps2, unsigned n, int block_size, int mode, void* workspace, size_t workspace_bytes, nb_stream_t stream, bool prepare_only = false) {
-    nb::PairPlan plan{};
-    if (workspace != nullptr && n != 0 && pair_applies<T>(n, mode, &plan) && workspace_bytes >= plan.workspace_bytes) {
+    const PairChoice choice = workspace != nullptr ? choose_pair_layout<T>(n, mode, workspace_bytes) : PairChoice{};
+    if (choice.slices != 0) {
         if (!new_pos || !old_pos || !vel || new_pos == old_pos) return NB_ERR_INVALID_ARGUMENT;
         if (!aligned_vec4<T>(old_pos) || !aligned_vec4<T>(new_pos) || !aligned_vec4<T>(vel) || (reinterpret_cast<std::uintptr_t>(workspace) % sizeof(T)) != 0) return NB_ERR_INVALID_ARGUMENT;
         {   // nothing the launch writes may overlap the bodies it reads (old_pos is read-only for the whole launch), and the four
@@ -153,7 +181,7 @@ int integrate_ws(T* new_pos, const T* old_pos, T* vel, T dt, T damping, T eps2, 
             auto overlap = [&](const void* a, std::uintptr_t a_len, const void* b, std::uintptr_t b_len) { return lo(a) < lo(b) + b_len && lo(b) < lo(a) + a_len; };
             if (overlap(new_pos, bytes, old_pos, bytes) || overlap(vel, bytes, old_pos, bytes) || overlap(new_pos, bytes, vel, bytes)) return NB_ERR_INVALID_ARGUMENT;
             for (const void* body_array : {static_cast<const void*>(old_pos), static_cast<const void*>(new_pos), static_cast<const void*>(vel)}) {
-                if (overlap(workspace, plan.workspace_bytes, body_array, bytes)) return NB_ERR_INVALID_ARGUMENT;
+                if (overlap(workspace, choice.bytes, body_array, bytes)) return NB_ERR_INVALID_ARGUMENT;
             }
         }
         nb::Shard<T> s{};
@@ -162,7 +190,8 @@ int integrate_ws(T* new_pos, const T* old_pos, T* vel, T dt, T damping, T eps2, 
         s.acc_in = false, s.finalize = true;
         s.dt = dt, s.damping = damping, s.eps2 = eps2;
         (void)current_device_ready();
-        return static_cast<int>(nb::launch_pair<T>(s, plan, workspace, as_stream(stream), prepare_only));
+        if (choice.slices == 1) return static_cast<int>(nb::launch_pair<T>(s, choice.plan, workspace, as_stream(stream), prepare_only));
+        return static_cast<int>(nb::launch_pair_sliced<T>(s, choice.sliced, workspace, as_stream(stream), prepare_only));
     }
     if (prepare_only) return 0;
     return integrate_shard<T>(new_pos, old_pos, vel, nullptr, 0, n, 0, n, NB_SHARD_FINALIZE, dt, damping, eps2, block_size, mode, stream);
@@ -223,9 +252,9 @@ template <typename T> int graph_create(nb_graph_t* out, T* pos_a, T* pos_b, T* v
 
 template <typename T> int pair_plan_query(unsigned n, nb_pair_plan_t* out) {
     if (out == nullptr || n == 0) return NB_ERR_INVALID_ARGUMENT;
-    const nb::PairPlan p  = nb::plan_pair<T>(n, cu_count_cached(), g_pair_r.load(), g_pair_s.load(), g_pair_c.load());
-    nb::PairPlan       chosen{};
-    out->applies          = pair_applies<T>(n, NB_MODE_FAST, &chosen) ? 1 : 0;
+    const PairChoice   chosen = choose_pair_layout<T>(n, NB_MODE_FAST, ~size_t{0});
+    const nb::PairPlan p      = nb::plan_pair<T>(n, cu_count_cached(), g_pair_r.load(), g_pair_s.load(), g_pair_c.load());  // the single tournament, whether or not it is affordable
+    out->applies          = chosen.slices != 0 ? 1 : 0;
     out->bodies_per_lane  = p.vectors_per_lane * (sizeof(T) == 4 ? 2 : 1);
     out->waves_per_block  = p.waves;
     out->splits           = p.splits;
@@ -234,7 +263,8 @@ template <typename T> int pair_plan_query(unsigned n, nb_pair_plan_t* out) {
     out->reaction_slots   = p.slots;
     out->grid_blocks      = p.grid_blocks;
     out->lds_bytes        = p.lds_bytes;
-    out->workspace_bytes  = p.workspace_bytes;
+    out->workspace_bytes  = chosen.slices >= 2 ? chosen.bytes : p.workspace_bytes;
+    out->slices           = chosen.slices >= 2 ? chosen.slices : 1u;
     return 0;
 }
 template <typename T> int plan_query(unsigned i_count, unsigned j_count, nb_launch_plan_t* out) {
@@ -453,16 +483,16 @@ int nb_graph_create_ws_f64(nb_graph_t* graph, double* position_a, double* positi
     return graph_create<double>(graph, position_a, position_b, velocities, dt, damping, g_softening_sq_f64.load(), num_bodies, block_size, mode, steps, workspace, workspace_bytes);
 }
 
-int nb_workspace_bytes_f32(unsigned num_bodies, int mode, size_t* bytes) {
+int nb_workspace_bytes_f32(unsigned num_bodies, int mode, size_t* bytes) { return nb_workspace_bytes_capped_f32(num_bodies, mode, ~size_t{0}, bytes); }
+int nb_workspace_bytes_f64(unsigned num_bodies, int mode, size_t* bytes) { return nb_workspace_bytes_capped_f64(num_bodies, mode, ~size_t{0}, bytes); }
+int nb_workspace_bytes_capped_f32(unsigned num_bodies, int mode, size_t max_bytes, size_t* bytes) {
     if (bytes == nullptr) return NB_ERR_INVALID_ARGUMENT;
-    nb::PairPlan plan{};
-    *bytes = pair_applies<float>(num_bodies, mode, &plan) ? plan.workspace_bytes : 0;
+    *bytes = choose_pair_layout<float>(num_bodies, mode, max_bytes).bytes;
     return 0;
 }
-int nb_workspace_bytes_f64(unsigned num_bodies, int mode, size_t* bytes) {
+int nb_workspace_bytes_capped_f64(unsigned num_bodies, int mode, size_t max_bytes, size_t* bytes) {
     if (bytes == nullptr) return NB_ERR_INVALID_ARGUMENT;
-    nb::PairPlan plan{};
-    *bytes = pair_applies<double>(num_bodies, mode, &plan) ? plan.workspace_bytes : 0;
+    *bytes = choose_pair_layout<double>(num_bodies, mode, max_bytes).bytes;
     return 0;
 }
 int nb_integrate_ws_f32(float* new_positions, const float* old_positions, float* velocities, float dt, float damping, unsigned num_bodies, int block_size, int mode, void* workspace, size_t workspace_bytes, nb_stream_t stream) {
@@ -487,6 +517,12 @@ int nb_set_pair_plan_override(int vectors_per_lane, int waves_per_block, int spl
     g_pair_s.store(waves_per_block);
     g_pair_c.store(splits);
     g_pair_min.store(min_bodies);
+    return 0;
+}
+
+int nb_set_pair_slices_override(int slices) {
+    if (slices < 0 || slices > 15) return NB_ERR_INVALID_ARGUMENT;
+    g_pair_slices.store(slices);
     return 0;
 }
 

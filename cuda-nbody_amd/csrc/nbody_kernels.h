@@ -59,6 +59,29 @@ struct PairPlan {
     size_t   workspace_bytes;
 };
 
+struct PairGeom {
+    int      vectors_per_lane;  // R
+    int      waves;             // S
+    unsigned splits;            // C
+};
+
+// The pairwise layout with a BOUNDED workspace (round 4): the reaction slots of one tournament over the whole system grow with N^2
+// (12.9 GB at 1 Mi bodies, 206 GB at 4 Mi).  Cut into K slices of bodies, the tournament runs slice by slice -- every slice against
+// itself (diag) and against the next K/2 slices (rectangles; for an even K the two partners at distance K/2 split theirs) -- through
+// ONE reusable region of reaction planes, each launch's planes folded straight away (pair_reduce) into one array per receiving
+// slice; the finish kernel of a slice adds its own sums and the arrays it received.  The same pieces, in the same roles, as one
+// rank's part of a multi-GPU pairwise step (nbody_comm.hip), only that "sending" is a pointer.  slices == 1: the single tournament.
+struct PairSlicing {
+    unsigned slices;        // K (after rounding: every slice holds at least one body)
+    unsigned slice_bodies;  // bodies per slice, a multiple of the block (the last slice may hold fewer)
+    unsigned partners;      // H = K / 2
+    bool     even;
+    PairGeom diag, rect;
+    unsigned block_bodies, plane;
+    size_t   self_per_slice, react_elements, recv_per_slice, elements;  // in units of T
+    size_t   workspace_bytes;
+};
+
 // One launch of the forces kernel: the bodies i of [i_begin, i_begin + i_count), cut into blocks of 64*I, against
 //   diag = 1: themselves -- the tournament of the header comment within that range (one GPU: the whole system; a rank of a
 //             multi-GPU system: its own slice), reaction slot q-1;
@@ -110,11 +133,6 @@ hipEvent_t pair_probe_event();
 // nb_set_pair_plan_override: 0 = automatic (defined in nbody_capi.hip; the multi-GPU layer honours it for its tiles too)
 void pair_plan_overrides(int* vectors_per_lane, int* waves, int* splits);
 
-struct PairGeom {
-    int      vectors_per_lane;  // R
-    int      waves;             // S
-    unsigned splits;            // C
-};
 
 template <typename T> PairPlan   plan_pair(unsigned n, int cu_count, int ovr_r, int ovr_s, int ovr_c);
 // the pieces of a pairwise step, for callers that compose them themselves (nbody_comm.hip: one rank of a multi-GPU system)
@@ -122,6 +140,8 @@ template <typename T> hipError_t launch_pair_tile(const PairArgs<T>& args, const
 template <typename T> hipError_t launch_pair_reduce(const T* react, unsigned react_plane, unsigned slots, T* out, unsigned out_plane, unsigned count, hipStream_t stream);
 template <typename T> hipError_t launch_pair_finish(const FinishArgs<T>& args, hipStream_t stream);
 template <typename T> hipError_t launch_pair(const Shard<T>& s, const PairPlan& p, void* workspace, hipStream_t stream, bool prepare_only = false);
+template <typename T> PairSlicing plan_pair_sliced(unsigned n, unsigned slices, int ovr_r, int ovr_s, int ovr_c);
+template <typename T> hipError_t  launch_pair_sliced(const Shard<T>& s, const PairSlicing& p, void* workspace, hipStream_t stream, bool prepare_only = false);
 template <typename T> Plan       plan_fast(unsigned i_count, unsigned j_count, int cu_count, int ovr_i, int ovr_s, int ovr_tile);
 template <typename T> hipError_t launch_fast(const Shard<T>& s, const Plan& p, hipStream_t stream, bool prepare_only = false);
 template <typename T> hipError_t launch_strict(const Shard<T>& s, int block_size, int cu_count, hipStream_t stream, bool prepare_only = false);

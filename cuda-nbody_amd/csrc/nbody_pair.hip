@@ -42,6 +42,7 @@
 #include "nbody_kernels.h"
 
 #include <algorithm>
+#include <vector>
 
 #ifdef NB_PAIR_STAMPS
 // Diagnostic build only (tools/build_pair_variant.sh stamps "-DNB_PAIR_STAMPS", read by tools/pair_stamps.py): per wave of the LAST
@@ -592,10 +593,120 @@ template <typename T> hipError_t launch_pair(const Shard<T>& s, const PairPlan& 
     return launch_pair_finish<T>(f, stream);
 }
 
+// ---- the same step through a bounded workspace: K slices (see PairSlicing in nbody_kernels.h) ----------------------------------
+template <typename T> PairSlicing plan_pair_sliced(unsigned n, unsigned slices, int ovr_r, int ovr_s, int ovr_c) {
+    constexpr unsigned W = sizeof(T) == 4 ? 2 : 1;
+    PairSlicing        p{};
+    if (n == 0 || slices < 2) return p;
+    const int R = (ovr_r == 1 || ovr_r == 2 || ovr_r == 4) ? ovr_r : 4;
+    const int S = (ovr_s == 4 || ovr_s == 8 || ovr_s == 16) ? ovr_s : 8;
+    p.block_bodies          = 64u * static_cast<unsigned>(R) * W;
+    const unsigned blocks   = (n + p.block_bodies - 1) / p.block_bodies;
+    const unsigned per      = (blocks + slices - 1) / slices;            // blocks per slice
+    p.slice_bodies          = per * p.block_bodies;
+    p.slices                = (n + p.slice_bodies - 1) / p.slice_bodies;  // (rounding can leave fewer slices than asked for)
+    if (p.slices < 2) return PairSlicing{};
+    p.partners = p.slices / 2;
+    p.even     = (p.slices % 2) == 0;
+    if (p.partners + 1 > static_cast<unsigned>(kMaxRecv) || p.partners + 1 > static_cast<unsigned>(kMaxSelfSets)) return PairSlicing{};
+    p.plane = p.slice_bodies;  // (a multiple of 64 already)
+    auto splits = [&](unsigned units) {  // workgroups per block: fill the chip (~512 workgroups of 8 waves) while a wave keeps >= 2 units
+        unsigned C = 1;
+        while (per * C * 2 <= 512 && units >= C * 2 * static_cast<unsigned>(S) * 2) C *= 2;
+        if (ovr_c > 0) C = static_cast<unsigned>(ovr_c);
+        while (C > 1 && units < C * static_cast<unsigned>(S)) C /= 2;
+        return C;
+    };
+    p.diag = {R, S, splits((per / 2 + 1) * static_cast<unsigned>(R) * W)};
+    p.rect = {R, S, splits(p.slice_bodies / 64)};
+    const size_t   plane3     = 3 * static_cast<size_t>(p.plane);
+    const unsigned diag_slots = per < 2 ? 0u : ((per & 1u) ? per / 2 : per / 2 - 1);
+    p.self_per_slice  = (p.diag.splits + static_cast<size_t>(p.partners) * p.rect.splits) * plane3;
+    p.react_elements  = static_cast<size_t>(std::max(diag_slots, per)) * plane3;  // one region, reused launch after launch (stream order)
+    p.recv_per_slice  = (1 + static_cast<size_t>(p.partners)) * plane3;          // [0]: the slice's own folded diagonal, [s]: from slice r - s
+    p.elements        = p.slices * (p.self_per_slice + p.recv_per_slice) + p.react_elements;
+    p.workspace_bytes = p.elements * sizeof(T);
+    return p;
+}
+
+template <typename T> hipError_t launch_pair_sliced(const Shard<T>& s, const PairSlicing& p, void* workspace, hipStream_t stream, bool prepare_only) {
+    const unsigned n = s.i_count, K = p.slices, ni = p.slice_bodies, H = p.partners;
+    const size_t   plane3 = 3 * static_cast<size_t>(p.plane);
+    T* const       work   = static_cast<T*>(workspace);
+    T* const       react  = work;                                                  // the reusable region of reaction planes
+    auto self_of = [&](unsigned r) { return work + p.react_elements + static_cast<size_t>(r) * p.self_per_slice; };
+    auto recv_of = [&](unsigned r) { return work + p.react_elements + static_cast<size_t>(K) * p.self_per_slice + static_cast<size_t>(r) * p.recv_per_slice; };
+    auto first_of = [&](unsigned r) { return r * ni; };
+    auto count_of = [&](unsigned r) { return std::min(ni, n - r * ni); };
+    auto blocks_of = [&](unsigned count) { return (count + p.block_bodies - 1) / p.block_bodies; };
+    auto half_of = [&](unsigned r) { return (blocks_of(count_of(r)) / 2) * p.block_bodies; };  // where a split rectangle cuts slice r
+
+    std::vector<FinishArgs<T>> finish(K);
+    for (unsigned r = 0; r < K; ++r) {
+        FinishArgs<T>& f = finish[r];
+        f                = {};
+        f.old_pos = s.old_pos, f.new_pos = s.new_pos, f.vel = s.vel;
+        f.self = self_of(r), f.react = react, f.recv = recv_of(r), f.extra = nullptr;
+        f.origin = first_of(r), f.count = count_of(r);
+        f.self_plane = f.react_plane = f.recv_plane = p.plane;
+        f.react_slots = 0;  // (the diagonal's slots are folded into recv[0] right after its launch: the region is reused)
+        f.dt = s.dt, f.damping = s.damping;
+        f.n_recv = 1 + H;
+        for (unsigned m = 0; m <= H; ++m) f.recv_set[m] = {0u, 0u};
+    }
+    for (unsigned r = 0; r < K; ++r) {
+        const unsigned own = first_of(r), cnt = count_of(r);
+        PairArgs<T>    a{};
+        a.old_pos = s.old_pos, a.self = self_of(r), a.n = n, a.eps2 = s.eps2;
+        a.self_origin = own, a.self_plane = p.plane, a.react = react, a.react_plane = p.plane;
+        // the slice against itself
+        a.react_origin = own, a.i_begin = a.j_begin = own, a.i_count = a.j_count = cnt, a.diag = 1, a.keep = 1, a.self_first = 0;
+        if (const auto err = launch_pair_tile<T>(a, p.diag, stream, prepare_only); err != hipSuccess) return err;
+        finish[r].self_set[finish[r].n_self++] = {0u, p.diag.splits, 0u, cnt};
+        const unsigned b = blocks_of(cnt), diag_slots = b < 2 ? 0u : ((b & 1u) ? b / 2 : b / 2 - 1);
+        if (diag_slots != 0) {
+            if (!prepare_only) {
+                if (const auto err = launch_pair_reduce<T>(react, p.plane, diag_slots, recv_of(r), p.plane, cnt, stream); err != hipSuccess) return err;
+            }
+            finish[r].recv_set[0] = {0u, cnt};
+        }
+        // the rectangles against the next H slices
+        for (unsigned q = 1; q <= H; ++q) {
+            const unsigned partner = (r + q) % K, pfirst = first_of(partner), pcnt = count_of(partner);
+            a.diag = 0, a.keep = 1;
+            a.i_begin = own, a.i_count = cnt, a.j_begin = pfirst, a.j_count = pcnt;
+            const bool split = p.even && q == H;  // both partners list this pair of slices: the HIGHER slice is the one that is cut
+            if (split) {
+                if (r < partner) a.j_count = half_of(partner);                              // all of this slice x the first half of the partner
+                else a.i_begin = own + half_of(r), a.i_count = cnt - half_of(r);            // the second half of this slice x all of the partner
+            }
+            a.react_origin = a.j_begin;
+            a.self_first   = p.diag.splits + (q - 1) * p.rect.splits;
+            if (a.i_count != 0 && a.j_count != 0) {
+                if (const auto err = launch_pair_tile<T>(a, p.rect, stream, prepare_only); err != hipSuccess) return err;
+                finish[r].self_set[finish[r].n_self++] = {a.self_first, p.rect.splits, a.i_begin - own, a.i_count};
+                if (!prepare_only) {
+                    if (const auto err = launch_pair_reduce<T>(react, p.plane, blocks_of(a.i_count), recv_of(partner) + q * plane3, p.plane, a.j_count, stream); err != hipSuccess) return err;
+                }
+                finish[partner].recv_set[q] = {0u, a.j_count};
+            }
+        }
+    }
+    if (prepare_only) return hipSuccess;
+    for (unsigned r = 0; r < K; ++r) {
+        if (const auto err = launch_pair_finish<T>(finish[r], stream); err != hipSuccess) return err;
+    }
+    return hipSuccess;
+}
+
 template PairPlan   plan_pair<float>(unsigned, int, int, int, int);
 template PairPlan   plan_pair<double>(unsigned, int, int, int, int);
 template hipError_t launch_pair<float>(const Shard<float>&, const PairPlan&, void*, hipStream_t, bool);
 template hipError_t launch_pair<double>(const Shard<double>&, const PairPlan&, void*, hipStream_t, bool);
+template PairSlicing plan_pair_sliced<float>(unsigned, unsigned, int, int, int);
+template PairSlicing plan_pair_sliced<double>(unsigned, unsigned, int, int, int);
+template hipError_t  launch_pair_sliced<float>(const Shard<float>&, const PairSlicing&, void*, hipStream_t, bool);
+template hipError_t  launch_pair_sliced<double>(const Shard<double>&, const PairSlicing&, void*, hipStream_t, bool);
 template hipError_t launch_pair_tile<float>(const PairArgs<float>&, const PairGeom&, hipStream_t, bool);
 template hipError_t launch_pair_tile<double>(const PairArgs<double>&, const PairGeom&, hipStream_t, bool);
 template hipError_t launch_pair_reduce<float>(const float*, unsigned, unsigned, float*, unsigned, unsigned, hipStream_t);

@@ -140,10 +140,19 @@ NB_API int nb_integrate_f64(double* new_positions, const double* old_positions, 
  *  preserved or cleared between steps, and one workspace serves any number of systems of that size on one stream.
  *  With workspace == NULL, too few bytes, STRICT mode or a system too small to gain, nb_integrate_ws_* IS nb_integrate_*.
  *  Which of the two a call takes is a function of (num_bodies, mode, workspace_bytes) alone: nb_pair_plan_* says whether the
- *  pairwise layout applies to this N and how many bytes it needs (applies == 1 && workspace_bytes >= plan.workspace_bytes).
+ *  pairwise layout applies to this N and how many bytes it asks for; given fewer bytes the step cuts the tournament into more
+ *  slices (nb_workspace_bytes_capped_* says which sizes are useful), given too few for any form it is the one-sided kernel.
  *  The workspace must not overlap any of the three body arrays (NB_ERR_INVALID_ARGUMENT). */
 NB_API int nb_workspace_bytes_f32(unsigned num_bodies, int mode, size_t* bytes);
 NB_API int nb_workspace_bytes_f64(unsigned num_bodies, int mode, size_t* bytes);
+/* The workspace of ONE tournament over the whole system grows with N^2 (0.8 GB at 262 144 bodies fp32, 12.9 GB at 1 Mi, 206 GB at
+ * 4 Mi).  When that is more than a third of the device's memory -- or more than the caller wants to spend -- the tournament is cut
+ * into K slices of bodies that share one reusable region of reaction planes (7 GB at 4 Mi bodies in eight slices; K <= 15):
+ * same pairs, same arithmetic, a few more launches.  nb_workspace_bytes_* asks for the fewest slices the device affords;
+ * nb_workspace_bytes_capped_* for the fewest whose workspace stays within max_bytes (0 = nothing fits: the one-sided kernel);
+ * nb_integrate_ws_* takes the fewest slices that fit the workspace_bytes it is given.  nb_pair_plan_t.slices reports K. */
+NB_API int nb_workspace_bytes_capped_f32(unsigned num_bodies, int mode, size_t max_bytes, size_t* bytes);
+NB_API int nb_workspace_bytes_capped_f64(unsigned num_bodies, int mode, size_t max_bytes, size_t* bytes);
 NB_API int nb_integrate_ws_f32(float* new_positions, const float* old_positions, float* velocities,
                                float delta_time, float damping, unsigned num_bodies, int block_size, int mode,
                                void* workspace, size_t workspace_bytes, nb_stream_t stream);
@@ -280,7 +289,9 @@ typedef struct nb_pair_plan {
     unsigned reaction_slots;   /* per body: partial reaction sums in the workspace                                   */
     unsigned grid_blocks;
     unsigned lds_bytes;
-    size_t   workspace_bytes;
+    size_t   workspace_bytes;  /* what nb_workspace_bytes_* asks for (of the sliced form when slices > 1)                  */
+    unsigned slices;           /* K: 1 = one tournament over the whole system (the fields above describe it); > 1: the     */
+                               /* tournament cut into K slices because one tournament's workspace is not affordable         */
 } nb_pair_plan_t;
 NB_API int nb_pair_plan_f32(unsigned num_bodies, nb_pair_plan_t* plan);
 NB_API int nb_pair_plan_f64(unsigned num_bodies, nb_pair_plan_t* plan);

@@ -24,6 +24,10 @@ NB_API int nb_set_plan_override(int bodies_per_lane, int lanes_per_body, int til
  * the golden sizes with min_bodies = 1). */
 NB_API int nb_set_pair_plan_override(int vectors_per_lane, int waves_per_block, int splits, int min_bodies);
 
+/* Force the number of slices of the one-GPU pairwise step (0 = automatic, 1 = one tournament or nothing, 2 .. 15): tests run the
+ * sliced form at sizes where one tournament would fit. */
+NB_API int nb_set_pair_slices_override(int slices);
+
 /* Smallest slice (bodies per rank) for which a multi-GPU step goes pairwise across the ranks; 0 = automatic (2 048). */
 NB_API int nb_comm_set_pair_min_slice(int min_bodies_per_rank);
 

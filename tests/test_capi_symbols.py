@@ -358,8 +358,11 @@ def test_workspace_memory_guard_without_gpu(pkg):
         assert free_single == 256 * 3 * 262144 * 4 and rc == 0 and free_rank > 0
         assert lib.nb_set_memory_budget(3 * free_single) == 0          # exactly a third: still fine
         assert single(262144) == free_single
-        assert lib.nb_set_memory_budget(3 * free_single - 1) == 0      # one byte less: the one-sided kernel (no workspace asked for)
+        assert lib.nb_set_memory_budget(3 * free_single - 1) == 0      # one byte less: the tournament is cut into two slices (bounded workspace)
+        assert 0 < single(262144) < free_single and pkg.pair_plan(262144).applies == 1 and pkg.pair_plan(262144).slices == 2
+        pkg.set_pair_slices_override(1)                                  # ... unless slicing is switched off: then the one-sided kernel, no workspace asked for
         assert single(262144) == 0 and pkg.pair_plan(262144).applies == 0
+        pkg.set_pair_slices_override(0)
         assert rank(262144, 8) == (0, free_rank)                        # (a rank of eight needs far less: 54 MiB)
         assert lib.nb_set_memory_budget(3 * free_rank - 1) == 0
         assert rank(262144, 8)[0] == 10002                              # NB_ERR_UNSUPPORTED: the step would be the one-sided tile schedule
@@ -368,3 +371,47 @@ def test_workspace_memory_guard_without_gpu(pkg):
         assert lib.nb_set_memory_budget(288 << 30) == 0 and rank(1048576, 2)[0] == 0
     finally:
         lib.nb_set_memory_budget(0)
+        pkg.set_pair_slices_override(0)
+
+
+def test_sliced_pairwise_plan_without_gpu(pkg):
+    """The pairwise layout with a bounded workspace (round 4): one tournament over N bodies wants N^2 / (128 I) * 12 B of reaction
+    slots -- 206 GB at 4 Mi bodies.  Cut into K slices that share one region of reaction planes it needs a fraction; the library
+    picks the fewest slices that fit a third of the device's memory, a caller's cap, or the workspace a step is handed.  Host logic."""
+    import ctypes
+
+    import numpy as np
+
+    lib = pkg.lib()
+    n = 4 * 1048576
+
+    def capped(cap, n=n, dtype=np.float32):
+        return pkg.workspace_bytes(n, dtype, pkg.NB_MODE_FAST, cap)
+
+    try:
+        assert lib.nb_set_memory_budget(288 << 30) == 0
+        one = pkg.pair_plan(1048576)
+        assert (one.applies, one.slices, one.workspace_bytes) == (1, 1, (1 + 1023) * 3 * 1048576 * 4)  # 12.9 GB: affordable, one tournament
+        big = pkg.pair_plan(n)
+        assert big.applies == 1 and big.slices == 3 and big.workspace_bytes < (96 << 30)  # 206 GB in one piece; three slices fit a third of 288 GB
+        assert pkg.workspace_bytes(n) == big.workspace_bytes
+        # a caller's cap: 16 GB -> six slices, 8 GB -> eight; more memory never means more slices
+        sizes = [capped(c << 30) for c in (4, 8, 16, 32, 64, 128)]
+        assert all(a <= b for a, b in zip(sizes, sizes[1:])) and all(0 < b <= (c << 30) for b, c in zip(sizes, (4, 8, 16, 32, 64, 128)))
+        assert capped(16 << 30) <= (16 << 30) and capped(16 << 30) > (8 << 30)
+        assert capped(1 << 20) == 0  # nothing fits one megabyte: the one-sided kernel
+        assert capped(1 << 62) == big.workspace_bytes  # the device's third still binds
+        # the formula of the sliced form, checked at a forced K on a size where everything is round: 262 144 bodies in 4 slices of
+        # 128 blocks: region max(63 diagonal slots, 128 rectangle planes) + per slice (1 + 2 x 1 self sets) + (1 + 2) received arrays
+        pkg.set_pair_slices_override(4)
+        p = pkg.pair_plan(262144)
+        assert p.slices == 4 and p.workspace_bytes == (128 + 4 * (4 * (1 + 2) + 3)) * 3 * 65536 * 4
+        assert capped(p.workspace_bytes - 1, 262144) == 0 and capped(p.workspace_bytes, 262144) == p.workspace_bytes
+        pkg.set_pair_slices_override(0)
+        assert lib.nb_set_pair_slices_override(16) == 10001 and lib.nb_set_pair_slices_override(-1) == 10001
+        need = ctypes.c_size_t(1)
+        assert lib.nb_workspace_bytes_capped_f64(n, pkg.NB_MODE_STRICT, 1 << 40, ctypes.byref(need)) == 0 and need.value == 0
+        assert lib.nb_workspace_bytes_capped_f32(n, pkg.NB_MODE_FAST, 1 << 40, None) == 10001
+    finally:
+        lib.nb_set_memory_budget(0)
+        pkg.set_pair_slices_override(0)

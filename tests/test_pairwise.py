@@ -134,7 +134,15 @@ def test_workspace_rules(gpu, oracle):
 
     one_sided = plain(gpu.NB_MODE_FAST)
     assert step(gpu.NB_MODE_FAST, None, 0).tobytes() == one_sided.tobytes()
-    assert step(gpu.NB_MODE_FAST, work.ptr, need.value - 4).tobytes() == one_sided.tobytes()
+    assert step(gpu.NB_MODE_FAST, work.ptr, 4096).tobytes() == one_sided.tobytes()  # far too few bytes for any form of the layout
+    # a few bytes short of the request: the tournament cut into the fewest slices that still fit (round 4) -- or, if no sliced form
+    # is smaller than the request at this size, the one-sided kernel; nb_workspace_bytes_capped_* says which
+    short = step(gpu.NB_MODE_FAST, work.ptr, need.value - 4)
+    if gpu.workspace_bytes(n, max_bytes=need.value - 4) == 0:
+        assert short.tobytes() == one_sided.tobytes()
+    else:
+        assert short.tobytes() != one_sided.tobytes()
+        np.testing.assert_allclose(short, one_sided, rtol=1e-5, atol=1e-5)
     assert step(gpu.NB_MODE_STRICT, work.ptr, need.value).tobytes() == plain(gpu.NB_MODE_STRICT).tobytes()
     pairwise = step(gpu.NB_MODE_FAST, work.ptr, need.value)
     assert pairwise.tobytes() != one_sided.tobytes()
@@ -224,3 +232,148 @@ def test_pair_reads_nothing_it_did_not_write(gpu, oracle, dtype, n, plan):
             b.free()
     finally:
         gpu.set_pair_plan_override(0, 0, 0, 0)
+
+
+# ------------------------------------------------------------------------------------------------ bounded workspace: K slices
+class sliced:
+    """nb_set_pair_slices_override(K) + the pairwise layout forced at any size, for the duration of a block"""
+
+    def __init__(self, gpu, slices, plan=(0, 0, 0)):
+        self.gpu, self.slices, self.plan = gpu, slices, plan
+
+    def __enter__(self):
+        self.gpu.set_pair_plan_override(*self.plan, 1)
+        self.gpu.set_pair_slices_override(self.slices)
+
+    def __exit__(self, *exc):
+        self.gpu.set_pair_slices_override(0)
+        self.gpu.set_pair_plan_override(0, 0, 0, 0)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("slices,n,plan", [(2, 3000, (2, 8, 1)), (3, 3000, (1, 4, 2)), (4, 4096 + 64, (2, 8, 2)), (5, 20000, (4, 8, 1)), (8, 20000, (2, 16, 1)), (15, 9000, (1, 8, 1)),
+                                           (2, 700, (4, 8, 1)), (3, 130, (1, 4, 1))])
+def test_sliced_pairwise_force_error(gpu, oracle, dtype, slices, n, plan):
+    """The tournament cut into K slices that share one region of reaction planes (csrc/nbody_pair.hip launch_pair_sliced): the
+    diagonal of every slice, the rectangles against the next K/2 slices -- for an even K the rectangle at distance K/2 split
+    between its two partners --, every launch folded into the receiving slice's arrays, K finish launches.  Even and odd K, ragged
+    last slices, slices of a single block (no diagonal reaction slots, an empty half of a split rectangle), masses from 0.5 to 2:
+    the accelerations of ALL bodies against the fp64 direct sum, to the tolerance of the single tournament."""
+    pos = random_bodies(oracle, n, masses="ramp")
+    with sliced(gpu, slices, plan):
+        p = gpu.pair_plan(n, dtype)
+        assert p.applies == 1 and 2 <= p.slices <= slices
+        acc, new_pos = accel_ws(gpu, pos, dtype)
+    # (the bodies are fp32 values in both precisions, so the oracle's fp64 sum over fp32 positions is the yardstick for both; its
+    # softening^2 is double(0.1f)^2, the fp64 kernels' -- the fp32 kernels use float(0.1f * 0.1f), 3e-9 away: far inside 5e-6)
+    ref = oracle.accel_f64(pos, 0, n)
+    err = np.linalg.norm(xyz(acc).astype(np.float64) - ref, axis=1) / np.linalg.norm(ref, axis=1)
+    assert err.max() < (5e-6 if dtype == np.float32 else 1e-12), err.max()
+    assert np.all(acc.reshape(n, 4)[:, 3] == 0) and np.all(new_pos.reshape(n, 4)[:, 3] == pos.reshape(n, 4)[:, 3].astype(dtype))
+
+
+@pytest.mark.parametrize("slices", [2, 3, 4, 7])
+def test_sliced_pairwise_reads_nothing_it_did_not_write_and_is_reproducible(gpu, oracle, slices):
+    """A step over a NaN-filled workspace gives the bits of a step over a zeroed one, for K > 1 too (the reusable region, the
+    received arrays of slices whose diagonal has no slots, the windows of split rectangles); two runs give the same bits; and the
+    result agrees with the single tournament to summation order."""
+    lib = gpu.lib()
+    n = 20000
+    pos0, vel0 = oracle.startup_state(n, np.float32)
+    gpu.set_softening_squared(np.float32(0.1) * np.float32(0.1))
+    out = []
+    with sliced(gpu, slices):
+        need = gpu.workspace_bytes(n)
+        assert need > 0 and gpu.pair_plan(n).slices == slices
+        bufs = [gpu.DeviceBuffer(pos0.nbytes) for _ in range(3)]
+        work = gpu.DeviceBuffer(need)
+        for fill in (0x00, 0xFF, 0x7F):
+            bufs[0].upload(pos0), bufs[2].upload(vel0)
+            gpu.check(lib.nb_memset(work.ptr, fill, need, None), "nb_memset")
+            for k in range(2):
+                gpu.check(lib.nb_integrate_ws_f32(bufs[1 - k].ptr, bufs[k].ptr, bufs[2].ptr, np.float32(0.016), np.float32(1), n, 256, gpu.NB_MODE_FAST, work.ptr, need, None), "nb_integrate_ws")
+            out.append((bufs[0].download(np.zeros_like(pos0)).copy(), bufs[2].download(np.zeros_like(vel0)).copy()))
+        for b in bufs + [work]:
+            b.free()
+    assert np.isfinite(out[1][0]).all()
+    for p, v in out[1:]:
+        assert p.tobytes() == out[0][0].tobytes() and v.tobytes() == out[0][1].tobytes()
+    single = gpu.BodySystemHIP(n, 256, gpu.NBodyParams(), np.float32, pos0, vel0, mode=gpu.NB_MODE_FAST, workspace=True)
+    assert gpu.pair_plan(n).slices == 1
+    for _ in range(2):
+        single.update(np.float32(0.016))
+    one = single.get_position().copy()
+    single.free()
+    assert one.tobytes() != out[0][0].tobytes()
+    np.testing.assert_allclose(out[0][0], one, rtol=2e-5, atol=2e-5)
+
+
+def test_sliced_pairwise_by_the_bytes_on_offer(gpu, oracle):
+    """nb_integrate_ws_* takes the fewest slices that fit the bytes it is handed: the full request -> one tournament; what
+    nb_workspace_bytes_capped_* names for a smaller budget -> that sliced form; one byte less than any form -> the one-sided kernel.
+    And BodySystemHIP(workspace_cap=...) / the hipGraph form run the sliced step."""
+    lib = gpu.lib()
+    n = 262144  # (slicing pays where a block needs no help to fill the chip: at small sizes the sliced forms want MORE memory than one tournament)
+    pos0, vel0 = oracle.startup_state(n, np.float32)
+    gpu.set_softening_squared(np.float32(0.1) * np.float32(0.1))
+    full = gpu.workspace_bytes(n)
+    assert gpu.pair_plan(n).slices == 1 and full > 0
+    third = gpu.workspace_bytes(n, max_bytes=full // 3)
+    assert 0 < third <= full // 3
+    smallest = gpu.workspace_bytes(n, max_bytes=full // 6)
+    assert 0 < smallest <= full // 6 and smallest < third
+    bufs = [gpu.DeviceBuffer(pos0.nbytes) for _ in range(3)]
+    work = gpu.DeviceBuffer(full)
+
+    def step(nbytes):
+        bufs[0].upload(pos0), bufs[2].upload(vel0)
+        gpu.check(lib.nb_integrate_ws_f32(bufs[1].ptr, bufs[0].ptr, bufs[2].ptr, np.float32(0.016), np.float32(1), n, 256, gpu.NB_MODE_FAST, work.ptr, nbytes, None), "nb_integrate_ws_f32")
+        return bufs[1].download(np.zeros_like(pos0)).copy()
+
+    bufs[0].upload(pos0), bufs[2].upload(vel0)
+    gpu.check(lib.nb_integrate_f32(bufs[1].ptr, bufs[0].ptr, bufs[2].ptr, np.float32(0.016), np.float32(1), n, 256, gpu.NB_MODE_FAST, None))
+    one_sided = bufs[1].download(np.zeros_like(pos0)).copy()
+    results = {nbytes: step(nbytes) for nbytes in (full, full - 4, third, third - 4, smallest, smallest - 4)}
+    assert results[full].tobytes() != results[full - 4].tobytes()          # one tournament / a sliced form
+    assert results[smallest].tobytes() != results[third].tobytes()         # more slices
+    assert len({r.tobytes() for r in results.values()}) >= 4
+    for r in results.values():
+        np.testing.assert_allclose(r, one_sided, rtol=2e-5, atol=2e-5)
+    tiny = gpu.workspace_bytes(n, max_bytes=1 << 16)
+    assert tiny == 0 and step(1 << 16).tobytes() == one_sided.tobytes()     # nothing fits: exactly nb_integrate_*
+    for b in bufs + [work]:
+        b.free()
+    a = gpu.BodySystemHIP(n, 256, gpu.NBodyParams(), np.float32, pos0, vel0, mode=gpu.NB_MODE_FAST, workspace=True, workspace_cap=full // 3)
+    b = gpu.BodySystemHIP(n, 256, gpu.NBodyParams(), np.float32, pos0, vel0, mode=gpu.NB_MODE_FAST, workspace=True, workspace_cap=full // 3)
+    assert a._workspace_bytes == third
+    for _ in range(4):
+        a.update(np.float32(0.016))
+    b.update_many(np.float32(0.016), 4)
+    assert a.get_position().tobytes() == b.get_position().tobytes() and a.get_velocity().tobytes() == b.get_velocity().tobytes()
+    a.free(), b.free()
+
+
+def test_sliced_pairwise_4mi_bodies_in_16_gb(gpu, O):
+    """4 194 304 bodies -- one tournament would want 206 GB of reaction slots -- step pairwise inside 16 GB:
+    sampled accelerations against the fp64 direct sum, total momentum change zero to summation accuracy."""
+    import os
+
+    n = 4 * 1048576
+    omp = O.Oracle(openmp=True)
+    omp.set_num_threads(min(16, os.cpu_count() or 1))
+    pos0, _ = omp.startup_state(n, np.float32)
+    need = gpu.workspace_bytes(n, max_bytes=16 << 30)
+    plan = gpu.pair_plan(n)
+    assert 0 < need <= (16 << 30) and plan.applies == 1 and plan.slices >= 2
+    system = gpu.BodySystemHIP(n, 256, gpu.NBodyParams(), np.float32, pos0, np.zeros_like(pos0), mode=gpu.NB_MODE_FAST, workspace=True, workspace_cap=16 << 30)
+    assert system._workspace_bytes == need
+    system.update(np.float32(1))
+    acc = xyz(system.get_velocity().copy()).astype(np.float64)
+    system.free()
+    rng = np.random.default_rng(11)
+    sample = np.sort(rng.choice(n, 96, replace=False))
+    ref = np.stack([omp.accel_f64(pos0, int(i), 1)[0] for i in sample])
+    err = np.linalg.norm(acc[sample] - ref, axis=1) / np.linalg.norm(ref, axis=1)
+    assert err.max() < 1e-5, err.max()
+    total = np.abs(acc.sum(axis=0)).max() / np.abs(acc).sum(axis=0).max()
+    assert total < 1e-6, total

@@ -210,3 +210,31 @@ def test_pairwise_graph_replay_vs_golden_16384(gpu, oracle):
     err = rel_err(system.get_position(), g["pos_10"])
     system.free()
     assert err.max() <= 2e-5, err.max()
+
+
+# ------------------------------------------------------------------------------- the bounded-workspace form (K slices)
+@pytest.mark.parametrize("slices", [2, 3, 5])
+@pytest.mark.parametrize("n", [1024, 4096])
+def test_sliced_pairwise_fp32_vs_golden(gpu, n, slices):
+    """The tournament cut into K slices (what a system too large for one tournament's workspace steps through) against the CPU
+    path's trajectory at the golden sizes: the same envelope again."""
+    g = load_golden(n, "f32")
+    gpu.set_pair_slices_override(slices)
+    try:
+        with forced_pairwise(gpu, (1, 8, 1)):  # blocks of 128 bodies: 8 / 32 blocks to cut
+            assert 2 <= gpu.pair_plan(n, np.float32).slices <= slices  # (rounding to whole blocks can leave fewer slices than asked for)
+            errs, _ = trajectory_errors(gpu, n, np.float32, g, golden_steps(g))
+    finally:
+        gpu.set_pair_slices_override(0)
+    assert_fp32_envelope(errs)
+
+
+def test_sliced_pairwise_fp64_vs_golden(gpu):
+    g = load_golden(4096, "f64")
+    gpu.set_pair_slices_override(4)
+    try:
+        with forced_pairwise(gpu, (2, 8, 1)):
+            errs, _ = trajectory_errors(gpu, 4096, np.float64, g, golden_steps(g))
+    finally:
+        gpu.set_pair_slices_override(0)
+    assert_fp64_envelope(errs)
