@@ -220,22 +220,28 @@ def other_configs(pkg, lib, headline):
         ("configs[0]'s system on the GPU", 1024, False, "fast", 100),
         ("configs[0]'s system on the GPU", 1024, False, "strict", 100),
         ("small system", 16384, False, "fast", 200),
+        # beyond BASELINE's sizes: one tournament would want 206 GB of reaction slots; the tournament cut into slices inside 16 GB
+        ("4 Mi bodies, workspace capped at 16 GB", 4194304, False, "fast", 2),
     ]
     out = []
     for what, n, fp64, mode_name, steps in cases:
         dtype = np.float64 if fp64 else np.float32
         mode = pkg.NB_MODE_FAST if mode_name == "fast" else pkg.NB_MODE_STRICT
         layouts = ["one-sided"] if mode_name == "fast" else ["strict"]
-        if mode_name == "fast" and pkg.workspace_bytes(n, dtype, mode):
+        cap = (16 << 30) if n > 1048576 else None
+        if mode_name == "fast" and pkg.workspace_bytes(n, dtype, mode, cap):
             layouts.insert(0, "pairwise")
+        if cap is not None:
+            layouts = layouts[:1]  # (the one-sided kernel at this size: 3.6 s per step, nothing new)
         pos0 = vel0 = None
         for layout in layouts:
             if (n, fp64, mode_name, layout) == headline:
                 continue
             if pos0 is None:
                 pos0, vel0 = make_bodies(n, dtype)
-            system = pkg.BodySystemHIP(n, 256, pkg.NBodyParams(), dtype, pos0, vel0, mode=mode, workspace=(layout == "pairwise"))
+            system = pkg.BodySystemHIP(n, 256, pkg.NBodyParams(), dtype, pos0, vel0, mode=mode, workspace=(layout == "pairwise"), workspace_cap=cap)
             dt = dtype(np.float32(0.016))
+            system_bytes = system._workspace_bytes
             system.update(dt)
             e0, e1 = pkg.Event(), pkg.Event()
             system.synchronize()
@@ -250,6 +256,8 @@ def other_configs(pkg, lib, headline):
             # (kept short: the whole line should stay well under what a log tail holds; interactions/s = bodies^2 / ms_per_step)
             out.append({"workload": what, "bodies": n, "dtype": "f64" if fp64 else "f32", "mode": mode_name, "layout": layout, "steps": steps,
                         "ms_per_step": float(f"{ms:.5g}"), "frac": frac, "executed_frac": executed})
+            if cap is not None:
+                out[-1]["workspace_bytes"] = system_bytes
     return out
 
 

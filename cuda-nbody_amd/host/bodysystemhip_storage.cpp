@@ -58,18 +58,22 @@ template <std::floating_point T, template <std::floating_point> class Storage> a
     const int mode = (Storage<T>::workspace_capable && nbody_hip::use_workspace()) ? nbody_hip::integration_mode() : -2;
     if (mode == workspace_mode_) return;
     workspace_mode_  = mode;
+    // Ask, allocate; when the device has no room for it, ask again for a form of the layout that fits in half as much (the library
+    // cuts the tournament into more slices) -- and only when nothing fits is the step the one-sided kernel.
+    std::size_t cap  = nbody_hip::workspace_cap_bytes() != 0 ? nbody_hip::workspace_cap_bytes() : ~std::size_t{0};
     std::size_t need = 0;
-    if (mode >= 0) {
+    while (mode >= 0) {
         if constexpr (std::same_as<T, float>) {
-            hip_check(nb_workspace_bytes_f32(this->nb_bodies_, mode, &need), "nb_workspace_bytes_f32");
+            hip_check(nb_workspace_bytes_capped_f32(this->nb_bodies_, mode, cap, &need), "nb_workspace_bytes_capped_f32");
         } else {
-            hip_check(nb_workspace_bytes_f64(this->nb_bodies_, mode, &need), "nb_workspace_bytes_f64");
+            hip_check(nb_workspace_bytes_capped_f64(this->nb_bodies_, mode, cap, &need), "nb_workspace_bytes_capped_f64");
         }
-    }
-    if (need > workspace_.size()) {
+        if (need <= workspace_.size()) break;
         try {
             workspace_ = DeviceArray<unsigned char>(need);
-        } catch (const std::runtime_error&) {  // no room for it: the step is then the one-sided kernel, nothing else changes
+            break;
+        } catch (const std::runtime_error&) {
+            cap  = need / 2;
             need = 0;
         }
     }

@@ -27,6 +27,12 @@ inline bool& use_workspace() {
     static bool on = true;
     return on;
 }
+// ... and `nbody --workspace-mib=<n>` bounds what a body system spends on it (0 = whatever the library asks for: at most a third
+// of the device's memory): the library then cuts the pair tournament into as many slices as the bound needs (nb_workspace_bytes_capped_*).
+inline std::size_t& workspace_cap_bytes() {
+    static std::size_t cap = 0;
+    return cap;
+}
 }  // namespace nbody_hip
 
 inline auto set_softening_squared(float softeningSq) -> void { hip_check(nb_set_softening_sq_f32(softeningSq), "set_softening_squared"); }

@@ -6,7 +6,7 @@
 //                     --tipsy=<file> -i,--iterations=<n> --blockSize=<n>      (single-dash spellings accepted too)
 //   extensions      : --numdevices=<n> | --devices=<list> (the NVIDIA sample's -numdevices, which this fork of it dropped)
 //                     --mode=fast|strict  --config=shell|random|expand  --demo=<0..6>  --steps=<n>  --dump=<file>
-//                     --seed=<n>  --graph  --no-workspace  --inject-error=<x> (test hook for --compare)
+//                     --seed=<n>  --graph  --no-workspace  --workspace-mib=<n>  --inject-error=<x> (test hook for --compare)
 #include "compute.hpp"
 #include "integrate_nbody_hip.hpp"
 
@@ -49,6 +49,7 @@ struct Options {
     std::optional<unsigned> seed;
     bool                  graph = false;
     bool                  no_workspace = false;
+    std::size_t           workspace_mib = 0;  // 0: no bound of our own
     std::vector<int>      devices;  // --numdevices=<n> (devices 0..n-1) or --devices=<a,b,...>: bodies sharded over several GPUs
     std::optional<std::size_t> demo;   // row of Compute::demo_params (the reference reaches them from the viewer's keys only)
     double                inject_error = 0.0;
@@ -82,6 +83,8 @@ Options:
   --graph                     --benchmark issues its (even number of) iterations as one captured hipGraph
   --no-workspace              Fast mode without scratch memory: every directed interaction evaluated, as the reference kernel does
                               (default: the body system owns a workspace and every PAIR of bodies is evaluated once)
+  --workspace-mib UINT        Spend at most this many MiB on that workspace (the pair tournament is then cut into slices that share
+                              one region of reaction planes; default: what the library asks for, at most a third of the device's memory)
   --inject-error FLOAT        Test hook: added to body 0's x of the fast result before --compare checks it
 )";
 
@@ -154,6 +157,9 @@ auto parse_args(int argc, char** argv) -> std::pair<Status, Options> {
         } else if (name == "steps") {
             const auto v = take_value();
             ok           = v && parse_number(*v, options.steps);
+        } else if (name == "workspace-mib" || name == "workspace_mib") {
+            const auto v = take_value();
+            ok           = v && parse_number(*v, options.workspace_mib);
         } else if (name == "seed") {
             const auto v = take_value();
             unsigned   s = 0;
@@ -245,6 +251,7 @@ auto main(int argc, char** argv) -> int {
         if (cmd_options.seed) std::srand(*cmd_options.seed);
         nbody_hip::integration_mode() = cmd_options.mode;
         nbody_hip::use_workspace()    = !cmd_options.no_workspace;
+        nbody_hip::workspace_cap_bytes() = cmd_options.workspace_mib << 20;
 
         const auto compare_to_cpu = (cmd_options.compare || cmd_options.qatest) && (!cmd_options.cpu);
         const auto headless_run   = cmd_options.benchmark || compare_to_cpu || cmd_options.steps > 0 || !cmd_options.dump.empty();

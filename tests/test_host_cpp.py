@@ -309,6 +309,30 @@ def test_cli_fast_on_a_three_species_galaxy_file(host, tmp_path, oracle):
 
 
 @pytest.mark.gpu
+def test_cli_workspace_cap_steps_through_the_sliced_tournament(tmp_path):
+    """`nbody --workspace-mib=<n>`: the body system spends at most that much on its workspace, the library cuts the pair tournament
+    into slices that share one region of reaction planes: the same trajectory up to summation order as the default (one
+    tournament, 805 MB at 262 144 bodies) and as --no-workspace, different bits; --compare passes; the benchmark lines print."""
+    n = 262144
+    dumps = {}
+    for name, extra in (("one", []), ("capped", ["--workspace-mib=200"]), ("tiny", ["--workspace-mib=1"]), ("none", ["--no-workspace"])):
+        dump = tmp_path / f"{name}.bin"
+        r = run_cli(f"--numbodies={n}", "--steps=2", f"--dump={dump}", *extra)
+        assert r.returncode == 0, r.stderr
+        dumps[name] = np.fromfile(dump, dtype=np.float32)
+    assert dumps["capped"].tobytes() != dumps["one"].tobytes() and dumps["capped"].tobytes() != dumps["none"].tobytes()
+    assert dumps["tiny"].tobytes() == dumps["none"].tobytes()  # nothing fits one MiB: the one-sided kernel
+    p = lambda a: a[:4 * n].reshape(n, 4)[:, :3]  # noqa: E731
+    scale = np.abs(p(dumps["one"])).max()
+    assert np.abs(p(dumps["capped"]) - p(dumps["one"])).max() / scale < 2e-5
+    assert np.abs(p(dumps["capped"]) - p(dumps["none"])).max() / scale < 2e-5
+    r = run_cli("--compare", "--numbodies=65536", "--workspace-mib=64")
+    assert r.returncode == 0 and "  OK" in r.stdout, r.stdout + r.stderr
+    r = run_cli("--benchmark", f"--numbodies={n}", "--workspace-mib=200", "-i", "4")
+    assert r.returncode == 0 and "billion interactions per second" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
 def test_cli_tipsy_and_other_configs(host, tmp_path, oracle):
     n = 700
     oracle.srand(9)
