@@ -42,6 +42,7 @@
 #include "nbody_kernels.h"
 
 #include <algorithm>
+#include <cmath>
 #include <vector>
 
 #ifdef NB_PAIR_STAMPS
@@ -501,6 +502,23 @@ template <typename T, int R> hipError_t launch_r(const PairArgs<T>& args, int wa
 
 }  // namespace
 
+// Workgroups per block, by how the launch fills the chip: all workgroups of a launch carry the same work, so a grid of r "rounds" of
+// resident workgroups (256 CUs x 16 waves / S) takes ceil(r) rounds of time -- 1 639 blocks of eight waves are 3.2 rounds and cost 4
+// (80 %); split in four they are 12.8 and cost 13 (98 %).  Starting from `wanted`, doubles C while that gains more than 2 % and every
+// wave keeps at least four units.  (Up to one round nothing is lost: the workgroups all run at once.)
+inline unsigned splits_for_full_rounds(unsigned blocks, unsigned units_per_block, int S, unsigned wanted) {
+    const double resident = 256.0 * 16.0 / S;
+    auto         eff      = [&](unsigned C) {
+        const double r = blocks * static_cast<double>(C) / resident;
+        return r <= 1.0 ? 1.0 : r / std::ceil(r);
+    };
+    unsigned best = std::max(1u, wanted);
+    for (unsigned C = best * 2; C <= 16 && units_per_block >= C * static_cast<unsigned>(S) * 4; C *= 2) {
+        if (eff(C) > eff(best) + 0.02) best = C;
+    }
+    return best;
+}
+
 // Geometry (measured: tools/pair_crossover.py -> profiles/round3_pair_crossover_f32.jsonl, _f64.jsonl).
 //   R = 4 vectors per lane (fp32: 8 bodies i, fp64: 4) is what 128 VGPRs hold and what amortises the 9 rotation moves best;
 //   smaller systems take R = 2: twice the blocks, so twice the workgroups to spread over the chip.
@@ -525,6 +543,7 @@ template <typename T> PairPlan plan_pair(unsigned n, int cu_count, int ovr_r, in
     const unsigned block  = 64u * static_cast<unsigned>(R * W);
     const unsigned blocks = (n + block - 1) / block;
     const unsigned units  = (blocks / 2 + 1) * static_cast<unsigned>(R * W);
+    C = splits_for_full_rounds(blocks, units, S, C);  // (the sizes the table was tuned on -- powers of two -- come out unchanged)
     if (ovr_c > 0) C = static_cast<unsigned>(ovr_c);
     while (C > 1 && units < C * static_cast<unsigned>(S)) C /= 2;  // no wave without a unit
     p.vectors_per_lane = R;
@@ -610,9 +629,10 @@ template <typename T> PairSlicing plan_pair_sliced(unsigned n, unsigned slices, 
     p.even     = (p.slices % 2) == 0;
     if (p.partners + 1 > static_cast<unsigned>(kMaxRecv) || p.partners + 1 > static_cast<unsigned>(kMaxSelfSets)) return PairSlicing{};
     p.plane = p.slice_bodies;  // (a multiple of 64 already)
-    auto splits = [&](unsigned units) {  // workgroups per block: fill the chip (~512 workgroups of 8 waves) while a wave keeps >= 2 units
+    auto splits = [&](unsigned units) {  // workgroups per block: fill the chip (~512 workgroups of 8 waves) while a wave keeps >= 2 units, then whole rounds
         unsigned C = 1;
         while (per * C * 2 <= 512 && units >= C * 2 * static_cast<unsigned>(S) * 2) C *= 2;
+        C = splits_for_full_rounds(per, units, S, C);
         if (ovr_c > 0) C = static_cast<unsigned>(ovr_c);
         while (C > 1 && units < C * static_cast<unsigned>(S)) C /= 2;
         return C;
