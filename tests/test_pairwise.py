@@ -377,3 +377,39 @@ def test_sliced_pairwise_4mi_bodies_in_16_gb(gpu, O):
     assert err.max() < 1e-5, err.max()
     total = np.abs(acc.sum(axis=0)).max() / np.abs(acc).sum(axis=0).max()
     assert total < 1e-6, total
+
+
+def test_pair_default_plan_at_awkward_body_counts(gpu, O):
+    """The automatic plan at body counts that are not powers of two (round 4: workgroups per block chosen so that the launch fills
+    whole rounds of resident workgroups -- C up to 16 --, ragged last blocks and tiles, odd and even block counts): sampled
+    accelerations against the fp64 direct sum and the pairwise layout's built-in property, total momentum change = 0; and the same
+    sizes through the bounded-workspace form with the fewest slices that fit a quarter of the full request."""
+    import os
+
+    omp = O.Oracle(openmp=True)
+    omp.set_num_threads(min(16, os.cpu_count() or 1))
+    rng = np.random.default_rng(2024)
+    sizes = [9001, 12345, 20000, 33333, 65537, 100000, 131071, 196609, 300000] + [int(x) for x in rng.integers(9000, 400000, 6)]
+    seen = set()
+    for n in sizes:
+        pos0, _ = omp.startup_state((n + 7) // 8 * 8, np.float32)
+        pos0 = pos0[:4 * n].copy()
+        plan = gpu.pair_plan(n)
+        assert plan.applies == 1 and plan.slices == 1
+        seen.add(plan.splits)
+        full = gpu.workspace_bytes(n)
+        for cap in (None, full // 4):
+            if cap is not None and gpu.workspace_bytes(n, max_bytes=cap) == 0:
+                continue  # (small systems: no sliced form is that much smaller)
+            system = gpu.BodySystemHIP(n, 256, gpu.NBodyParams(), np.float32, pos0, np.zeros_like(pos0), mode=gpu.NB_MODE_FAST, workspace=True, workspace_cap=cap)
+            system.update(np.float32(1))
+            acc = xyz(system.get_velocity().copy()).astype(np.float64)
+            system.free()
+            sample = np.sort(rng.choice(n, 48, replace=False))
+            sample[0], sample[-1] = 0, n - 1
+            ref = np.stack([omp.accel_f64(pos0, int(i), 1)[0] for i in sample])
+            err = np.linalg.norm(acc[sample] - ref, axis=1) / np.linalg.norm(ref, axis=1)
+            assert err.max() < 1e-5, (n, cap, err.max())
+            total = np.abs(acc.sum(axis=0)).max() / np.abs(acc).sum(axis=0).max()
+            assert total < 1e-6, (n, cap, total)
+    assert len(seen) >= 3, seen  # several values of C were exercised
