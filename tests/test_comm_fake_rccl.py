@@ -263,6 +263,29 @@ def test_pairwise_step_across_ranks_full_size(tmp_path, oracle):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("world,workspace", [(4, False), (4, True), (8, True)])
+def test_full_size_calm_system_five_steps_tightly(tmp_path, oracle, world, workspace):
+    """the SHELL start-up system collapses and amplifies any difference ~10x per step, so the full-size FAST
+    checks above can hold only ONE step tightly.  The EXPAND configuration (bodies moving outward from rest positions,
+    randomise_bodies.cpp:149-187) amplifies nothing: 262 144 bodies over 4 and 8 ranks, one-sided tiles and pairwise across the ranks,
+    FIVE steps against one rank at 1e-5 of the system's size -- a stale or missing tile at ANY of the five steps would be off by
+    orders of magnitude more (a body moves ~1e-2 of the system's size per step)."""
+    n, steps = 262144, 5
+    oracle.srand(3)
+    pos0, vel0 = oracle.randomise(2, n, 1.54, 8.0, np.float32)  # NBODY_CONFIG_EXPAND
+    got = _run(tmp_path, "all", pos0, vel0, world, steps, "fast", workspace=workspace)
+    assert list(got["layout"]) == [1 if workspace else 0] * world
+    for k in range(1, world):
+        assert got[f"pos_{k}"].tobytes() == got["pos_0"].tobytes()
+    size = np.abs(got["single_pos"].reshape(n, 4)[:, :3]).max()
+    moved = np.abs(got["single_pos"] - pos0).reshape(n, 4)[:, :3].max()
+    assert moved > 1e-2 * size  # (the bodies did move: five steps are not a no-op)
+    np.testing.assert_allclose(got["pos_0"], got["single_pos"], rtol=0, atol=1e-5 * size)
+    vel = np.concatenate([got[f"vel_{k}"] for k in range(world)])
+    np.testing.assert_allclose(vel, got["single_vel"], rtol=0, atol=1e-5 * np.abs(got["single_vel"]).max() + 1e-4 * size)
+
+
+@pytest.mark.gpu
 def test_cli_sharded_fast_owns_workspaces(tmp_path):
     """`nbody --devices=0,0,0,0` in FAST mode: BodySystemHIPSharded lends every shard the workspace the library asks for, so the
     step is the pairwise one across the shards; `--no-workspace` is the one-sided tile schedule.  Same trajectory up to summation
