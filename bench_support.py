@@ -1,0 +1,351 @@
+"""bench_support.py -- what bench.py measures AROUND its timed region (never inside it): the workload generator, the other
+BASELINE configs, the one-rank projection, the per-kernel split of the pairwise step, the CPU baseline and the N > 1 diagnostics.
+Benchmark support, not product: everything here goes through the C-ABI via cuda-nbody_amd/__init__.py; the CPU baseline is the
+only place that loads oracle/ (test infrastructure).  Reference citations are relative to /root/reference/."""
+from __future__ import annotations
+
+import ctypes
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+import __graft_entry__ as entry  # noqa: E402
+
+FP32_VECTOR_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md:41
+FP64_VECTOR_PEAK_TFLOPS = 78.6   # public spec
+HBM_PEAK_GBS = 8000.0
+
+
+def make_bodies(n: int, dtype):
+    """The bodies a fresh `nbody --numbodies=N [--fp64]` process starts from, drawn by the PRODUCT's randomise_bodies
+    (libnbody_host.so, pinned bit-for-bit to the reference's own code in tests/test_host_cpp.py): SHELL configuration,
+    third segment of the unseeded rand() stream (fp32 reset, fp64 reset with demo_params[0] scales, then the active
+    precision with the N-scaled params).  "synthetic random bodies" of BASELINE.json."""
+    host = ctypes.CDLL(os.path.join(ROOT, "cuda-nbody_amd", "libnbody_host.so"))
+    f32p, f64p = ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_double)
+    host.nbh_srand.argtypes = [ctypes.c_uint]
+    host.nbh_randomise_f32.argtypes = [ctypes.c_int, f32p, f32p, ctypes.c_size_t, ctypes.c_float, ctypes.c_float]
+    host.nbh_randomise_f64.argtypes = [ctypes.c_int, f64p, f64p, ctypes.c_size_t, ctypes.c_float, ctypes.c_float]
+    host.nbh_scale_params_for.argtypes = [ctypes.c_size_t, f32p, f32p]
+    shell = 1  # NBodyConfig::NBODY_CONFIG_SHELL
+
+    def draw(T, cluster, velocity):
+        pos, vel = np.zeros(4 * n, T), np.zeros(4 * n, T)
+        if T == np.float32:
+            host.nbh_randomise_f32(shell, pos.ctypes.data_as(f32p), vel.ctypes.data_as(f32p), n, cluster, velocity)
+        else:
+            host.nbh_randomise_f64(shell, pos.ctypes.data_as(f64p), vel.ctypes.data_as(f64p), n, cluster, velocity)
+        return pos, vel
+
+    host.nbh_srand(1)
+    draw(np.float32, 1.54, 8.0)
+    draw(np.float64, 1.54, 8.0)
+    c, v = ctypes.c_float(1.54), ctypes.c_float(8.0)
+    host.nbh_scale_params_for(n, ctypes.byref(c), ctypes.byref(v))
+    return draw(dtype, c.value, v.value)
+
+
+# What the instruction mix of the production loop can do at best on this chip: the unit-mass inner loop run in isolation
+# (tools/loop_microbench_gen.py, profiles/round2_loop_microbench.txt) sustains one packed interaction pair per 61.5 SIMD cycles
+# with 3-4 runnable waves (11 v_pk_* at ~4 cycles + 2 v_rsq_f32 at ~8.3); at the nominal 2.4 GHz that is
+# 1024 SIMDs x 128 interactions / 61.5 cycles = 5.115e12 interactions/s = 65.0 % of the 157.3 TFLOP/s "20 flop" roofline.
+FP32_ISSUE_CEILING_INTERACTIONS_PER_S = 1024 * 128 * 2.4e9 / 61.5
+# fp64 (profiles/round2_fp64_issue_probes.txt): 14 add/mul/fma at 4.41 cycles + one v_rsq_f64 at 16.3 = 78 cycles per interaction and wave
+FP64_ISSUE_CEILING_INTERACTIONS_PER_S = 1024 * 64 * 2.4e9 / 78.0
+
+
+def pair_evaluations(pair) -> float:
+    """pair evaluations per step of the pairwise layout: NB x (NB/2 + 1) block pairs of (64 I)^2"""
+    return float(pair.blocks) * (pair.blocks // 2 + 1) * pair.block_bodies * pair.block_bodies
+
+
+def fractions(n, fp64, layout, ms, pair=None):
+    """(frac, executed_frac) of the vector-FMA peak.  `frac`: ALGORITHMIC flop of the reference convention -- 20 (30) per directed
+    interaction, N^2 interactions (compute.cpp:16-18) -- over the time; it can pass 1 for the pairwise layout, which
+    evaluates each pair once.  `executed_frac`: the flop the kernels really issue -- 24 (36) per pair evaluation for the pairwise
+    layout, the algorithmic count for the one-sided and STRICT kernels (they do evaluate every directed interaction) -- i.e. how
+    busy the FMA pipes are; never above 1."""
+    flops, peak = (30, FP64_VECTOR_PEAK_TFLOPS) if fp64 else (20, FP32_VECTOR_PEAK_TFLOPS)
+    frac = flops * float(n) * n / (ms * 1e-3) / (peak * 1e12)
+    if layout != "pairwise" or pair is None:
+        return round(frac, 4), round(frac, 4)
+    return round(frac, 4), round((36 if fp64 else 24) * pair_evaluations(pair) / (ms * 1e-3) / (peak * 1e12), 4)
+
+
+def other_configs(pkg, lib, headline):
+    """BASELINE.json configs besides the headline one, plus STRICT (the parity-exact mode) and, for FAST, both layouts
+    (pairwise = nb_integrate_ws_* with a workspace, one-sided = nb_integrate_*), each as
+    {workload, bodies, dtype, mode, layout, steps, ms_per_step, frac, executed_frac}: 1 warm-up step, then K steps between two
+    HIP events on the launch stream (the reference's GPU protocol, compute_cuda.cpp:183-195); the fractions: see fractions()."""
+    cases = [
+        ("configs[1]", 65536, False, "fast", 200),
+        ("configs[2]", 262144, False, "fast", 20),
+        ("configs[4]", 262144, True, "fast", 5),
+        ("configs[3]'s system on ONE GPU", 1048576, False, "fast", 3),
+        ("STRICT = the CPU path's bits", 262144, False, "strict", 5),
+        ("STRICT", 262144, True, "strict", 3),
+        ("configs[0]'s system on the GPU", 1024, False, "fast", 100),
+        ("configs[0]'s system on the GPU", 1024, False, "strict", 100),
+        ("small system", 16384, False, "fast", 200),
+        # beyond BASELINE's sizes: one tournament would want 206 GB of reaction slots; the tournament cut into slices inside 16 GB
+        ("4 Mi bodies, workspace capped at 16 GB", 4194304, False, "fast", 2),
+    ]
+    out = []
+    for what, n, fp64, mode_name, steps in cases:
+        dtype = np.float64 if fp64 else np.float32
+        mode = pkg.NB_MODE_FAST if mode_name == "fast" else pkg.NB_MODE_STRICT
+        layouts = ["one-sided"] if mode_name == "fast" else ["strict"]
+        cap = (16 << 30) if n > 1048576 else None
+        if mode_name == "fast" and pkg.workspace_bytes(n, dtype, mode, cap):
+            layouts.insert(0, "pairwise")
+        if cap is not None:
+            layouts = layouts[:1]  # (the one-sided kernel at this size: 3.6 s per step, nothing new)
+        pos0 = vel0 = None
+        for layout in layouts:
+            if (n, fp64, mode_name, layout) == headline:
+                continue
+            if pos0 is None:
+                pos0, vel0 = make_bodies(n, dtype)
+            system = pkg.BodySystemHIP(n, 256, pkg.NBodyParams(), dtype, pos0, vel0, mode=mode, workspace=(layout == "pairwise"), workspace_cap=cap)
+            dt = dtype(np.float32(0.016))
+            system_bytes = system._workspace_bytes
+            system.update(dt)
+            e0, e1 = pkg.Event(), pkg.Event()
+            system.synchronize()
+            e0.record(None)
+            for _ in range(steps):
+                system.update(dt)
+            e1.record(None)
+            e1.synchronize()
+            ms = e0.elapsed_ms(e1) / steps
+            system.free()
+            frac, executed = fractions(n, fp64, layout, ms, pkg.pair_plan(n, dtype) if layout == "pairwise" else None)
+            # (kept short: the whole line should stay well under what a log tail holds; interactions/s = bodies^2 / ms_per_step)
+            out.append({"workload": what, "bodies": n, "dtype": "f64" if fp64 else "f32", "mode": mode_name, "layout": layout, "steps": steps,
+                        "ms_per_step": float(f"{ms:.5g}"), "frac": frac, "executed_frac": executed})
+            if cap is not None:
+                out[-1]["workspace_bytes"] = system_bytes
+    return out
+
+
+def rank_projection(pkg, lib, n, dtype, dt, damping, single_ms):
+    """ms of ONE rank's kernels of a 2 / 4 / 8-rank pairwise step on this GPU (rank G/2; diagonal + G/2 rectangles + folds + finish),
+    no exchange -- tools/pair_rank_probe.py has the longer version."""
+    f32 = np.dtype(dtype) == np.float32
+    emulate = lib.nb_emulate_pair_rank_f32 if f32 else lib.nb_emulate_pair_rank_f64
+    pos0, vel0 = make_bodies(n, dtype)
+    bufs = [pkg.DeviceBuffer(pos0.nbytes) for _ in range(3)]
+    bufs[0].upload(pos0), bufs[2].upload(vel0)
+    out = {"what": "PROJECTION, not a multi-GPU measurement: kernel ms of ONE rank of a G-rank pairwise step, alone on one GPU, no exchange",
+           "single_gpu_ms_per_step": float(f"{single_ms:.5g}"), "ranks": {}}
+    for G in (2, 4, 8):
+        need = ctypes.c_size_t(0)
+        if emulate(None, None, None, None, ctypes.byref(need), n, G, 0, dt, damping, None) != 0:
+            continue
+        work = pkg.DeviceBuffer(need.value)
+
+        def one_step():
+            pkg.check(emulate(bufs[1].ptr, bufs[0].ptr, bufs[2].ptr, work.ptr, ctypes.byref(need), n, G, G // 2, dt, damping, None), "nb_emulate_pair_rank")
+
+        one_step()
+        pkg.check(lib.nb_device_synchronize())
+        e0, e1 = pkg.Event(), pkg.Event()
+        e0.record(None)
+        for _ in range(10):
+            one_step()
+        e1.record(None)
+        e1.synchronize()
+        ms = e0.elapsed_ms(e1) / 10
+        out["ranks"][str(G)] = {"kernel_ms": float(f"{ms:.5g}"), "speedup_excl_exchange": round(single_ms / ms, 2)}
+        work.free()
+    for b in bufs:
+        b.free()
+    return out
+
+
+def pair_kernel_split(pkg, lib, step, stream, reps=10):
+    """Average duration of the two kernels of the pairwise step, each on its own: pair_forces (the dominant kernel) and pair_finish,
+    from HIP events on the launch stream -- one before the step, one the library records BETWEEN the two launches
+    (nb_set_pair_probe_event, tuning header), one after.  Taken after the timed region."""
+    before, between, after = pkg.Event(), pkg.Event(), pkg.Event()
+    forces = finish = 0.0
+    pkg.check(lib.nb_set_pair_probe_event(between.h), "nb_set_pair_probe_event")
+    try:
+        for _ in range(reps):
+            before.record(stream)
+            step()
+            after.record(stream)
+            after.synchronize()
+            forces += before.elapsed_ms(between)
+            finish += between.elapsed_ms(after)
+    finally:
+        pkg.check(lib.nb_set_pair_probe_event(None), "nb_set_pair_probe_event")
+    return forces / reps, finish / reps
+
+
+def cpu_baseline(n, dtype, pos0, vel0, sample_bodies):
+    """The CPU path (oracle/: a port of BodySystemCPU<T>::update; test infrastructure, loaded here only) timed on this host:
+    a bounded sample of the headline workload, and BASELINE configs[0] exactly as stated -- 1 024 bodies, fp32, 100 steps, no
+    warm-up, steady clock around the loop (compute_cpu.cpp:72-88)."""
+    O = entry.load_oracle()
+    orc1 = O.Oracle()
+    pos_h, vel_h = orc1.startup_state(n, dtype)
+    # the workload above came from the product's randomise_bodies; the checker's must be the same bytes
+    assert pos_h.tobytes() == pos0.tobytes() and vel_h.tobytes() == vel0.tobytes(), "product and oracle start-up bodies differ"
+    sample = sample_bodies or max(8, min(n, int(2.0e10 // n) // 8 * 8))
+    base = {}
+    # OpenMP leg: the reference's fp32 loop forks INSIDE the j loop (bodysystemcpu.cpp:156-168), i.e. one fork/join per body j --
+    # it is slow by construction, so it gets a smaller sample and at most the box's CPU share (16 threads per GPU).
+    for key, omp, smp in (("one_thread", False, sample), ("openmp", True, max(8, sample // 16 // 8 * 8))):
+        orc = O.Oracle(openmp=omp)
+        if omp:
+            orc.set_num_threads(min(16, os.cpu_count() or 1))
+        ms = orc.benchmark_partial(pos_h, smp)
+        base[key] = {"value": smp * float(n) / (ms * 1e-3), "cores": orc.num_threads() if omp else 1, "ms": ms, "sample_bodies_i": smp}
+    p0, v0 = orc1.startup_state(1024, np.float32)
+    ms0 = orc1.benchmark(p0, v0, np.float32(0.016), 100)
+    return {
+        "value": base["one_thread"]["value"],
+        "unit": "interactions/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"force pass of BodySystemCPU::update (oracle/ port) for the first {sample} bodies i against all {n} bodies j = {sample * n:.3g} "
+                  f"interactions; 1 thread is how the reference ships",
+        "openmp": base["openmp"],
+        "config0": {"what": "BASELINE configs[0]: 1024 bodies, fp32, 100 steps of the CPU path, no warm-up (compute_cpu.cpp:72-88), 1 thread",
+                    "ms_total": float(f"{ms0:.5g}"), "interactions_per_s": 1024.0 * 1024.0 * 100 / (ms0 * 1e-3), "gflops": 20 * 1024.0 * 1024.0 * 100 / (ms0 * 1e-3) * 1e-9},
+    }
+
+
+CONFIG3_BODIES = 1048576  # BASELINE.json configs[3]: 1 048 576 bodies over the GPUs of one node
+
+
+def multi_gpu_diagnostics(pkg, lib, dist, torch, args, capi_rank, system, sharded, launch, fence, step, finish, lend, stream_ptr, rank, world, n, dtype, mode, dt, damping,
+                          bufs, vel_t, acc_t, work_t, work_bytes, big, dev):
+    """The same job timed other ways, by every rank together (max over ranks, ms per step): the other exchange grouping, the
+    one-sided tile schedule, the exchange legs alone, the kernels alone; and BASELINE configs[3] through the same entry points.
+    Returns a dict for the JSON line."""
+    def timed(fn, reps):
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        finish()
+        fence()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(f"{float(t.item()) / reps * 1e3:.5g}")
+
+    def stream_timed(fn, reps):
+        """this rank's stream time (HIP events), max over ranks: for work that involves no other rank"""
+        fence()
+        e0, e1 = pkg.Event(), pkg.Event()
+        e0.record(stream_ptr)
+        for _ in range(reps):
+            fn()
+        e1.record(stream_ptr)
+        e1.synchronize()
+        t = torch.tensor([e0.elapsed_ms(e1) / reps], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        fence()
+        return float(f"{float(t.item()):.5g}")
+
+    reps = max(2, min(args.steps, 10))
+    out = {"what": "ms per step, max over ranks, taken after the timed region; not part of `value`", "reps": reps}
+    if capi_rank is None:
+        out["exchange_alone_ms"] = timed(lambda: system.exchange_once(system.positions()), reps)
+        i0, ni, schedule = system.i0, system.ni, system.schedule
+
+        def kernels():
+            for k, (j0, nj, _) in enumerate(schedule):
+                launch(system.pos[1 - system.read], system.pos[system.read], system.vel, system.acc, i0, ni, j0, nj, (pkg.NB_SHARD_ACC_IN if k else 0) | (pkg.NB_SHARD_FINALIZE if k == len(schedule) - 1 else 0))
+
+        out["one_sided_kernels_alone_ms"] = stream_timed(kernels, reps)
+        return out
+
+    was_one_group, was_pairwise = capi_rank.exchange_grouping(), capi_rank.pairwise()
+    label = lambda pw, og: ("pairwise" if pw else "one_sided") + ("_one_group" if og else "_group_per_round")  # noqa: E731
+    steps = {}
+    # (1) the step as timed in the headline, then with the other grouping of the position rounds
+    for og in (was_one_group, not was_one_group):
+        capi_rank.set_exchange_grouping(og)
+        steps[label(was_pairwise, og)] = timed(step, reps)
+    capi_rank.set_exchange_grouping(was_one_group)
+    # (2) the exchange legs on their own
+    out["position_exchange_alone_ms"] = {}
+    for og in (True, False):
+        capi_rank.set_exchange_grouping(og)
+        out["position_exchange_alone_ms"]["one_group" if og else "group_per_round"] = timed(lambda: capi_rank.exchange_once(), reps)
+    capi_rank.set_exchange_grouping(was_one_group)
+    if was_pairwise:
+        out["reaction_exchange_alone_ms"] = timed(capi_rank.reaction_exchange_once, reps)
+        # (3) this rank's kernels alone: exactly what it launches in a pairwise step, no exchange, no waits
+        emulate = lib.nb_emulate_pair_rank_f32 if np.dtype(dtype) == np.float32 else lib.nb_emulate_pair_rank_f64
+        need = ctypes.c_size_t(work_bytes)
+        r = capi_rank.read
+        out["pairwise_kernels_alone_ms"] = stream_timed(lambda: pkg.check(emulate(bufs[1 - r].data_ptr(), bufs[r].data_ptr(), vel_t.data_ptr(), work_t.data_ptr(), ctypes.byref(need), n, world, rank, dt, damping,
+                                                                                 stream_ptr), "nb_emulate_pair_rank"), reps)
+    i0, ni = sharded.slice_of(rank, world, n)
+    schedule = sharded.tile_schedule(rank, world, n, mode == pkg.NB_MODE_STRICT)
+
+    def tile_kernels():
+        r = capi_rank.read
+        for k, (j0, nj, _) in enumerate(schedule):
+            launch(bufs[1 - r], bufs[r], vel_t, acc_t, i0, ni, j0, nj, (pkg.NB_SHARD_ACC_IN if k else 0) | (pkg.NB_SHARD_FINALIZE if k == len(schedule) - 1 else 0))
+
+    out["one_sided_kernels_alone_ms"] = stream_timed(tile_kernels, reps)
+    # (4) the other layout: every rank takes its workspace back (the call is collective) -> the one-sided tile schedule
+    if was_pairwise:
+        capi_rank.set_workspace(None, 0)
+        assert not capi_rank.pairwise()
+        for og in (True, False):
+            capi_rank.set_exchange_grouping(og)
+            steps[label(False, og)] = timed(step, reps)
+        capi_rank.set_exchange_grouping(was_one_group)
+        capi_rank.set_workspace(work_t.data_ptr(), work_bytes)
+        assert capi_rank.pairwise()
+    out["step_ms"] = steps
+    out["headline_was"] = label(was_pairwise, was_one_group)
+    # (5) BASELINE configs[3]: 1 048 576 bodies over the ranks, same communicator, same entry points
+    if big is not None:
+        pos_b, vel_b = big
+        nb = pos_b.size // 4
+        p0 = torch.from_numpy(pos_b.reshape(nb, 4)).to(dev)
+        b_bufs, b_vel, b_acc = [p0, p0.clone()], torch.from_numpy(vel_b.reshape(nb, 4)).to(dev), torch.zeros_like(p0)
+        job = pkg.ShardedRank(None, world, rank, [b.data_ptr() for b in b_bufs], b_vel.data_ptr(), b_acc.data_ptr(), nb, np.float32, mode, 256, stream_ptr, comm=capi_rank.comm)
+        b_work = lend(job.workspace_bytes()) if was_pairwise else None
+        job.set_workspace(b_work.data_ptr() if b_work is not None else None, b_work.numel() if b_work is not None else 0)
+        job.exchange_once(0)
+
+        def big_fence():
+            job.finish()
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+
+        big_step = lambda: job.update(np.float32(dt), np.float32(damping))  # noqa: E731
+        big_step()
+        big_fence()
+        k = 3
+        t0 = time.perf_counter()
+        for _ in range(k):
+            big_step()
+        big_fence()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        ms = float(t.item()) / k * 1e3
+        out["configs"] = [{"workload": "configs[3]" if nb == CONFIG3_BODIES else f"configs[3]'s shape at {nb} bodies (rehearsal)", "bodies": nb, "n_gpus": world, "dtype": "f32", "mode": "fast",
+                           "layout": "pairwise across ranks" if job.pairwise() else "one-sided tiles", "steps": k, "ms_per_step": float(f"{ms:.5g}"),
+                           "interactions_per_s": float(nb) * nb / (ms * 1e-3), "frac": round(20 * float(nb) * nb / (ms * 1e-3) / world / (FP32_VECTOR_PEAK_TFLOPS * 1e12), 4),
+                           "workspace_bytes_per_rank": b_work.numel() if b_work is not None else 0}]
+        # hand the communicator back to the headline system
+        capi_rank.set_workspace(work_t.data_ptr() if work_t is not None else None, work_bytes)
+        job.destroy()
+    return out
+
+
