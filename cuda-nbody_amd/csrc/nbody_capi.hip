@@ -512,7 +512,7 @@ int nb_set_pair_plan_override(int vectors_per_lane, int waves_per_block, int spl
             if (v == a) return true;
         return false;
     };
-    if (!ok(vectors_per_lane, {0, 1, 2, 4}) || !ok(waves_per_block, {0, 4, 8, 16}) || splits < 0 || splits > 64 || min_bodies < 0) return NB_ERR_INVALID_ARGUMENT;
+    if (!ok(vectors_per_lane, {0, 1, 2, 4, 8}) || !ok(waves_per_block, {0, 4, 8, 12, 16}) || splits < 0 || splits > 64 || min_bodies < 0) return NB_ERR_INVALID_ARGUMENT;
     g_pair_r.store(vectors_per_lane);
     g_pair_s.store(waves_per_block);
     g_pair_c.store(splits);

@@ -302,7 +302,7 @@ template <> struct Api<double> {
 // tiles' kernels; the position exchange is unchanged, so every rank still ends a step with all positions).
 struct PairShard {
     bool         applies = false;
-    nb::PairGeom diag{}, rect{};
+    nb::PairGeom diag{}, rect{}, rect_upper{};  // rect_upper: the split rectangle as the HIGHER partner runs it (half of its blocks of bodies i: twice the workgroups per block)
     unsigned     ni = 0, block = 0, blocks = 0, plane = 0, half = 0, H = 0, diag_slots = 0;
     bool         even = false;
     size_t       self_at = 0, react_d_at = 0, react_r_at = 0, send_at = 0, recv_at = 0, elements = 0;  // offsets in T
@@ -316,8 +316,10 @@ template <typename T> PairShard plan_pair_shard(unsigned num_bodies, int G, int 
     if (p.ni < static_cast<unsigned>(min_slice > 0 ? min_slice : 2048) || G / 2 > nb::kMaxRecv || G / 2 + 1 > nb::kMaxSelfSets) return p;
     int ovr_r = 0, ovr_s = 0, ovr_c = 0;
     nb::pair_plan_overrides(&ovr_r, &ovr_s, &ovr_c);  // (tuning sweeps: tools/pair_rank_probe.py)
-    const int R = ovr_r > 0 ? ovr_r : ((sizeof(T) == 4 ? p.ni >= 16384 : p.ni >= 8192) ? 4 : 2);
+    // (slices of 131 072 bodies and more: R = 8, one 8-wave workgroup per CU, as on one GPU -- nbody_pair.hip)
+    const int R = ovr_r > 0 ? ovr_r : (p.ni >= 131072 ? 8 : ((sizeof(T) == 4 ? p.ni >= 16384 : p.ni >= 8192) ? 4 : 2));
     const int S = ovr_s > 0 ? ovr_s : 8;
+    const unsigned chip = R > 4 ? 256u : 512u;  // workgroups the chip holds at once
     p.block  = 64u * static_cast<unsigned>(R) * W;
     p.blocks = (p.ni + p.block - 1) / p.block;
     p.plane  = (p.ni + 63u) / 64u * 64u;
@@ -327,16 +329,18 @@ template <typename T> PairShard plan_pair_shard(unsigned num_bodies, int G, int 
     p.diag_slots = p.blocks < 2 ? 0u : ((p.blocks & 1u) ? p.blocks / 2 : p.blocks / 2 - 1);
     auto splits = [&](unsigned units) {  // workgroups per block: fill the chip (~512 workgroups of 8 waves) while a wave keeps >= 2 units
         unsigned C = 1;
-        while (p.blocks * C * 2 <= 512 && units >= C * 2 * static_cast<unsigned>(S) * 2) C *= 2;
+        while (p.blocks * C * 2 <= chip && units >= C * 2 * static_cast<unsigned>(S) * 2) C *= 2;
         if (ovr_c > 0) C = static_cast<unsigned>(ovr_c);
         while (C > 1 && units < C * static_cast<unsigned>(S)) C /= 2;
         return C;
     };
     p.diag = {R, S, splits((p.blocks / 2 + 1) * static_cast<unsigned>(R) * W)};
     p.rect = {R, S, splits((p.ni + 63) / 64)};
+    p.rect_upper = p.rect;
+    if (p.even && p.blocks >= 2 && (p.ni + 63) / 64 >= p.rect.splits * 2 * static_cast<unsigned>(S) * 2) p.rect_upper.splits = p.rect.splits * 2;
     const size_t plane3 = 3 * static_cast<size_t>(p.plane);
     p.self_at    = 0;
-    p.react_d_at = p.self_at + (p.diag.splits + static_cast<size_t>(p.H) * p.rect.splits) * plane3;
+    p.react_d_at = p.self_at + (p.diag.splits + static_cast<size_t>(p.H - 1) * p.rect.splits + p.rect_upper.splits) * plane3;  // (the last rectangle is the one that may be split)
     p.react_r_at = p.react_d_at + p.diag_slots * plane3;
     p.send_at    = p.react_r_at + 2 * p.blocks * plane3;  // (two regions: the rectangles alternate between two streams)
     p.recv_at    = p.send_at + p.H * plane3;
@@ -398,8 +402,9 @@ int pair_rank_tiles(Comm* c, unsigned r, int G, const PairShard& plan, T* work, 
         }
         a.react_origin = a.j_begin;
         a.self_first   = plan.diag.splits + (s - 1) * plan.rect.splits;
-        if (const auto err = nb::launch_pair_tile<T>(a, plan.rect, on); err != hipSuccess) return static_cast<int>(err);
-        f.self_set[f.n_self++] = {a.self_first, plan.rect.splits, a.i_begin - own, a.i_count};
+        const nb::PairGeom& geom = (plan.even && s == plan.H && !(r < p)) ? plan.rect_upper : plan.rect;
+        if (const auto err = nb::launch_pair_tile<T>(a, geom, on); err != hipSuccess) return static_cast<int>(err);
+        f.self_set[f.n_self++] = {a.self_first, geom.splits, a.i_begin - own, a.i_count};
         const unsigned blocks_i = (a.i_count + plan.block - 1) / plan.block;
         if (const auto err = nb::launch_pair_reduce<T>(a.react, plan.plane, blocks_i, work + plan.send_at + (s - 1) * plane3, plan.plane, a.j_count, on); err != hipSuccess) return static_cast<int>(err);
         if (c != nullptr) {

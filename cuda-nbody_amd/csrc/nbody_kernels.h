@@ -76,7 +76,7 @@ struct PairSlicing {
     unsigned slice_bodies;  // bodies per slice, a multiple of the block (the last slice may hold fewer)
     unsigned partners;      // H = K / 2
     bool     even;
-    PairGeom diag, rect;
+    PairGeom diag, rect, rect_upper;  // rect_upper: a split rectangle as the higher slice runs it (half of its blocks: twice the workgroups per block)
     unsigned block_bodies, plane;
     size_t   self_per_slice, react_elements, recv_per_slice, elements;  // in units of T
     size_t   workspace_bytes;

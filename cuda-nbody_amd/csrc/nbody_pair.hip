@@ -91,7 +91,12 @@ template <typename T> __device__ __forceinline__ bool usable_unit(T m) {
 }
 
 // T: float|double   R: vectors per lane (I = R*W bodies i)   S: waves of a workgroup
-template <typename T, int R, int S> __global__ __launch_bounds__(64 * S) __attribute__((amdgpu_waves_per_eu(4, 4))) void pair_forces(PairArgs<T> s) {
+// Registers and occupancy: up to R = 4 vectors per lane (fp32: eight bodies i) fit 128 VGPRs -> four waves per SIMD.  R = 8 (round 4:
+// sixteen bodies i per lane in fp32, the nine rotation moves of a step amortised over twice the arithmetic -- 4.30 instead of 4.56
+// vector instructions per directed interaction) takes 256 VGPRs at two waves per SIMD (one 8-wave workgroup per CU), or ~168 with
+// spills outside the rotation loops at three (one 12-wave workgroup per CU: used where twelve waves divide a block's units evenly).
+template <int R, int S> constexpr int kPairWavesPerSimd = R <= 4 ? 4 : (S == 12 ? 3 : 2);
+template <typename T, int R, int S> __global__ __launch_bounds__(64 * S) __attribute__((amdgpu_waves_per_eu(kPairWavesPerSimd<R, S>, kPairWavesPerSimd<R, S>))) void pair_forces(PairArgs<T> s) {
     using LT            = Lane<T>;
     using vec4          = typename LT::vec4;
     using vec           = typename LT::vec;
@@ -495,6 +500,7 @@ template <typename T, int R> hipError_t launch_r(const PairArgs<T>& args, int wa
     switch (waves) {
         case 4: return launch_rs<T, R, 4>(args, grid, lds_bytes, stream, prepare_only);
         case 8: return launch_rs<T, R, 8>(args, grid, lds_bytes, stream, prepare_only);
+        case 12: return launch_rs<T, R, 12>(args, grid, lds_bytes, stream, prepare_only);
         case 16: return launch_rs<T, R, 16>(args, grid, lds_bytes, stream, prepare_only);
         default: return hipErrorInvalidValue;
     }
@@ -506,8 +512,8 @@ template <typename T, int R> hipError_t launch_r(const PairArgs<T>& args, int wa
 // resident workgroups (256 CUs x 16 waves / S) takes ceil(r) rounds of time -- 1 639 blocks of eight waves are 3.2 rounds and cost 4
 // (80 %); split in four they are 12.8 and cost 13 (98 %).  Starting from `wanted`, doubles C while that gains more than 2 % and every
 // wave keeps at least four units.  (Up to one round nothing is lost: the workgroups all run at once.)
-inline unsigned splits_for_full_rounds(unsigned blocks, unsigned units_per_block, int S, unsigned wanted) {
-    const double resident = 256.0 * 16.0 / S;
+inline unsigned splits_for_full_rounds(unsigned blocks, unsigned units_per_block, int S, unsigned wanted, int waves_per_simd = 4) {
+    const double resident = 256.0 * 4.0 * waves_per_simd / S;  // workgroups the chip holds at once
     auto         eff      = [&](unsigned C) {
         const double r = blocks * static_cast<double>(C) / resident;
         return r <= 1.0 ? 1.0 : r / std::ceil(r);
@@ -531,19 +537,27 @@ template <typename T> PairPlan plan_pair(unsigned n, int cu_count, int ovr_r, in
     int           R = 4, S = 8;
     unsigned      C = 1;
     if (sizeof(T) == 4) {
-        R = n < 32768 ? 2 : 4;
-        C = n < 32768 ? (n <= 16384 ? 4 : 8) : (n < 262144 ? 4 : 1);
+        // from 65 536 bodies: R = 8 (same box, tools/ab.sh: 262 144 bodies 10.10 -> 9.59 ms, 65 536 bodies 0.712 -> 0.665 ms; half the
+        // blocks, so half the reaction slots, half the workspace and half of pair_finish); twelve waves where eight leave a remainder
+        R = n < 32768 ? 2 : (n < 65536 ? 4 : 8);
+        S = (n >= 65536 && n < 131072) ? 12 : 8;
+        C = n < 32768 ? (n <= 16384 ? 4 : 8) : (n < 65536 ? 4 : 1);
     } else {
-        R = n < 16384 ? 2 : 4;
-        S = n >= 65536 ? 16 : 8;
-        C = n < 65536 ? 4 : (n < 131072 ? 2 : 1);
+        // from 65 536 bodies: R = 8 doubles per lane, 252 VGPRs, two waves per SIMD (262 144 bodies 24.5 -> 23.1 ms, 65 536: 1.54 -> 1.47)
+        R = n < 16384 ? 2 : (n < 65536 ? 4 : 8);
+        S = 8;
+        C = n < 65536 ? 4 : 1;
     }
-    if (ovr_r == 1 || ovr_r == 2 || ovr_r == 4) R = ovr_r;  // (R = 6 was tried: 74 KB of LDS per workgroup and 342 ragged blocks -- 11.8 against 10.2 ms)
-    if (ovr_s == 4 || ovr_s == 8 || ovr_s == 16) S = ovr_s;
+    if (ovr_r == 1 || ovr_r == 2 || ovr_r == 4 || ovr_r == 8) R = ovr_r;  // (R = 6 was tried: 74 KB of LDS per workgroup and 342 ragged blocks -- 11.8 against 10.2 ms)
+    if (ovr_s == 4 || ovr_s == 8 || ovr_s == 12 || ovr_s == 16) S = ovr_s;
     const unsigned block  = 64u * static_cast<unsigned>(R * W);
     const unsigned blocks = (n + block - 1) / block;
     const unsigned units  = (blocks / 2 + 1) * static_cast<unsigned>(R * W);
-    C = splits_for_full_rounds(blocks, units, S, C);  // (the sizes the table was tuned on -- powers of two -- come out unchanged)
+    const int      held   = R <= 4 ? 4 : (S == 12 ? 3 : 2);  // waves per SIMD (kPairWavesPerSimd)
+    if (R > 4) {
+        while (blocks * C < 256 && units >= C * 2 * static_cast<unsigned>(S) * 4) C *= 2;  // one workgroup per CU: fill the 256 CUs first
+    }
+    C = splits_for_full_rounds(blocks, units, S, C, held);  // (the sizes the table was tuned on -- powers of two -- come out unchanged)
     if (ovr_c > 0) C = static_cast<unsigned>(ovr_c);
     while (C > 1 && units < C * static_cast<unsigned>(S)) C /= 2;  // no wave without a unit
     p.vectors_per_lane = R;
@@ -570,6 +584,7 @@ template <typename T> hipError_t launch_pair_tile(const PairArgs<T>& args, const
         case 1: return launch_r<T, 1>(a, g.waves, a.blocks * a.splits, lds_bytes, stream, prepare_only);
         case 2: return launch_r<T, 2>(a, g.waves, a.blocks * a.splits, lds_bytes, stream, prepare_only);
         case 4: return launch_r<T, 4>(a, g.waves, a.blocks * a.splits, lds_bytes, stream, prepare_only);
+        case 8: return launch_r<T, 8>(a, g.waves, a.blocks * a.splits, lds_bytes, stream, prepare_only);
         default: return hipErrorInvalidValue;
     }
 }
@@ -617,8 +632,10 @@ template <typename T> PairSlicing plan_pair_sliced(unsigned n, unsigned slices, 
     constexpr unsigned W = sizeof(T) == 4 ? 2 : 1;
     PairSlicing        p{};
     if (n == 0 || slices < 2) return p;
-    const int R = (ovr_r == 1 || ovr_r == 2 || ovr_r == 4) ? ovr_r : 4;
-    const int S = (ovr_s == 4 || ovr_s == 8 || ovr_s == 16) ? ovr_s : 8;
+    // slices of 131 072 bodies and more take R = 8 (sixteen fp32 / eight fp64 bodies i per lane, one 8-wave workgroup per CU), as whole systems do
+    const int R = (ovr_r == 1 || ovr_r == 2 || ovr_r == 4 || ovr_r == 8) ? ovr_r : (n / slices >= 131072 ? 8 : 4);
+    const int S = (ovr_s == 4 || ovr_s == 8 || ovr_s == 12 || ovr_s == 16) ? ovr_s : 8;
+    const unsigned chip = R > 4 ? 256u : 512u;  // workgroups the chip holds at once
     p.block_bodies          = 64u * static_cast<unsigned>(R) * W;
     const unsigned blocks   = (n + p.block_bodies - 1) / p.block_bodies;
     const unsigned per      = (blocks + slices - 1) / slices;            // blocks per slice
@@ -631,17 +648,19 @@ template <typename T> PairSlicing plan_pair_sliced(unsigned n, unsigned slices, 
     p.plane = p.slice_bodies;  // (a multiple of 64 already)
     auto splits = [&](unsigned units) {  // workgroups per block: fill the chip (~512 workgroups of 8 waves) while a wave keeps >= 2 units, then whole rounds
         unsigned C = 1;
-        while (per * C * 2 <= 512 && units >= C * 2 * static_cast<unsigned>(S) * 2) C *= 2;
-        C = splits_for_full_rounds(per, units, S, C);
+        while (per * C * 2 <= chip && units >= C * 2 * static_cast<unsigned>(S) * 2) C *= 2;
+        C = splits_for_full_rounds(per, units, S, C, R > 4 ? 2 : 4);
         if (ovr_c > 0) C = static_cast<unsigned>(ovr_c);
         while (C > 1 && units < C * static_cast<unsigned>(S)) C /= 2;
         return C;
     };
     p.diag = {R, S, splits((per / 2 + 1) * static_cast<unsigned>(R) * W)};
     p.rect = {R, S, splits(p.slice_bodies / 64)};
+    p.rect_upper = p.rect;
+    if (p.even && per >= 2 && p.slice_bodies / 64 >= p.rect.splits * 2 * static_cast<unsigned>(S) * 2) p.rect_upper.splits = p.rect.splits * 2;
     const size_t   plane3     = 3 * static_cast<size_t>(p.plane);
     const unsigned diag_slots = per < 2 ? 0u : ((per & 1u) ? per / 2 : per / 2 - 1);
-    p.self_per_slice  = (p.diag.splits + static_cast<size_t>(p.partners) * p.rect.splits) * plane3;
+    p.self_per_slice  = (p.diag.splits + static_cast<size_t>(p.partners - 1) * p.rect.splits + p.rect_upper.splits) * plane3;  // (the last rectangle may be split)
     p.react_elements  = static_cast<size_t>(std::max(diag_slots, per)) * plane3;  // one region, reused launch after launch (stream order)
     p.recv_per_slice  = (1 + static_cast<size_t>(p.partners)) * plane3;          // [0]: the slice's own folded diagonal, [s]: from slice r - s
     p.elements        = p.slices * (p.self_per_slice + p.recv_per_slice) + p.react_elements;
@@ -703,8 +722,9 @@ template <typename T> hipError_t launch_pair_sliced(const Shard<T>& s, const Pai
             a.react_origin = a.j_begin;
             a.self_first   = p.diag.splits + (q - 1) * p.rect.splits;
             if (a.i_count != 0 && a.j_count != 0) {
-                if (const auto err = launch_pair_tile<T>(a, p.rect, stream, prepare_only); err != hipSuccess) return err;
-                finish[r].self_set[finish[r].n_self++] = {a.self_first, p.rect.splits, a.i_begin - own, a.i_count};
+                const PairGeom& geom = (split && !(r < partner)) ? p.rect_upper : p.rect;
+                if (const auto err = launch_pair_tile<T>(a, geom, stream, prepare_only); err != hipSuccess) return err;
+                finish[r].self_set[finish[r].n_self++] = {a.self_first, geom.splits, a.i_begin - own, a.i_count};
                 if (!prepare_only) {
                     if (const auto err = launch_pair_reduce<T>(react, p.plane, blocks_of(a.i_count), recv_of(partner) + q * plane3, p.plane, a.j_count, stream); err != hipSuccess) return err;
                 }

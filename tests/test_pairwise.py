@@ -318,10 +318,12 @@ def test_sliced_pairwise_by_the_bytes_on_offer(gpu, oracle):
     gpu.set_softening_squared(np.float32(0.1) * np.float32(0.1))
     full = gpu.workspace_bytes(n)
     assert gpu.pair_plan(n).slices == 1 and full > 0
-    third = gpu.workspace_bytes(n, max_bytes=full // 3)
-    assert 0 < third <= full // 3
-    smallest = gpu.workspace_bytes(n, max_bytes=full // 6)
-    assert 0 < smallest <= full // 6 and smallest < third
+    # the sizes the library names for smaller and smaller budgets: each within its budget, never growing, at least two sliced forms
+    named = [gpu.workspace_bytes(n, max_bytes=int(full * f)) for f in (0.9, 0.6, 0.4, 0.3, 0.25)]
+    assert all(0 <= b <= int(full * f) for b, f in zip(named, (0.9, 0.6, 0.4, 0.3, 0.25))) and all(a >= b for a, b in zip(named, named[1:]))
+    forms = sorted({b for b in named if b}, reverse=True)
+    assert len(forms) >= 2, named
+    third, smallest = forms[0], forms[-1]
     bufs = [gpu.DeviceBuffer(pos0.nbytes) for _ in range(3)]
     work = gpu.DeviceBuffer(full)
 
@@ -343,8 +345,8 @@ def test_sliced_pairwise_by_the_bytes_on_offer(gpu, oracle):
     assert tiny == 0 and step(1 << 16).tobytes() == one_sided.tobytes()     # nothing fits: exactly nb_integrate_*
     for b in bufs + [work]:
         b.free()
-    a = gpu.BodySystemHIP(n, 256, gpu.NBodyParams(), np.float32, pos0, vel0, mode=gpu.NB_MODE_FAST, workspace=True, workspace_cap=full // 3)
-    b = gpu.BodySystemHIP(n, 256, gpu.NBodyParams(), np.float32, pos0, vel0, mode=gpu.NB_MODE_FAST, workspace=True, workspace_cap=full // 3)
+    a = gpu.BodySystemHIP(n, 256, gpu.NBodyParams(), np.float32, pos0, vel0, mode=gpu.NB_MODE_FAST, workspace=True, workspace_cap=third)
+    b = gpu.BodySystemHIP(n, 256, gpu.NBodyParams(), np.float32, pos0, vel0, mode=gpu.NB_MODE_FAST, workspace=True, workspace_cap=third)
     assert a._workspace_bytes == third
     for _ in range(4):
         a.update(np.float32(0.016))
