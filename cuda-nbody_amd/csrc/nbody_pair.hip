@@ -15,6 +15,8 @@
 //     reaction sums are back in their home lanes.  Per step and lane: R x (14 v_pk_* + 2 v_rsq_f32) + 9 v_mov_b32_dpp for
 //     4R directed interactions; measured in isolation (tools/sym_microbench.hip, profiles/round3_pairwise_loop_microbench.txt)
 //     275 SIMD cycles per step at R = 4 with 4 waves per SIMD = 17.2 cycles per directed interaction against 30.75.
+//     Round 4: R = 8 from 65 536 bodies on -- the nine moves amortised over twice the arithmetic (4.30 instead of 4.56 vector
+//     instructions per directed interaction), 256 VGPRs at two waves per SIMD, 5 % faster than R = 4 at four.
 //   * Work: the bodies are cut into blocks of 64*I; block pair (a, a+q) is evaluated by the workgroup(s) of block a for
 //     q = 0 .. NB/2 (indices mod NB) -- a round-robin tournament, every workgroup gets the same amount.  q = 0 (the block with
 //     itself) and, for an even block count, q = NB/2 (which both partners list) run the same loop but keep only the i side.
@@ -526,9 +528,10 @@ inline unsigned splits_for_full_rounds(unsigned blocks, unsigned units_per_block
 }
 
 // Geometry (measured: tools/pair_crossover.py -> profiles/round3_pair_crossover_f32.jsonl, _f64.jsonl).
-//   R = 4 vectors per lane (fp32: 8 bodies i, fp64: 4) is what 128 VGPRs hold and what amortises the 9 rotation moves best;
+//   R = 4 vectors per lane (fp32: 8 bodies i, fp64: 4) is what 128 VGPRs hold; from 65 536 bodies R = 8 (256 VGPRs, two waves
+//   per SIMD, one 8-wave workgroup per CU) amortises the 9 rotation moves over twice the arithmetic and wins by 4-6 % (round 4);
 //   smaller systems take R = 2: twice the blocks, so twice the workgroups to spread over the chip.
-//   S = 8 waves per workgroup, two workgroups per CU (fp64 from 65 536 bodies: S = 16, one per CU, 2-3 % better).
+//   S = 8 waves per workgroup (R <= 4: two workgroups per CU); S = 12 at 65 536 .. 131 071 bodies fp32 (528 units per block = 48 x 11).
 //   C workgroups share a block of bodies i (and split its tiles) while the blocks alone do not fill the chip.
 template <typename T> PairPlan plan_pair(unsigned n, int cu_count, int ovr_r, int ovr_s, int ovr_c) {
     constexpr int W = sizeof(T) == 4 ? 2 : 1;
