@@ -47,7 +47,7 @@ def random_bodies(oracle, n, seed=3, masses="unit"):
     return pos
 
 
-@pytest.mark.parametrize("plan", [(4, 8, 1), (4, 8, 2), (4, 16, 1), (4, 4, 3), (2, 8, 1), (2, 16, 2), (1, 8, 1), (1, 4, 5)])
+@pytest.mark.parametrize("plan", [(8, 8, 1), (8, 12, 2), (8, 4, 3), (4, 8, 1), (4, 8, 2), (4, 16, 1), (4, 4, 3), (2, 8, 1), (2, 16, 2), (1, 8, 1), (1, 4, 5)])
 @pytest.mark.parametrize("n", [3000, 4096 + 64, 517])
 def test_pair_force_error_every_geometry_fp32(gpu, oracle, plan, n):
     """Every (vectors per lane, waves, workgroups per block) instantiation, ragged body counts (a last block and a last tile
@@ -200,7 +200,8 @@ def test_pair_full_size_sampled_forces_and_momentum(gpu, oracle, n, dtype):
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
-@pytest.mark.parametrize("n,plan", [(600, (1, 4, 5)), (8256, (2, 8, 4)), (20000, (0, 0, 0)), (20000, (4, 4, 3)), (65536, (0, 0, 0)), (100032, (0, 0, 0)), (100032, (2, 16, 2))])
+@pytest.mark.parametrize("n,plan", [(600, (1, 4, 5)), (8256, (2, 8, 4)), (20000, (0, 0, 0)), (20000, (4, 4, 3)), (20000, (8, 12, 2)), (65536, (0, 0, 0)), (100032, (0, 0, 0)), (100032, (2, 16, 2)),
+                                    (262144, (0, 0, 0))])
 def test_pair_reads_nothing_it_did_not_write(gpu, oracle, dtype, n, plan):
     """The workspace carries nothing from launch to launch: a step over a workspace filled with NaN bit patterns gives the bits
     of a step over a zeroed one (every slot the second kernel adds was written by the first in the same step, whatever the

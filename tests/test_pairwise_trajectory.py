@@ -19,8 +19,8 @@ from test_gpu_parity import DT, rel_err
 pytestmark = pytest.mark.gpu
 
 # (vectors per lane R, waves per workgroup S, workgroups per block C): every instantiation launch_pair_tile can pick
-PLANS_F32 = [(4, 8, 1), (4, 8, 2), (4, 16, 1), (4, 4, 3), (2, 8, 1), (2, 16, 2), (1, 8, 1), (1, 4, 5)]
-PLANS_F64 = [(4, 8, 1), (4, 16, 2), (2, 8, 1), (2, 4, 3), (1, 8, 2), (1, 16, 1)]
+PLANS_F32 = [(8, 8, 1), (8, 12, 2), (8, 4, 1), (4, 8, 1), (4, 8, 2), (4, 16, 1), (4, 4, 3), (2, 8, 1), (2, 16, 2), (1, 8, 1), (1, 4, 5)]
+PLANS_F64 = [(8, 8, 1), (8, 12, 1), (8, 4, 2), (4, 8, 1), (4, 16, 2), (2, 8, 1), (2, 4, 3), (1, 8, 2), (1, 16, 1)]
 
 
 class forced_pairwise:
