@@ -133,7 +133,7 @@ template <typename T> constexpr unsigned kPairMinBodies = sizeof(T) == 4 ? 8193u
 // Which form of the pairwise layout a system of n bodies takes when `have` bytes of workspace are on offer: the single tournament
 // (slices == 1) if its workspace fits, else the tournament cut into the FEWEST slices (2 .. 15) whose workspace fits -- fewer
 // slices = fewer, larger launches and less folding.  "Fits" = within `have` and within a third of the device's memory (the
-// workspace grows with N^2: 12.9 GB at 1 Mi bodies, 206 GB at 4 Mi in one tournament; 7 GB at 4 Mi in eight slices).
+// workspace grows with N^2: 6.4 GB at 1 Mi bodies, 103 GB at 4 Mi in one tournament; 7 GB at 4 Mi in eight slices).
 struct PairChoice {
     unsigned        slices = 0;  // 0: the pairwise layout does not apply (the step is the one-sided kernel)
     nb::PairPlan    plan{};      // slices == 1

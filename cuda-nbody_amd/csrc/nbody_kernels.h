@@ -66,7 +66,7 @@ struct PairGeom {
 };
 
 // The pairwise layout with a BOUNDED workspace (round 4): the reaction slots of one tournament over the whole system grow with N^2
-// (12.9 GB at 1 Mi bodies, 206 GB at 4 Mi).  Cut into K slices of bodies, the tournament runs slice by slice -- every slice against
+// (6.4 GB at 1 Mi bodies, 103 GB at 4 Mi).  Cut into K slices of bodies, the tournament runs slice by slice -- every slice against
 // itself (diag) and against the next K/2 slices (rectangles; for an even K the two partners at distance K/2 split theirs) -- through
 // ONE reusable region of reaction planes, each launch's planes folded straight away (pair_reduce) into one array per receiving
 // slice; the finish kernel of a slice adds its own sums and the arrays it received.  The same pieces, in the same roles, as one

@@ -26,7 +26,7 @@
 //     slot q-1 of body j (each (slot, body) is written by exactly one wave per step: no atomics, no zeroing).  The i-side
 //     sums are folded over the S waves through LDS in a fixed order (as in nbody_fast.hip) and stored to the workspace too.
 //     A second kernel adds a body's slots in a fixed order and integrates (integrateBodies, bodysystemcuda.cu:166-183).
-//     Workspace traffic: 12 B per tile visit and body = N^2 / (128 I) * 12 B per step (0.8 GB at 262 144 bodies, written once,
+//     Workspace traffic: 12 B per tile visit and body = N^2 / (128 I) * 12 B per step (0.8 GB at 262 144 bodies with I = 8, 0.4 GB with I = 16, written once,
 //     read once: ~0.3 ms of a ~8 ms step).
 //   * Masses: a tile whose 64 bodies j are ONE species (one mass) multiplies nothing on the i side -- the wave's i-side sums are
 //     kept in units of the mass of the species it is working through (re-expressed once when that changes); a block whose 64*I

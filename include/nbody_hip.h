@@ -145,9 +145,9 @@ NB_API int nb_integrate_f64(double* new_positions, const double* old_positions, 
  *  The workspace must not overlap any of the three body arrays (NB_ERR_INVALID_ARGUMENT). */
 NB_API int nb_workspace_bytes_f32(unsigned num_bodies, int mode, size_t* bytes);
 NB_API int nb_workspace_bytes_f64(unsigned num_bodies, int mode, size_t* bytes);
-/* The workspace of ONE tournament over the whole system grows with N^2 (0.8 GB at 262 144 bodies fp32, 12.9 GB at 1 Mi, 206 GB at
+/* The workspace of ONE tournament over the whole system grows with N^2 (0.4 GB at 262 144 bodies fp32, 6.4 GB at 1 Mi, 103 GB at
  * 4 Mi).  When that is more than a third of the device's memory -- or more than the caller wants to spend -- the tournament is cut
- * into K slices of bodies that share one reusable region of reaction planes (7 GB at 4 Mi bodies in eight slices; K <= 15):
+ * into K slices of bodies that share one reusable region of reaction planes (12 GB at 4 Mi bodies in four slices, 7 GB in eight; K <= 15):
  * same pairs, same arithmetic, a few more launches.  nb_workspace_bytes_* asks for the fewest slices the device affords;
  * nb_workspace_bytes_capped_* for the fewest whose workspace stays within max_bytes (0 = nothing fits: the one-sided kernel);
  * nb_integrate_ws_* takes the fewest slices that fit the workspace_bytes it is given.  nb_pair_plan_t.slices reports K. */

@@ -397,7 +397,7 @@ def test_workspace_memory_guard_without_gpu(pkg):
 
 def test_sliced_pairwise_plan_without_gpu(pkg):
     """The pairwise layout with a bounded workspace (round 4): one tournament over N bodies wants N^2 / (128 I) * 12 B of reaction
-    slots -- 206 GB at 4 Mi bodies.  Cut into K slices that share one region of reaction planes it needs a fraction; the library
+    slots -- 206 GB at 4 Mi bodies with eight bodies i per lane.  Cut into K slices that share one region of reaction planes it needs a fraction; the library
     picks the fewest slices that fit a third of the device's memory, a caller's cap, or the workspace a step is handed.  Host logic.
     (Round 4, later: with sixteen bodies i per lane one tournament wants half of that -- 103 GB at 4 Mi bodies.)"""
     import ctypes

@@ -312,7 +312,7 @@ def test_cli_fast_on_a_three_species_galaxy_file(host, tmp_path, oracle):
 def test_cli_workspace_cap_steps_through_the_sliced_tournament(tmp_path):
     """`nbody --workspace-mib=<n>`: the body system spends at most that much on its workspace, the library cuts the pair tournament
     into slices that share one region of reaction planes: the same trajectory up to summation order as the default (one
-    tournament, 805 MB at 262 144 bodies) and as --no-workspace, different bits; --compare passes; the benchmark lines print."""
+    tournament, 403 MB at 262 144 bodies) and as --no-workspace, different bits; --compare passes; the benchmark lines print."""
     n = 262144
     dumps = {}
     for name, extra in (("one", []), ("capped", ["--workspace-mib=200"]), ("tiny", ["--workspace-mib=1"]), ("none", ["--no-workspace"])):

@@ -357,7 +357,7 @@ def test_sliced_pairwise_by_the_bytes_on_offer(gpu, oracle):
 
 
 def test_sliced_pairwise_4mi_bodies_in_16_gb(gpu, O):
-    """4 194 304 bodies -- one tournament would want 206 GB of reaction slots -- step pairwise inside 16 GB:
+    """4 194 304 bodies -- one tournament would want 103 GB of reaction slots -- step pairwise inside 16 GB:
     sampled accelerations against the fp64 direct sum, total momentum change zero to summation accuracy."""
     import os
 
