@@ -66,13 +66,16 @@ def test_pair_force_error_every_geometry_fp32(gpu, oracle, plan, n):
     assert np.all(new_pos.reshape(n, 4)[:, 3] == pos.reshape(n, 4)[:, 3])  # and so is the mass
 
 
+@pytest.mark.parametrize("plan", [(0, 0, 0), (8, 8, 1), (8, 12, 2), (4, 8, 1)])
 @pytest.mark.parametrize("masses", ["unit", "species", "odd", "first_zero"])
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
-def test_pair_mass_forms(gpu, oracle, dtype, masses):
-    """Unit-mass tiles (no mass multiply), tiles of mixed masses, zero / negative / huge masses, a first body of mass zero."""
+def test_pair_mass_forms(gpu, oracle, dtype, masses, plan):
+    """Unit-mass tiles (no mass multiply), tiles of mixed masses, zero / negative / huge masses, a first body of mass zero -- the four
+    compiled loops (neither side multiplies / mixed bodies j / mixed bodies i / both) of the automatic plan at this size (R = 2) and of
+    the large-system kernels (R = 8 with 8 and 12 waves, R = 4)."""
     n = 64 * 37 + 41
     pos = random_bodies(oracle, n, seed=5, masses=masses)
-    gpu.set_pair_plan_override(0, 0, 0, 1)
+    gpu.set_pair_plan_override(*plan, 1)
     try:
         acc, _ = accel_ws(gpu, pos, dtype)
     finally:
