@@ -96,6 +96,7 @@ template <typename T> struct PairArgs {
     unsigned blocks;        // NB = ceil(i_count / (64*I))
     unsigned splits;        // C workgroups per block
     unsigned diag, keep;
+    unsigned interleave;    // unit -> wave map: 0: workgroup c of a block takes slots c*S .. c*S+S-1, 1: slot = wave * C + c (set by launch_pair_tile)
     unsigned self_first, self_origin, self_plane;
     unsigned react_origin, react_plane;
     T        eps2;

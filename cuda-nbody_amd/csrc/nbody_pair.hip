@@ -21,7 +21,8 @@
 //     q = 0 .. NB/2 (indices mod NB) -- a round-robin tournament, every workgroup gets the same amount.  q = 0 (the block with
 //     itself) and, for an even block count, q = NB/2 (which both partners list) run the same loop but keep only the i side.
 //     The S waves of a workgroup (and the C workgroups of a block, for small systems) share the bodies i and split the
-//     64-body tiles of those blocks: unit u -> wave u mod (C*S), static, so every sum is formed in the same order in every run.
+//     64-body tiles of those blocks: unit u -> slot u mod (C*S), slot = wave * C + workgroup, static, so every sum is formed in the
+//     same order in every run.
 //   * The reaction sums of a tile leave the wave once, after its 64 steps: 3 coalesced stores into the caller's WORKSPACE,
 //     slot q-1 of body j (each (slot, body) is written by exactly one wave per step: no atomics, no zeroing).  The i-side
 //     sums are folded over the S waves through LDS in a fixed order (as in nbody_fast.hip) and stored to the workspace too.
@@ -207,7 +208,12 @@ template <typename T, int R, int S> __global__ __launch_bounds__(64 * S) __attri
     const unsigned j_end   = s.j_begin + s.j_count;
     const unsigned n_units = diag ? (Q + 1) * TB : (s.j_count + 63) / 64;
     const unsigned G       = s.splits * S;
-    const unsigned g       = c * S + static_cast<unsigned>(wave);
+    // Which units are this wave's: unit u belongs to slot u mod (C*S).  Blocked (slot = c*S + wave): a workgroup takes consecutive
+    // units.  Interleaved (slot = wave*C + c): when the units do not divide evenly -- 528 over 32 waves at 65 536 bodies -- the waves
+    // with one unit more are the low wave ids of EVERY workgroup, one or two per SIMD, instead of all the waves of the first workgroups
+    // (65 536 bodies 653 -> 634 us, 98 304 bodies 1 566 -> 1 494 us, same box); where the remainder is under 3 % of a wave's units the
+    // blocked map is kept (196 608 bodies: 5.60 against 5.70 ms).  launch_pair_tile decides.
+    const unsigned g       = s.interleave ? static_cast<unsigned>(wave) * s.splits + c : c * S + static_cast<unsigned>(wave);
 
     auto tile_first = [&](unsigned u) {
         if (!diag) return s.j_begin + u * 64;
@@ -531,7 +537,7 @@ inline unsigned splits_for_full_rounds(unsigned blocks, unsigned units_per_block
 //   R = 4 vectors per lane (fp32: 8 bodies i, fp64: 4) is what 128 VGPRs hold; from 65 536 bodies R = 8 (256 VGPRs, two waves
 //   per SIMD, one 8-wave workgroup per CU) amortises the 9 rotation moves over twice the arithmetic and wins by 4-6 % (round 4);
 //   smaller systems take R = 2: twice the blocks, so twice the workgroups to spread over the chip.
-//   S = 8 waves per workgroup (R <= 4: two workgroups per CU); S = 12 at 65 536 .. 131 071 bodies fp32 (528 units per block = 48 x 11).
+//   S = 8 waves per workgroup (R <= 4: two workgroups per CU; R = 8: one).
 //   C workgroups share a block of bodies i (and split its tiles) while the blocks alone do not fill the chip.
 template <typename T> PairPlan plan_pair(unsigned n, int cu_count, int ovr_r, int ovr_s, int ovr_c) {
     constexpr int W = sizeof(T) == 4 ? 2 : 1;
@@ -543,7 +549,7 @@ template <typename T> PairPlan plan_pair(unsigned n, int cu_count, int ovr_r, in
         // from 65 536 bodies: R = 8 (same box, tools/ab.sh: 262 144 bodies 10.10 -> 9.59 ms, 65 536 bodies 0.712 -> 0.665 ms; half the
         // blocks, so half the reaction slots, half the workspace and half of pair_finish); twelve waves where eight leave a remainder
         R = n < 32768 ? 2 : (n < 65536 ? 4 : 8);
-        S = (n >= 65536 && n < 131072) ? 12 : 8;
+        S = 8;  // (twelve waves -- <float, 8, 12>, 168 VGPRs, three per SIMD -- stay available through the override: with the units interleaved eight do better)
         C = n < 32768 ? (n <= 16384 ? 4 : 8) : (n < 65536 ? 4 : 1);
     } else {
         // from 65 536 bodies: R = 8 doubles per lane, 252 VGPRs, two waves per SIMD (262 144 bodies 24.5 -> 23.1 ms, 65 536: 1.54 -> 1.47)
@@ -581,6 +587,11 @@ template <typename T> hipError_t launch_pair_tile(const PairArgs<T>& args, const
     const unsigned block     = 64u * static_cast<unsigned>(g.vectors_per_lane * W);
     a.blocks                 = (a.i_count + block - 1) / block;
     a.splits                 = g.splits;
+    {   // interleave the workgroups of a block when the units leave a remainder worth spreading (see the kernel)
+        const unsigned units = a.diag ? (a.blocks / 2 + 1) * static_cast<unsigned>(g.vectors_per_lane * W) : (a.j_count + 63) / 64;
+        const unsigned slots = g.splits * static_cast<unsigned>(g.waves), each = units / slots;
+        a.interleave         = (g.splits > 1 && units % slots != 0 && each < 34) ? 1u : 0u;
+    }
     const unsigned lds_bytes = static_cast<unsigned>(static_cast<size_t>(g.waves) * 3 * g.vectors_per_lane * W * 64 * sizeof(T)) + 256u;
     if (a.blocks == 0) return hipSuccess;
     switch (g.vectors_per_lane) {

@@ -211,7 +211,7 @@ def test_pair_plan_heuristics_without_gpu(pkg):
 
     assert plan(262144) == (1, 16, 8, 1, 256)      # the headline (round 4: sixteen bodies i per lane): 256 workgroups of 8 waves, one per CU, 127 reaction slots
     assert plan(1048576) == (1, 16, 8, 1, 1024)
-    assert plan(65536) == (1, 16, 12, 4, 64)       # four 12-wave workgroups share a block of bodies i and split its 528 units evenly (11 each)
+    assert plan(65536) == (1, 16, 8, 4, 64)        # four workgroups share a block of bodies i and split its 528 units: 16.5 per wave, interleaved so that every SIMD gets 33
     assert plan(131072) == (1, 16, 8, 2, 128) and plan(32768) == (1, 8, 8, 4, 64)
     assert plan(16384) == (1, 4, 8, 4, 64)         # small systems: half the bodies per lane, twice the blocks
     assert plan(8192)[0] == 0 and plan(10240)[0] == 1
@@ -280,8 +280,8 @@ def test_pairwise_inner_loops_keep_their_instruction_mix():
 
 def test_pairwise_headline_kernels_register_budget():
     """The register budget of the kernels the headline numbers come from (round 4: R = 8 vectors per lane) -- pair_forces<float, 8, 8>
-    (262 144 bodies fp32: 256 VGPRs, two waves per SIMD, one 8-wave workgroup per CU), pair_forces<float, 8, 12> (65 536 bodies: 168
-    VGPRs under launch_bounds(768), three waves per SIMD), pair_forces<double, 8, 8> (fp64: 252 VGPRs, nothing spilled) -- and of
+    (65 536 bodies and more, fp32: 256 VGPRs, two waves per SIMD, one 8-wave workgroup per CU), pair_forces<float, 8, 12> (reachable
+    through the plan override: 168 VGPRs under launch_bounds(768), three waves per SIMD), pair_forces<double, 8, 8> (fp64: 252 VGPRs, nothing spilled) -- and of
     pair_forces<float, 4, 8> (32 768 .. 65 535 bodies, slices and shards under 131 072: 128 VGPRs, four waves per SIMD): the
     occupancy asked for with amdgpu_waves_per_eu is what the compiler delivers, no AGPRs, and the VGPR spills that
     the per-tile prologue and epilogue carry neither grow nor reach the rotation loops: not one scratch_* instruction between a
