@@ -42,7 +42,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as entry  # noqa: E402
 
-from bench_support import (CONFIG3_BODIES, FP32_ISSUE_CEILING_INTERACTIONS_PER_S, FP32_VECTOR_PEAK_TFLOPS, FP64_ISSUE_CEILING_INTERACTIONS_PER_S,  # noqa: E402
+from bench_support import (CONFIG3_BODIES, ChipWatch, FP32_ISSUE_CEILING_INTERACTIONS_PER_S, FP32_VECTOR_PEAK_TFLOPS, FP64_ISSUE_CEILING_INTERACTIONS_PER_S,  # noqa: E402
                            FP64_VECTOR_PEAK_TFLOPS, cpu_baseline, make_bodies, multi_gpu_diagnostics, other_configs, pair_evaluations, pair_kernel_split,
                            rank_projection)
 
@@ -79,6 +79,7 @@ def parse_args():
     ap.add_argument("--rehearse-one-gpu", action="store_true",
                     help="REHEARSAL of the N-rank C-ABI path on a one-GPU box: every rank uses device 0 and RCCL is replaced by the test double "
                          "(NBODY_RCCL_LIB=tests/fake_rccl/libfake_rccl.so with FAKE_RCCL_IPC=1, set here when absent).  Never a performance number.")
+    ap.add_argument("--no-chip-watch", action="store_true", help="do not sample the card's clock and power (sysfs) during the timed region")
     ap.add_argument("--no-diagnostics", action="store_true", help="N>1: skip the A/B timings and BASELINE configs[3] after the timed region")
     ap.add_argument("--diagnostics-timeout", type=float, default=240.0, help="N>1: seconds the post-headline measurements may take before the line is printed without them")
     return ap.parse_args()
@@ -147,6 +148,15 @@ def self_launch(n_ranks: int, explicit_exchange: bool, limit_s: float) -> int:
         print(f"[bench] the {n_ranks}-rank run ended with status {rc} before reporting; one more attempt with --exchange {fallback}", file=sys.stderr, flush=True)
         rc, reported = attempt(["--exchange", fallback])
     return rc
+
+
+def pci_address(torch, device_index):
+    """'0000:c5:00.0' of a HIP device, as sysfs spells it (None when torch does not say)."""
+    try:
+        p = torch.cuda.get_device_properties(device_index)
+        return f"{p.pci_domain_id:04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0"
+    except Exception:  # noqa: BLE001
+        return None
 
 
 def main():
@@ -373,9 +383,11 @@ def main():
             torch.cuda.synchronize()
 
     # ------------------------------------------------------------------------------------------------ the timed region
+    chip = ChipWatch(None if args.no_chip_watch or rank != 0 else pci_address(torch, local_rank))  # (a child process reading two sysfs files; see bench_support.ChipWatch)
     for _ in range(args.warmup):
         step()
     fence()
+    chip.start()
     ev0, ev1 = pkg.Event(), pkg.Event()
     t0 = time.perf_counter()
     ev0.record(stream_ptr)
@@ -385,6 +397,7 @@ def main():
     ev1.record(stream_ptr)
     fence()
     elapsed = time.perf_counter() - t0
+    chip.stop()
     ev1.synchronize()
     stream_ms_per_step = ev0.elapsed_ms(ev1) / args.steps  # HIP events on the launch stream: this rank's step, kernels only at N = 1
 
@@ -471,6 +484,15 @@ def main():
             "algorithmic_hbm_bytes_per_launch": (128 if args.fp64 else 64) * (n // world),
             "workspace_rw_bytes_per_step": (2 * pair.workspace_bytes) if pair is not None else None,
         }
+        # The clock the chip ran at while it was timed (rank 0's card): the peak above assumes 2.4 GHz; under this load the socket
+        # sits near its power cap and the power management grants 2.0-2.3 GHz by box.  frac_at_delivered_clock = step_frac x 2400 /
+        # sclk: the timed steps' algorithmic flop over what the vector ALUs could issue AT THE CLOCK SAMPLED WHILE THEY RAN (step_frac,
+        # not frac: the dominant kernel is timed apart, after the region the samples come from).  Never the headline fraction.
+        roofline["chip"] = chip.summary()
+        if roofline["chip"] and roofline["chip"]["sclk_mhz"]:
+            roofline["frac_at_delivered_clock"] = roofline["step_frac"] * ChipWatch.PEAK_CLOCK_MHZ / roofline["chip"]["sclk_mhz"]
+            if world == 1 and roofline["chip"]["socket_power_w"]:
+                roofline["chip"]["interactions_per_joule"] = value / roofline["chip"]["socket_power_w"]
         line = {
             "metric": "body-body interactions/s, all-pairs N-body step (reference convention N^2 per step)",
             "value": value,

@@ -59,6 +59,114 @@ FP32_ISSUE_CEILING_INTERACTIONS_PER_S = 1024 * 128 * 2.4e9 / 61.5
 FP64_ISSUE_CEILING_INTERACTIONS_PER_S = 1024 * 64 * 2.4e9 / 78.0
 
 
+_CHIP_SAMPLER = r"""
+import os, sys, time
+hwmon, out, parent = sys.argv[1], sys.argv[2], int(sys.argv[3])
+def read(name):
+    try:
+        with open(os.path.join(hwmon, name)) as fh:
+            return fh.read().strip()
+    except OSError:
+        return ""
+end = time.time() + 900
+with open(out, "a", buffering=1) as fh:
+    while os.getppid() == parent and time.time() < end:
+        fh.write("%.6f %s %s\n" % (time.time(), read("freq1_input") or "-", read("power1_input") or "-"))
+        time.sleep(0.025)
+"""
+
+
+class ChipWatch:
+    """The chip's shader clock and socket power WHILE the timed region runs, read from the amdgpu driver's sysfs files of the card
+    with this device's PCI address (hwmon freq1_input / power1_input; an ordinary user may read them).  Why it is in the line: the
+    pairwise kernel keeps the vector ALUs ~97 % busy and the socket sits at its power cap (measured: 1 337-1 354 W of 1 400 W), so
+    the clock the power management grants -- 2.04 ... 2.29 GHz by box, against the 2.4 GHz the peak is computed at -- decides
+    `roofline.frac` between 0.85 and 0.93 for the same binary.
+    The sampler is a CHILD PROCESS (two small files every 25 ms, time-stamped lines into a temporary file) started before the
+    warm-up; start() / stop() only note the wall-clock window whose samples count.  It never opens the GPU and shares no
+    interpreter lock with the timing loop (a sampler THREAD cost a 26 ms timed region 1.6 ms: the loop's ctypes calls give up the
+    interpreter lock at every launch and wait to get it back).  Everything is None where the files are missing or unreadable."""
+
+    PEAK_CLOCK_MHZ = 2400.0  # what FP32_VECTOR_PEAK_TFLOPS / FP64_VECTOR_PEAK_TFLOPS assume
+
+    def __init__(self, pci_address, sysfs="/sys/class/drm"):
+        import glob
+        import subprocess
+        import tempfile
+
+        self.hwmon, self.child, self.path, self.window, self.samples = None, None, None, [None, None], []
+        for dev in glob.glob(os.path.join(sysfs, "card*", "device")) if pci_address else ():
+            try:
+                if os.path.basename(os.path.realpath(dev)).lower() != str(pci_address).lower():
+                    continue
+                found = sorted(glob.glob(os.path.join(dev, "hwmon", "hwmon*")))
+                if found and os.access(os.path.join(found[0], "freq1_input"), os.R_OK):
+                    self.hwmon = found[0]
+                    break
+            except OSError:
+                continue
+        if self.hwmon is None:
+            return
+        try:
+            fd, self.path = tempfile.mkstemp(prefix="nbody_chip_watch_", suffix=".txt")
+            os.close(fd)
+            # (an environment of its own: under rocprofv3 the parent's LD_PRELOAD / tool variables would make the child a second
+            # profiled process that opens the GPU; this one must never touch it)
+            self.child = subprocess.Popen([sys.executable, "-S", "-E", "-c", _CHIP_SAMPLER, self.hwmon, self.path, str(os.getpid())],
+                                          stdin=subprocess.DEVNULL, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, env={"PATH": "/usr/bin:/bin"})
+        except OSError:
+            self.child = None
+
+    def start(self):
+        self.window[0] = time.time()
+
+    def stop(self):
+        """Only notes the end of the window: ending the child and reading its file waits for summary(), so that nothing idles the
+        GPU between the timed region and what is timed right after it (30 ms of idling cost the next kernels 3 % of clock)."""
+        self.window[1] = time.time()
+
+    def _collect(self):
+        if self.child is None:
+            return
+        wait = self.window[1] + 0.03 - time.time()  # (one more sample period: the last line of the window is on disk)
+        if wait > 0:
+            time.sleep(wait)
+        self.child.terminate()
+        try:
+            self.child.wait(timeout=2)
+        except Exception:  # noqa: BLE001
+            self.child.kill()
+        self.child = None
+        try:
+            with open(self.path) as fh:
+                for text in fh:
+                    part = text.split()
+                    if len(part) == 3 and part[1] != "-" and self.window[0] <= float(part[0]) <= self.window[1]:
+                        self.samples.append((float(part[1]) * 1e-6, None if part[2] == "-" else float(part[2]) * 1e-6))
+            os.unlink(self.path)
+        except (OSError, ValueError):
+            pass
+
+    def _read(self, name):
+        try:
+            with open(os.path.join(self.hwmon, name)) as fh:
+                return float(fh.read().strip())
+        except (OSError, ValueError):
+            return None
+
+    def summary(self):
+        self._collect()
+        if not self.samples:
+            return None
+        clocks = sorted(c for c, _ in self.samples)
+        powers = sorted(p for _, p in self.samples if p is not None)
+        cap = self._read("power1_cap")
+        mid = lambda v: v[len(v) // 2] if v else None  # noqa: E731
+        return {"what": "shader clock and socket power during the timed region (amdgpu hwmon freq1_input / power1_input, a child process sampling every 25 ms)",
+                "sclk_mhz": mid(clocks), "sclk_mhz_min": clocks[0], "sclk_mhz_max": clocks[-1], "socket_power_w": mid(powers),
+                "power_cap_w": None if cap is None else cap * 1e-6, "samples": len(clocks), "peak_is_computed_at_mhz": self.PEAK_CLOCK_MHZ}
+
+
 def pair_evaluations(pair) -> float:
     """pair evaluations per step of the pairwise layout: NB x (NB/2 + 1) block pairs of (64 I)^2"""
     return float(pair.blocks) * (pair.blocks // 2 + 1) * pair.block_bodies * pair.block_bodies
@@ -77,11 +185,16 @@ def fractions(n, fp64, layout, ms, pair=None):
     return round(frac, 4), round((36 if fp64 else 24) * pair_evaluations(pair) / (ms * 1e-3) / (peak * 1e12), 4)
 
 
+CONFIG_WARMUP_S = 0.25  # other_configs: steps run (untimed) for at least this long before a config is timed
+
+
 def other_configs(pkg, lib, headline):
     """BASELINE.json configs besides the headline one, plus STRICT (the parity-exact mode) and, for FAST, both layouts
     (pairwise = nb_integrate_ws_* with a workspace, one-sided = nb_integrate_*), each as
-    {workload, bodies, dtype, mode, layout, steps, ms_per_step, frac, executed_frac}: 1 warm-up step, then K steps between two
-    HIP events on the launch stream (the reference's GPU protocol, compute_cuda.cpp:183-195); the fractions: see fractions()."""
+    {workload, bodies, dtype, mode, layout, steps, warmup_steps, ms_per_step, frac, executed_frac}: untimed steps for at least
+    CONFIG_WARMUP_S (steady clocks -- these entries are steady-state figures; the headline keeps the driver's W warm-up steps), then
+    K steps between two HIP events on the launch stream (the reference's GPU protocol, compute_cuda.cpp:183-195); the fractions:
+    see fractions()."""
     cases = [
         ("configs[1]", 65536, False, "fast", 200),
         ("configs[2]", 262144, False, "fast", 20),
@@ -89,9 +202,9 @@ def other_configs(pkg, lib, headline):
         ("configs[3]'s system on ONE GPU", 1048576, False, "fast", 3),
         ("STRICT = the CPU path's bits", 262144, False, "strict", 5),
         ("STRICT", 262144, True, "strict", 3),
-        ("configs[0]'s system on the GPU", 1024, False, "fast", 100),
-        ("configs[0]'s system on the GPU", 1024, False, "strict", 100),
-        ("small system", 16384, False, "fast", 200),
+        ("configs[0]'s system on the GPU", 1024, False, "fast", 2000),
+        ("configs[0]'s system on the GPU", 1024, False, "strict", 500),
+        ("small system", 16384, False, "fast", 1000),
         # beyond BASELINE's sizes: one tournament would want 206 GB of reaction slots; the tournament cut into slices inside 16 GB
         ("4 Mi bodies, workspace capped at 16 GB", 4194304, False, "fast", 2),
     ]
@@ -114,9 +227,16 @@ def other_configs(pkg, lib, headline):
             system = pkg.BodySystemHIP(n, 256, pkg.NBodyParams(), dtype, pos0, vel0, mode=mode, workspace=(layout == "pairwise"), workspace_cap=cap)
             dt = dtype(np.float32(0.016))
             system_bytes = system._workspace_bytes
-            system.update(dt)
+            # warm-up by TIME, not by count: the chip leaves its sleep clock while the bodies are made on the host, and the power
+            # management takes ~0.2 s under load to settle (a 13 ms run of 16 384 bodies right after a cold start is timed at
+            # 2.1-2.2 GHz, the same run after 0.25 s of steps at 2.39 GHz: kernel fraction 0.58 against 0.60)
+            warm_until, warmed = time.perf_counter() + CONFIG_WARMUP_S, 0
+            while warmed == 0 or time.perf_counter() < warm_until:
+                for _ in range(max(1, steps // 10)):
+                    system.update(dt)
+                system.synchronize()
+                warmed += max(1, steps // 10)
             e0, e1 = pkg.Event(), pkg.Event()
-            system.synchronize()
             e0.record(None)
             for _ in range(steps):
                 system.update(dt)
@@ -126,7 +246,7 @@ def other_configs(pkg, lib, headline):
             system.free()
             frac, executed = fractions(n, fp64, layout, ms, pkg.pair_plan(n, dtype) if layout == "pairwise" else None)
             # (kept short: the whole line should stay well under what a log tail holds; interactions/s = bodies^2 / ms_per_step)
-            out.append({"workload": what, "bodies": n, "dtype": "f64" if fp64 else "f32", "mode": mode_name, "layout": layout, "steps": steps,
+            out.append({"workload": what, "bodies": n, "dtype": "f64" if fp64 else "f32", "mode": mode_name, "layout": layout, "steps": steps, "warmup_steps": warmed,
                         "ms_per_step": float(f"{ms:.5g}"), "frac": frac, "executed_frac": executed})
             if cap is not None:
                 out[-1]["workspace_bytes"] = system_bytes

@@ -435,37 +435,45 @@ template <typename T> __global__ __launch_bounds__(256) void pair_finish(FinishA
     const unsigned k    = blockIdx.x * 64 + lane;  // relative to the rank's first body
     const bool     live = k < s.count;
     T              t[3] = {0, 0, 0};
+    // Wave 0 finishes the body: what it needs besides the reaction sums -- the body's own sums, its velocity and position -- is
+    // requested BEFORE the slot sums and the barrier, so that those loads are in flight together with the slot loads instead of one
+    // latency after the other (a finish launch at 16 384 bodies is latency, not bandwidth: 6 MB in 8 us).
+    const unsigned body   = s.origin + k;
+    const bool     closer = wave == 0 && live;
+    vec4           v{}, pn{}, e{};
+    T              own[3] = {0, 0, 0};
+    if (closer) {
+        v  = reinterpret_cast<const vec4*>(s.vel)[body];
+        pn = reinterpret_cast<const vec4*>(s.old_pos)[body];
+        if (s.extra != nullptr) e = reinterpret_cast<const vec4*>(s.extra)[body];
+#pragma unroll
+        for (int comp = 0; comp < 3; ++comp) {
+            for (unsigned m = 0; m < s.n_self; ++m) {
+                const auto& set = s.self_set[m];
+                if (k < set.first || k - set.first >= set.count) continue;
+                for (unsigned c = 0; c < set.slots; ++c) own[comp] += s.self[(static_cast<size_t>(set.slot + c) * 3 + comp) * s.self_plane + k];
+            }
+        }
+    }
     if (live) quarter_sums(s.react + k, s.react_plane, s.react_slots, wave, t);
     if (wave != 0) {
 #pragma unroll
         for (int comp = 0; comp < 3; ++comp) part[wave - 1][comp][lane] = t[comp];
     }
     __syncthreads();
-    if (wave != 0 || !live) return;
-    const unsigned body = s.origin + k;
-    T              f[3];
+    if (!closer) return;
+    T f[3];
 #pragma unroll
     for (int comp = 0; comp < 3; ++comp) {
-        T own = 0;
-        for (unsigned m = 0; m < s.n_self; ++m) {
-            const auto& set = s.self_set[m];
-            if (k < set.first || k - set.first >= set.count) continue;
-            for (unsigned c = 0; c < set.slots; ++c) own += s.self[(static_cast<size_t>(set.slot + c) * 3 + comp) * s.self_plane + k];
-        }
         T others = (t[comp] + part[0][comp][lane]) + (part[1][comp][lane] + part[2][comp][lane]);
         for (unsigned m = 0; m < s.n_recv; ++m) {
             const auto& set = s.recv_set[m];
             if (k < set.first || k - set.first >= set.count) continue;
             others += s.recv[(static_cast<size_t>(m) * 3 + comp) * s.recv_plane + k];
         }
-        f[comp] = own - others;  // d = p_j - p_i: what body j feels from body i is -m_i d w
+        f[comp] = own[comp] - others;  // d = p_j - p_i: what body j feels from body i is -m_i d w
     }
-    if (s.extra != nullptr) {
-        const vec4 e = reinterpret_cast<const vec4*>(s.extra)[body];
-        f[0] += e.x, f[1] += e.y, f[2] += e.z;
-    }
-    vec4 v  = reinterpret_cast<const vec4*>(s.vel)[body];
-    vec4 pn = reinterpret_cast<const vec4*>(s.old_pos)[body];
+    if (s.extra != nullptr) f[0] += e.x, f[1] += e.y, f[2] += e.z;
     v.x     = __builtin_fma(f[0], s.dt, v.x) * s.damping;
     v.y     = __builtin_fma(f[1], s.dt, v.y) * s.damping;
     v.z     = __builtin_fma(f[2], s.dt, v.z) * s.damping;

@@ -42,6 +42,37 @@ def test_launcher_does_not_retry_an_exchange_the_caller_chose():
     assert "one more attempt" not in out.stderr
 
 
+def test_chip_watch_reads_the_card_with_the_devices_pci_address(tmp_path):
+    """bench_support.ChipWatch on a made-up sysfs tree: the card is found by PCI address (a box shows the cards of the whole host),
+    the samples are the hwmon files' values in MHz and W, and a missing or unreadable tree gives None, never an error."""
+    import time
+
+    sys.path.insert(0, ROOT)
+    from bench_support import ChipWatch
+
+    for card, address, clock, power in ((0, "0000:05:00.0", 101000000, 244000000), (40, "0000:c5:00.0", 2256000000, 1354000000)):
+        real = tmp_path / "devices" / address
+        (real / "hwmon" / "hwmon7").mkdir(parents=True)
+        (real / "hwmon" / "hwmon7" / "freq1_input").write_text(f"{clock}\n")
+        (real / "hwmon" / "hwmon7" / "power1_input").write_text(f"{power}\n")
+        (real / "hwmon" / "hwmon7" / "power1_cap").write_text("1400000000\n")
+        (tmp_path / "drm" / f"card{card}").mkdir(parents=True)
+        os.symlink(real, tmp_path / "drm" / f"card{card}" / "device")
+    watch = ChipWatch("0000:C5:00.0", sysfs=str(tmp_path / "drm"))
+    time.sleep(0.5)  # (the child process starts up: samples before start() must not count)
+    before = time.time()
+    watch.start()
+    time.sleep(0.2)
+    watch.stop()
+    got = watch.summary()
+    assert not os.path.exists(watch.path) and watch.child is None
+    assert got["sclk_mhz"] == 2256.0 and got["socket_power_w"] == 1354.0 and got["power_cap_w"] == 1400.0 and 2 <= got["samples"] <= 12
+    assert time.time() - before < 1.0
+    for nothing in (ChipWatch(None, sysfs=str(tmp_path / "drm")), ChipWatch("0000:aa:00.0", sysfs=str(tmp_path / "drm")), ChipWatch("0000:c5:00.0", sysfs=str(tmp_path / "none"))):
+        nothing.start(), nothing.stop()
+        assert nothing.summary() is None and nothing.child is None
+
+
 @pytest.mark.gpu
 def test_plain_shell_bench_starts_two_ranks_on_one_gpu():
     """The rehearsal form (gloo, ranks sharing the one GPU): the launcher, the rank set-up, the sharded step and the
@@ -111,6 +142,9 @@ def test_default_line_carries_every_baseline_config():
     assert roof["kernel"] == "pair_forces" and roof["kernel_ms"] == roof["pair_forces_ms"] > 10 * roof["pair_finish_ms"] > 0
     assert abs(roof["pair_forces_ms"] + roof["pair_finish_ms"] - roof["stream_ms_per_step"]) < 0.05 * roof["stream_ms_per_step"]
     assert roof["step_frac"] <= roof["frac"]
+    if roof["chip"] is not None:  # (sysfs readable: the clock the chip ran at, and the fraction of what it could issue at THAT clock)
+        assert 500 < roof["chip"]["sclk_mhz"] <= 2500 and roof["chip"]["samples"] >= 1
+        assert 0.98 * roof["step_frac"] <= roof["frac_at_delivered_clock"] < 1.05
     # algorithmic HBM bytes are the bodies in and out; the workspace traffic is stated next to them
     assert roof["algorithmic_hbm_bytes_per_launch"] == 64 * 262144
     assert roof["workspace_rw_bytes_per_step"] == 2 * line["config"]["kernel_plan"]["workspace_bytes"]

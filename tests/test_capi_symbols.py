@@ -438,3 +438,30 @@ def test_sliced_pairwise_plan_without_gpu(pkg):
     finally:
         lib.nb_set_memory_budget(0)
         pkg.set_pair_slices_override(0)
+
+
+def test_makefile_rebuilds_an_object_when_any_header_it_includes_changes():
+    """PairArgs / FinishArgs / Shard cross translation units BY VALUE: an object built against an older nbody_kernels.h launches
+    kernels with a shifted argument block (round 4 met that as a GPU memory fault after one new field).  Every object rule of
+    csrc/Makefile must therefore list every header its source includes, directly or through another header of ours."""
+    import re
+
+    csrc = os.path.join(ROOT, "cuda-nbody_amd", "csrc")
+    with open(os.path.join(csrc, "Makefile")) as fh:
+        rules = {m.group(1): m.group(2).split() for m in re.finditer(r"^(\w+)\.o:(.*)$", fh.read(), re.M)}
+
+    def includes(path, seen):
+        with open(path) as fh:
+            for name in re.findall(r'^\s*#include "([^"]+)"', fh.read(), re.M):
+                full = os.path.normpath(os.path.join(os.path.dirname(path), name))
+                if full not in seen:
+                    seen.add(full)
+                    includes(full, seen)
+        return seen
+
+    sources = sorted(f for f in os.listdir(csrc) if f.endswith(".hip") and f.startswith("nbody_"))
+    assert {s[:-4] for s in sources} == set(rules), (sources, sorted(rules))
+    for src in sources:
+        listed = {os.path.normpath(os.path.join(csrc, p)) for p in rules[src[:-4]]}
+        missing = includes(os.path.join(csrc, src), set()) - listed
+        assert not missing, f"{src[:-4]}.o does not depend on {sorted(os.path.relpath(m, csrc) for m in missing)}"
