@@ -116,6 +116,9 @@ class ChipWatch:
                                           stdin=subprocess.DEVNULL, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, env={"PATH": "/usr/bin:/bin"})
         except OSError:
             self.child = None
+        import atexit
+
+        atexit.register(self._collect)  # (a run that ends before summary(): the child and its file do not outlive it)
 
     def start(self):
         self.window[0] = time.time()
@@ -127,7 +130,11 @@ class ChipWatch:
 
     def _collect(self):
         if self.child is None:
+            if self.path and os.path.exists(self.path):
+                os.unlink(self.path)
             return
+        if self.window[1] is None:
+            self.window = [0.0, 0.0]  # (never stopped: nothing counts)
         wait = self.window[1] + 0.03 - time.time()  # (one more sample period: the last line of the window is on disk)
         if wait > 0:
             time.sleep(wait)
