@@ -524,12 +524,18 @@ template <typename T, int R> hipError_t launch_r(const PairArgs<T>& args, int wa
 
 }  // namespace
 
-// Workgroups per block, by how the launch fills the chip: all workgroups of a launch carry the same work, so a grid of r "rounds" of
-// resident workgroups (256 CUs x 16 waves / S) takes ceil(r) rounds of time -- 1 639 blocks of eight waves are 3.2 rounds and cost 4
-// (80 %); split in four they are 12.8 and cost 13 (98 %).  Starting from `wanted`, doubles C while that gains more than 2 % and every
-// wave keeps at least four units.  (Up to one round nothing is lost: the workgroups all run at once.)
-inline unsigned splits_for_full_rounds(unsigned blocks, unsigned units_per_block, int S, unsigned wanted, int waves_per_simd = 4) {
-    const double resident = 256.0 * 4.0 * waves_per_simd / S;  // workgroups the chip holds at once
+// How a launch fills the chip (what the two functions below model).  A workgroup of eight waves puts two waves on every SIMD of its
+// CU, and two runnable waves already take ~97 % of a SIMD's issue slots: a second workgroup on the same CU (R <= 4 fits two)
+// does not add throughput, the two share it.  So whatever the residency, a launch costs  max over CUs of (workgroups on it) x (one
+// workgroup's time) = ceil(grid / 256) "rounds" for eight waves (measured, round 4: 36 000 bodies as 71 blocks x 4 = 284 workgroups of
+// R = 4 took 359 us -- two rounds -- against 181 us for the 256 workgroups of 32 768 bodies; profiles/round4_plan_sweep.txt).
+inline double resident_workgroups(int S) { return 256.0 * std::max(1, 8 / S); }  // (four waves: two workgroups saturate a CU)
+
+// Workgroups per block for the shard / slice plans: all workgroups of a launch carry the same work, so a grid of r rounds takes
+// ceil(r) rounds of time -- 1 639 blocks of eight waves are 6.4 rounds and cost 7 (91 %); split in four they are 25.6 and cost 26
+// (98 %).  Starting from `wanted`, doubles C while that gains more than 2 % and every wave keeps at least four units.
+inline unsigned splits_for_full_rounds(unsigned blocks, unsigned units_per_block, int S, unsigned wanted) {
+    const double resident = resident_workgroups(S);
     auto         eff      = [&](unsigned C) {
         const double r = blocks * static_cast<double>(C) / resident;
         return r <= 1.0 ? 1.0 : r / std::ceil(r);
@@ -541,52 +547,82 @@ inline unsigned splits_for_full_rounds(unsigned blocks, unsigned units_per_block
     return best;
 }
 
-// Geometry (measured: tools/pair_crossover.py -> profiles/round3_pair_crossover_f32.jsonl, _f64.jsonl).
-//   R = 4 vectors per lane (fp32: 8 bodies i, fp64: 4) is what 128 VGPRs hold; from 65 536 bodies R = 8 (256 VGPRs, two waves
-//   per SIMD, one 8-wave workgroup per CU) amortises the 9 rotation moves over twice the arithmetic and wins by 4-6 % (round 4);
-//   smaller systems take R = 2: twice the blocks, so twice the workgroups to spread over the chip.
-//   S = 8 waves per workgroup (R <= 4: two workgroups per CU; R = 8: one).
-//   C workgroups share a block of bodies i (and split its tiles) while the blocks alone do not fill the chip.
+// The units the busiest SIMD of a workgroup works through (eight waves: SIMD s holds waves s and s + 4): U units dealt to C*S slots,
+// the first U mod (C*S) slots taking one more -- interleaved (slot = wave*C + c: the longer waves are the low wave ids of every
+// workgroup) or blocked (slot = c*S + wave: all the waves of the first workgroups), as launch_pair_tile decides.
+inline unsigned busiest_simd_units(unsigned U, unsigned C, int S, bool* interleave = nullptr) {
+    const unsigned slots = C * static_cast<unsigned>(S), base = U / slots, rem = U % slots;
+    const bool     inter = C > 1 && rem != 0 && base < 34;  // (the rule of launch_pair_tile)
+    if (interleave) *interleave = inter;
+    if (rem == 0) return 2 * base;
+    const unsigned longer = (inter || C == 1) ? (rem + C - 1) / C : std::min(rem, static_cast<unsigned>(S));  // longer waves in the worst workgroup
+    return 2 * base + (longer <= 4 ? 1u : 2u);
+}
+
+// Geometry of the single-GPU tournament: R (vectors per lane: blocks of 64*R*W bodies) and C (workgroups sharing a block, any
+// number up to 16) by a cost model fitted to sweeps of 83 body counts x up to 15 geometries (fp32; 31 x 15 fp64;
+// profiles/round4_plan_sweep.txt; tools/pair_plan_times.py):
+//     us ~ rounds * ((units of the busiest SIMD) * unit[R] + wg[R])  +  slot * n * (reaction slots + C) * 1e-6  (+ a constant)
+// -- rounds and units as above; unit[R] = what 64 rotation steps of two waves cost a SIMD (16R + 9 vector instructions per step);
+// wg[R] = a workgroup's set-up and fold (it grows with the bodies i a lane holds); the last term is everything that grows with the
+// reaction planes (pair_finish, the stores).  It reproduces the sweeps to 2.6 % (worst 10 %), and fitted on one half of the fp32
+// sweep its choice on the other half is within 1.5 % of the best measured geometry on average (worst 8 %) -- the fixed table it
+// replaces: 6 % on average and 44 % at 34 000 bodies, where 4 x 67 = 268 workgroups cost two rounds.  The powers of two come out
+// as the table had them: R = 2 up to 16 384 bodies, 4 at 32 768, 8 from 65 536 (256 VGPRs, two waves per SIMD, the 9 rotation
+// moves amortised over twice the arithmetic); C = 4 / 4 / 4 / 2 / 1 at 16 384 ... 262 144.  In between, C is whatever fills whole
+// rounds: 50 000 bodies are 49 blocks of 1 024 -- x 5 = 245 workgroups, one round (0.67 -> 0.80 of the peak); 33 000 bodies
+// 0.59 -> 0.71.  Only the ratios of the constants matter (box clocks differ).
+template <typename T> struct PairCost;
+template <> struct PairCost<float> {
+    static constexpr double unit[3] = {4.53, 9.17, 17.72}, wg[3] = {0.0, 1.45, 6.86}, slot = 14.1;
+};
+template <> struct PairCost<double> {
+    static constexpr double unit[3] = {5.12, 10.39, 20.72}, wg[3] = {0.0, 0.0, 0.0}, slot = 21.9;  // (the sweep does not resolve wg: fitted freely it comes out negative)
+};
+
 template <typename T> PairPlan plan_pair(unsigned n, int cu_count, int ovr_r, int ovr_s, int ovr_c) {
     constexpr int W = sizeof(T) == 4 ? 2 : 1;
     (void)cu_count;
-    PairPlan      p{};
-    int           R = 4, S = 8;
-    unsigned      C = 1;
-    if (sizeof(T) == 4) {
-        // from 65 536 bodies: R = 8 (same box, tools/ab.sh: 262 144 bodies 10.10 -> 9.59 ms, 65 536 bodies 0.712 -> 0.665 ms; half the
-        // blocks, so half the reaction slots, half the workspace and half of pair_finish); twelve waves where eight leave a remainder
-        R = n < 32768 ? 2 : (n < 65536 ? 4 : 8);
-        S = 8;  // (twelve waves -- <float, 8, 12>, 168 VGPRs, three per SIMD -- stay available through the override: with the units interleaved eight do better)
-        C = n < 32768 ? (n <= 16384 ? 4 : 8) : (n < 65536 ? 4 : 1);
-    } else {
-        // from 65 536 bodies: R = 8 doubles per lane, 252 VGPRs, two waves per SIMD (262 144 bodies 24.5 -> 23.1 ms, 65 536: 1.54 -> 1.47)
-        R = n < 16384 ? 2 : (n < 65536 ? 4 : 8);
-        S = 8;
-        C = n < 65536 ? 4 : 1;
+    const bool fixed_r = ovr_r == 1 || ovr_r == 2 || ovr_r == 4 || ovr_r == 8;  // (R = 6 was tried: 74 KB of LDS per workgroup and 342 ragged blocks -- 11.8 against 10.2 ms)
+    const int  S       = (ovr_s == 4 || ovr_s == 8 || ovr_s == 12 || ovr_s == 16) ? ovr_s : 8;  // (twelve waves -- <float, 8, 12>, 168 VGPRs -- through the override only: with the units interleaved eight do better)
+    auto geometry = [&](int R, unsigned C) {
+        PairPlan p{};
+        const unsigned block  = 64u * static_cast<unsigned>(R * W);
+        const unsigned blocks = (n + block - 1) / block;
+        p.vectors_per_lane = R;
+        p.waves            = S;
+        p.splits           = C;
+        p.blocks           = blocks;
+        p.block_bodies     = block;
+        p.slots            = blocks < 2 ? 0u : ((blocks & 1u) ? blocks / 2 : blocks / 2 - 1);
+        p.grid_blocks      = blocks * C;
+        p.lds_bytes        = static_cast<unsigned>(static_cast<size_t>(S) * 3 * R * W * 64 * sizeof(T)) + 256u;
+        p.workspace_bytes  = (static_cast<size_t>(C) + p.slots) * 3 * static_cast<size_t>(blocks) * block * sizeof(T);
+        return p;
+    };
+    auto units_of = [&](const PairPlan& p) { return (p.blocks / 2 + 1) * static_cast<unsigned>(p.vectors_per_lane * W); };
+    auto with_units = [&](int R, unsigned C) {  // no wave without a unit
+        PairPlan p = geometry(R, C);
+        while (p.splits > 1 && units_of(p) < p.splits * static_cast<unsigned>(S)) p = geometry(R, p.splits / 2);
+        return p;
+    };
+    PairPlan best{};
+    double   best_cost = 0;
+    for (int R : {1, 2, 4, 8}) {  // (near-ties go to the smaller R -- 32 768 bodies: R = 4, C = 4 178 us, R = 8, C = 8 184 us -- and the smaller C)
+        if (fixed_r ? R != ovr_r : R == 1) continue;  // (R = 1 through the override only: 25 instructions for 4 pair evaluations)
+        for (unsigned C = 1; C <= 16; ++C) {  // (any C, not only powers of two: 50 000 bodies are 49 blocks of 1 024 -- x 5 = 245 workgroups, one round)
+            const PairPlan p = ovr_c > 0 ? with_units(R, static_cast<unsigned>(ovr_c)) : geometry(R, C);
+            const unsigned U = units_of(p);
+            if (ovr_c <= 0 && C > 1 && U < 2 * C * static_cast<unsigned>(S)) continue;  // every wave at least two units (a workgroup's set-up and fold cost about one)
+            const double rounds = std::ceil(p.grid_blocks / resident_workgroups(S));
+            const int    k      = R <= 2 ? 0 : (R == 4 ? 1 : 2);
+            const double cost   = rounds * (busiest_simd_units(U, p.splits, S) * PairCost<T>::unit[k] * (R == 1 ? 0.61 : 1.0) + PairCost<T>::wg[k]) +
+                                PairCost<T>::slot * 1e-6 * static_cast<double>(n) * (p.slots + p.splits);
+            if (best.blocks == 0 || cost < 0.995 * best_cost) best = p, best_cost = cost;
+            if (ovr_c > 0) break;
+        }
     }
-    if (ovr_r == 1 || ovr_r == 2 || ovr_r == 4 || ovr_r == 8) R = ovr_r;  // (R = 6 was tried: 74 KB of LDS per workgroup and 342 ragged blocks -- 11.8 against 10.2 ms)
-    if (ovr_s == 4 || ovr_s == 8 || ovr_s == 12 || ovr_s == 16) S = ovr_s;
-    const unsigned block  = 64u * static_cast<unsigned>(R * W);
-    const unsigned blocks = (n + block - 1) / block;
-    const unsigned units  = (blocks / 2 + 1) * static_cast<unsigned>(R * W);
-    const int      held   = R <= 4 ? 4 : (S == 12 ? 3 : 2);  // waves per SIMD (kPairWavesPerSimd)
-    if (R > 4) {
-        while (blocks * C < 256 && units >= C * 2 * static_cast<unsigned>(S) * 4) C *= 2;  // one workgroup per CU: fill the 256 CUs first
-    }
-    C = splits_for_full_rounds(blocks, units, S, C, held);  // (the sizes the table was tuned on -- powers of two -- come out unchanged)
-    if (ovr_c > 0) C = static_cast<unsigned>(ovr_c);
-    while (C > 1 && units < C * static_cast<unsigned>(S)) C /= 2;  // no wave without a unit
-    p.vectors_per_lane = R;
-    p.waves            = S;
-    p.splits           = C;
-    p.blocks           = blocks;
-    p.block_bodies     = block;
-    p.slots            = blocks < 2 ? 0u : ((blocks & 1u) ? blocks / 2 : blocks / 2 - 1);
-    p.grid_blocks      = blocks * C;
-    p.lds_bytes        = static_cast<unsigned>(static_cast<size_t>(S) * 3 * R * W * 64 * sizeof(T)) + 256u;
-    p.workspace_bytes  = (static_cast<size_t>(C) + p.slots) * 3 * static_cast<size_t>(blocks) * block * sizeof(T);
-    return p;
+    return best;
 }
 
 template <typename T> hipError_t launch_pair_tile(const PairArgs<T>& args, const PairGeom& g, hipStream_t stream, bool prepare_only) {
@@ -671,7 +707,7 @@ template <typename T> PairSlicing plan_pair_sliced(unsigned n, unsigned slices, 
     auto splits = [&](unsigned units) {  // workgroups per block: fill the chip (~512 workgroups of 8 waves) while a wave keeps >= 2 units, then whole rounds
         unsigned C = 1;
         while (per * C * 2 <= chip && units >= C * 2 * static_cast<unsigned>(S) * 2) C *= 2;
-        C = splits_for_full_rounds(per, units, S, C, R > 4 ? 2 : 4);
+        C = splits_for_full_rounds(per, units, S, C);
         if (ovr_c > 0) C = static_cast<unsigned>(ovr_c);
         while (C > 1 && units < C * static_cast<unsigned>(S)) C /= 2;
         return C;

@@ -465,3 +465,31 @@ def test_makefile_rebuilds_an_object_when_any_header_it_includes_changes():
         listed = {os.path.normpath(os.path.join(csrc, p)) for p in rules[src[:-4]]}
         missing = includes(os.path.join(csrc, src), set()) - listed
         assert not missing, f"{src[:-4]}.o does not depend on {sorted(os.path.relpath(m, csrc) for m in missing)}"
+
+
+def test_pair_plan_fills_whole_rounds_at_any_body_count(pkg):
+    """The geometry search of plan_pair (csrc/nbody_pair.hip): a launch of eight-wave workgroups costs ceil(grid / 256) rounds, so
+    at ANY body count the plan must not leave much of its last round empty (the fixed table it replaces put 284 workgroups on
+    256 CUs at 36 000 bodies: two rounds for the work of 1.1), must give every wave of a shared block at least two units, and must
+    keep the choices measured at the powers of two.  Pure host logic."""
+    import numpy as np
+
+    worst = {}
+    for dtype in (np.float32, np.float64):
+        W = 2 if dtype is np.float32 else 1
+        sizes = sorted(set([8193 + 977 * k for k in range(0, 120)] + [100003 + 20011 * k for k in range(0, 100)] + [1 << k for k in range(14, 23)]))
+        for n in sizes:
+            p = pkg.pair_plan(n, dtype)
+            if not p.applies:
+                continue
+            assert p.waves_per_block == 8 and 1 <= p.splits <= 16 and p.bodies_per_lane // W in (2, 4, 8), (n, p.bodies_per_lane, p.splits)
+            units = (p.blocks // 2 + 1) * p.bodies_per_lane
+            assert p.splits == 1 or units >= 2 * p.splits * 8, (n, units, p.splits)
+            rounds = p.grid_blocks / 256
+            fill = rounds / -(-p.grid_blocks // 256)
+            if p.grid_blocks > 256:
+                assert fill >= 0.80, (n, dtype.__name__, p.bodies_per_lane, p.splits, p.blocks, fill)
+                worst[dtype.__name__] = min(worst.get(dtype.__name__, 1.0), fill)
+            if n >= 200000:
+                assert p.bodies_per_lane // W == 8, (n, p.bodies_per_lane)  # large systems: sixteen (eight) bodies i per lane
+    assert worst["float32"] >= 0.80 and worst["float64"] >= 0.80

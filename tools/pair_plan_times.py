@@ -19,7 +19,7 @@ lib = pkg.lib()
 pkg.check(lib.nb_set_device(0))
 dtype = np.float64 if sys.argv[1] == "f64" else np.float32
 sizes = [int(x) for x in sys.argv[2].split(",")]
-plans = [tuple(int(v) for v in a.split(",")) for a in sys.argv[3:] if not a.startswith("--")]
+plans = [tuple(int(v) for v in a.split(",")) for a in sys.argv[3:] if a.count(",") == 2]
 reps = int(sys.argv[sys.argv.index("--reps") + 1]) if "--reps" in sys.argv else 3
 host = entry.load_oracle().Oracle()  # (start-up bodies only)
 
