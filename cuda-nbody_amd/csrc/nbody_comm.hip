@@ -316,10 +316,14 @@ template <typename T> PairShard plan_pair_shard(unsigned num_bodies, int G, int 
     if (p.ni < static_cast<unsigned>(min_slice > 0 ? min_slice : 2048) || G / 2 > nb::kMaxRecv || G / 2 + 1 > nb::kMaxSelfSets) return p;
     int ovr_r = 0, ovr_s = 0, ovr_c = 0;
     nb::pair_plan_overrides(&ovr_r, &ovr_s, &ovr_c);  // (tuning sweeps: tools/pair_rank_probe.py)
-    // (slices of 131 072 bodies and more: R = 8, one 8-wave workgroup per CU, as on one GPU -- nbody_pair.hip)
-    const int R = ovr_r > 0 ? ovr_r : (p.ni >= 131072 ? 8 : ((sizeof(T) == 4 ? p.ni >= 16384 : p.ni >= 8192) ? 4 : 2));
+    // R = 8 from slices of 32 768 bodies (round 4, one rank's kernels alone on one GPU: 65 536-body slices 2.54 -> 2.45 ms, 32 768-body
+    // slices 1.356 -> 1.284 ms together with the workgroup count below; half the blocks, so half the reaction planes and workspace).
+    const int R = ovr_r > 0 ? ovr_r : (p.ni >= 32768u ? 8 : ((sizeof(T) == 4 ? p.ni >= 16384 : p.ni >= 8192) ? 4 : 2));
     const int S = ovr_s > 0 ? ovr_s : 8;
-    const unsigned chip = R > 4 ? 256u : 512u;  // workgroups the chip holds at once
+    // Workgroups per launch: a launch of eight-wave workgroups costs ceil(grid / 256) rounds whatever the residency (nbody_pair.hip),
+    // and from two partners on, two rectangles run at once (they alternate between two streams): 128 workgroups each fill the
+    // chip together, 256 each only queue behind one another (32 768-body slices, R = 8: C = 4 1.284 ms, C = 8 1.334 ms).
+    const unsigned chip = (static_cast<unsigned>(G) / 2 >= 2) ? 128u : 256u;
     p.block  = 64u * static_cast<unsigned>(R) * W;
     p.blocks = (p.ni + p.block - 1) / p.block;
     p.plane  = (p.ni + 63u) / 64u * 64u;
@@ -327,7 +331,7 @@ template <typename T> PairShard plan_pair_shard(unsigned num_bodies, int G, int 
     p.even   = (G % 2) == 0;
     p.half   = (p.blocks / 2) * p.block;
     p.diag_slots = p.blocks < 2 ? 0u : ((p.blocks & 1u) ? p.blocks / 2 : p.blocks / 2 - 1);
-    auto splits = [&](unsigned units) {  // workgroups per block: fill the chip (~512 workgroups of 8 waves) while a wave keeps >= 2 units
+    auto splits = [&](unsigned units) {  // workgroups per block: up to `chip` workgroups per launch while a wave keeps >= 2 units
         unsigned C = 1;
         while (p.blocks * C * 2 <= chip && units >= C * 2 * static_cast<unsigned>(S) * 2) C *= 2;
         if (ovr_c > 0) C = static_cast<unsigned>(ovr_c);

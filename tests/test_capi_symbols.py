@@ -324,7 +324,7 @@ def test_pairwise_headline_kernels_register_budget():
 
 
 def test_pair_shard_plan_without_gpu(pkg):
-    """(Slices of 131 072 bodies and more take sixteen bodies i per lane; 32 768 per rank keep eight.)  The multi-GPU pairwise plan is host logic too: nb_emulate_pair_rank_* with no workspace only answers how many bytes a
+    """(Slices of 32 768 bodies and more take sixteen bodies i per lane.)  The multi-GPU pairwise plan is host logic too: nb_emulate_pair_rank_* with no workspace only answers how many bytes a
     rank of a G-rank step needs -- (self sets + diagonal slots + two rectangle regions + send + receive planes) x 3 x the padded
     slice -- or says that the pairwise step does not apply (slices under 2 048 bodies, a world of one, bodies that do not shard)."""
     import ctypes
@@ -339,9 +339,10 @@ def test_pair_shard_plan_without_gpu(pkg):
         return rc, bytes_.value
 
     rc, b8 = need(262144, 8)
-    # 32 768 bodies per rank: R = 4 -> 64 blocks of 512, C = 8 for the diagonal and the rectangles -- 16 for the split rectangle at
-    # distance 4 as its higher partner runs it (half of its blocks of bodies i) --, H = 4 partners, 31 diagonal slots
-    assert rc == 0 and b8 == ((8 + 3 * 8 + 16) + 31 + 2 * 64 + 4 + 4) * 3 * 32768 * 4
+    # 32 768 bodies per rank: R = 8 -> 32 blocks of 1 024, C = 4 for the diagonal and the rectangles (128 workgroups per launch: two
+    # rectangles run at once) -- 8 for the split rectangle at distance 4 as its higher partner runs it (half of its blocks of
+    # bodies i) --, H = 4 partners, 15 diagonal slots
+    assert rc == 0 and b8 == ((4 + 3 * 4 + 8) + 15 + 2 * 32 + 4 + 4) * 3 * 32768 * 4
     rc, b2 = need(262144, 2)
     assert rc == 0 and b2 > b8
     assert need(262144, 8, fn=lib.nb_emulate_pair_rank_f64, dt=0.016)[0] == 0
