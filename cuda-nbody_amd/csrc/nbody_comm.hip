@@ -331,10 +331,8 @@ template <typename T> PairShard plan_pair_shard(unsigned num_bodies, int G, int 
     p.even   = (G % 2) == 0;
     p.half   = (p.blocks / 2) * p.block;
     p.diag_slots = p.blocks < 2 ? 0u : ((p.blocks & 1u) ? p.blocks / 2 : p.blocks / 2 - 1);
-    auto splits = [&](unsigned units) {  // workgroups per block: up to `chip` workgroups per launch while a wave keeps >= 2 units
-        unsigned C = 1;
-        while (p.blocks * C * 2 <= chip && units >= C * 2 * static_cast<unsigned>(S) * 2) C *= 2;
-        if (ovr_c > 0) C = static_cast<unsigned>(ovr_c);
+    auto splits = [&](unsigned units) {  // workgroups per block: `chip` workgroups per launch, or whole multiples (nb::splits_to_fill)
+        unsigned C = ovr_c > 0 ? static_cast<unsigned>(ovr_c) : nb::splits_to_fill(p.blocks, units, S, chip);
         while (C > 1 && units < C * static_cast<unsigned>(S)) C /= 2;
         return C;
     };

@@ -59,6 +59,25 @@ struct PairPlan {
     size_t   workspace_bytes;
 };
 
+// Workgroups per block for ONE launch of the slice / shard plans (diagonal or rectangle): all workgroups of a launch carry the same
+// work, and a launch of eight-wave workgroups costs ceil(grid / 256) rounds whatever the residency (nbody_pair.hip), so the C
+// (any number up to 16) that fills `chip` workgroups -- or whole multiples of it -- best, while every wave keeps two units; among
+// the choices within 2 % of the best fill the smallest C (fewer planes of partial sums).  chip: 256, or 128 where two launches
+// run at once.  (69 blocks x 2 = 138 workgroups fill 54 % of a round; x 11 = 759 fill 99 % of three.)
+inline unsigned splits_to_fill(unsigned blocks, unsigned units_per_block, int waves, unsigned chip) {
+    auto fill = [&](unsigned C) {
+        const double r = static_cast<double>(blocks) * C / chip;
+        const double whole = static_cast<double>(static_cast<unsigned long long>(r) + ((r > static_cast<double>(static_cast<unsigned long long>(r))) ? 1 : 0));
+        return r <= 1.0 ? r : r / whole;
+    };
+    double best = 0;
+    for (unsigned C = 1; C <= 16 && (C == 1 || units_per_block >= 2 * C * static_cast<unsigned>(waves)); ++C) best = fill(C) > best ? fill(C) : best;
+    for (unsigned C = 1; C <= 16 && (C == 1 || units_per_block >= 2 * C * static_cast<unsigned>(waves)); ++C) {
+        if (fill(C) >= best - 0.02) return C;
+    }
+    return 1;
+}
+
 struct PairGeom {
     int      vectors_per_lane;  // R
     int      waves;             // S

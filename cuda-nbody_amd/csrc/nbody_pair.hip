@@ -531,22 +531,6 @@ template <typename T, int R> hipError_t launch_r(const PairArgs<T>& args, int wa
 // R = 4 took 359 us -- two rounds -- against 181 us for the 256 workgroups of 32 768 bodies; profiles/round4_plan_sweep.txt).
 inline double resident_workgroups(int S) { return 256.0 * std::max(1, 8 / S); }  // (four waves: two workgroups saturate a CU)
 
-// Workgroups per block for the shard / slice plans: all workgroups of a launch carry the same work, so a grid of r rounds takes
-// ceil(r) rounds of time -- 1 639 blocks of eight waves are 6.4 rounds and cost 7 (91 %); split in four they are 25.6 and cost 26
-// (98 %).  Starting from `wanted`, doubles C while that gains more than 2 % and every wave keeps at least four units.
-inline unsigned splits_for_full_rounds(unsigned blocks, unsigned units_per_block, int S, unsigned wanted) {
-    const double resident = resident_workgroups(S);
-    auto         eff      = [&](unsigned C) {
-        const double r = blocks * static_cast<double>(C) / resident;
-        return r <= 1.0 ? 1.0 : r / std::ceil(r);
-    };
-    unsigned best = std::max(1u, wanted);
-    for (unsigned C = best * 2; C <= 16 && units_per_block >= C * static_cast<unsigned>(S) * 4; C *= 2) {
-        if (eff(C) > eff(best) + 0.02) best = C;
-    }
-    return best;
-}
-
 // The units the busiest SIMD of a workgroup works through (eight waves: SIMD s holds waves s and s + 4): U units dealt to C*S slots,
 // the first U mod (C*S) slots taking one more -- interleaved (slot = wave*C + c: the longer waves are the low wave ids of every
 // workgroup) or blocked (slot = c*S + wave: all the waves of the first workgroups), as launch_pair_tile decides.
@@ -690,10 +674,11 @@ template <typename T> PairSlicing plan_pair_sliced(unsigned n, unsigned slices, 
     constexpr unsigned W = sizeof(T) == 4 ? 2 : 1;
     PairSlicing        p{};
     if (n == 0 || slices < 2) return p;
-    // slices of 131 072 bodies and more take R = 8 (sixteen fp32 / eight fp64 bodies i per lane, one 8-wave workgroup per CU), as whole systems do
-    const int R = (ovr_r == 1 || ovr_r == 2 || ovr_r == 4 || ovr_r == 8) ? ovr_r : (n / slices >= 131072 ? 8 : 4);
+    // slices of 32 768 bodies and more take R = 8 (sixteen fp32 / eight fp64 bodies i per lane, one 8-wave workgroup per CU), as the
+    // slices of a multi-GPU step do (measured there: profiles/round4_shard_plan_times.txt)
+    const int R = (ovr_r == 1 || ovr_r == 2 || ovr_r == 4 || ovr_r == 8) ? ovr_r : (n / slices >= 32768 ? 8 : 4);
     const int S = (ovr_s == 4 || ovr_s == 8 || ovr_s == 12 || ovr_s == 16) ? ovr_s : 8;
-    const unsigned chip = R > 4 ? 256u : 512u;  // workgroups the chip holds at once
+    const unsigned chip = 256u;  // a launch costs ceil(grid / 256) rounds whatever the residency; the launches of a step run one after the other
     p.block_bodies          = 64u * static_cast<unsigned>(R) * W;
     const unsigned blocks   = (n + p.block_bodies - 1) / p.block_bodies;
     const unsigned per      = (blocks + slices - 1) / slices;            // blocks per slice
@@ -704,11 +689,8 @@ template <typename T> PairSlicing plan_pair_sliced(unsigned n, unsigned slices, 
     p.even     = (p.slices % 2) == 0;
     if (p.partners + 1 > static_cast<unsigned>(kMaxRecv) || p.partners + 1 > static_cast<unsigned>(kMaxSelfSets)) return PairSlicing{};
     p.plane = p.slice_bodies;  // (a multiple of 64 already)
-    auto splits = [&](unsigned units) {  // workgroups per block: fill the chip (~512 workgroups of 8 waves) while a wave keeps >= 2 units, then whole rounds
-        unsigned C = 1;
-        while (per * C * 2 <= chip && units >= C * 2 * static_cast<unsigned>(S) * 2) C *= 2;
-        C = splits_for_full_rounds(per, units, S, C);
-        if (ovr_c > 0) C = static_cast<unsigned>(ovr_c);
+    auto splits = [&](unsigned units) {  // workgroups per block: whole rounds of 256 workgroups (splits_to_fill)
+        unsigned C = ovr_c > 0 ? static_cast<unsigned>(ovr_c) : splits_to_fill(per, units, S, chip);
         while (C > 1 && units < C * static_cast<unsigned>(S)) C /= 2;
         return C;
     };

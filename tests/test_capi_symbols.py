@@ -425,11 +425,11 @@ def test_sliced_pairwise_plan_without_gpu(pkg):
         assert capped(1 << 20) == 0  # nothing fits one megabyte: the one-sided kernel
         assert capped(1 << 62) == big.workspace_bytes  # the device's third still binds
         # the formula of the sliced form, checked at a forced K on a size where everything is round: 262 144 bodies in 4 slices of
-        # 128 blocks: region max(63 diagonal slots, 128 rectangle planes) + per slice the self sets (C = 4 for the diagonal and the full
-        # rectangle, 8 for the split one as its higher partner runs it) + (1 + 2) received arrays
+        # 64 blocks of 1 024: region max(31 diagonal slots, 64 rectangle planes) + per slice the self sets (C = 4 for the diagonal and the
+        # full rectangle, 8 for the split one as its higher partner runs it) + (1 + 2) received arrays
         pkg.set_pair_slices_override(4)
         p = pkg.pair_plan(262144)
-        assert p.slices == 4 and p.workspace_bytes == (128 + 4 * ((4 + 4 + 8) + 3)) * 3 * 65536 * 4
+        assert p.slices == 4 and p.workspace_bytes == (64 + 4 * ((4 + 4 + 8) + 3)) * 3 * 65536 * 4
         assert capped(p.workspace_bytes - 1, 262144) == 0 and capped(p.workspace_bytes, 262144) == p.workspace_bytes
         pkg.set_pair_slices_override(0)
         assert lib.nb_set_pair_slices_override(16) == 10001 and lib.nb_set_pair_slices_override(-1) == 10001
