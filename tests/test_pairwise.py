@@ -386,8 +386,9 @@ def test_sliced_pairwise_4mi_bodies_in_16_gb(gpu, O):
 
 
 def test_pair_default_plan_at_awkward_body_counts(gpu, O):
-    """The automatic plan at body counts that are not powers of two (round 4: workgroups per block chosen so that the launch fills
-    whole rounds of resident workgroups -- C up to 16 --, ragged last blocks and tiles, odd and even block counts): sampled
+    """The automatic plan at body counts that are not powers of two (round 4: R and any C up to 16 chosen so that the launch fills
+    whole rounds of 256 workgroups -- 5, 7, 11, 13 and 15 workgroups per block among these sizes --, ragged last blocks and tiles,
+    odd and even block counts): sampled
     accelerations against the fp64 direct sum and the pairwise layout's built-in property, total momentum change = 0; and the same
     sizes through the bounded-workspace form with the fewest slices that fit a quarter of the full request."""
     import os
@@ -418,4 +419,4 @@ def test_pair_default_plan_at_awkward_body_counts(gpu, O):
             assert err.max() < 1e-5, (n, cap, err.max())
             total = np.abs(acc.sum(axis=0)).max() / np.abs(acc).sum(axis=0).max()
             assert total < 1e-6, (n, cap, total)
-    assert len(seen) >= 3, seen  # several values of C were exercised
+    assert len(seen) >= 6 and any(c > 1 and c % 2 for c in seen), seen  # many values of C were exercised, odd ones among them (any C up to 16 is a plan)
