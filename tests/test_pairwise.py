@@ -420,3 +420,55 @@ def test_pair_default_plan_at_awkward_body_counts(gpu, O):
             total = np.abs(acc.sum(axis=0)).max() / np.abs(acc).sum(axis=0).max()
             assert total < 1e-6, (n, cap, total)
     assert len(seen) >= 6 and any(c > 1 and c % 2 for c in seen), seen  # many values of C were exercised, odd ones among them (any C up to 16 is a plan)
+
+
+@pytest.mark.parametrize("seed", [11, 12])
+def test_pair_random_geometries_against_the_one_sided_kernel(gpu, seed):
+    """Seeded random cases over everything a plan may be -- R in {1, 2, 4, 8}, 4 / 8 / 12 / 16 waves, ANY number of workgroups per
+    block up to 16 (the automatic plan takes odd ones since round 4), one tournament or 2 ... 5 slices, fp32 and fp64, 1 ... 9 000 bodies,
+    equal / scaled / ramped / two-species / partly massless bodies: the accelerations of nb_integrate_ws_* against those of the
+    one-sided kernel (nb_integrate_*) on the same bodies, and no NaN anywhere.  (The one-sided kernel is held to the fp64 direct sum
+    in test_gpu_parity.py; this test is about indexing: every unit lands on a wave, every sum in its plane.)"""
+    rng = np.random.default_rng(seed)
+
+    def accel(pos, dtype, workspace):
+        n = pos.size // 4
+        s = gpu.BodySystemHIP(n, 256, gpu.NBodyParams(), dtype, pos.astype(dtype), np.zeros(4 * n, dtype), mode=gpu.NB_MODE_FAST, workspace=workspace)
+        s.update(dtype(1))
+        a = s.get_velocity().copy()
+        s.free()
+        return xyz(a).astype(np.float64)
+
+    ran_sliced = 0
+    try:
+        for case in range(70):
+            n = int(rng.integers(1, 9000)) if case % 3 else int(rng.integers(1, 400))
+            R, S, C = int(rng.choice([1, 2, 4, 8])), int(rng.choice([4, 8, 12, 16])), int(rng.integers(1, 17))
+            if R == 8 and S == 16:
+                S = 8  # (196 KB of LDS: not a launch)
+            slices = int(rng.integers(2, 6)) if case % 4 == 3 else 0
+            dtype = np.float32 if case % 5 else np.float64
+            pos = rng.uniform(-5, 5, size=(n, 4)).astype(np.float32)
+            kind = case % 6
+            pos[:, 3] = 2.5 if kind == 1 else 1.0
+            if kind == 2:
+                pos[:, 3] = rng.uniform(0.5, 2.0, n)
+            if kind == 3:
+                pos[n // 2:, 3] = 3.0
+            if kind == 4:
+                pos[rng.integers(0, n, max(1, n // 10)), 3] = 0.0
+            gpu.set_pair_plan_override(R, S, C, 1)
+            gpu.set_pair_slices_override(slices)
+            plan = gpu.pair_plan(n, dtype)
+            ran_sliced += plan.slices > 1
+            pairwise = accel(pos.ravel(), dtype, True)
+            gpu.set_pair_plan_override(0, 0, 0, 0)
+            gpu.set_pair_slices_override(0)
+            one_sided = accel(pos.ravel(), dtype, False)
+            assert np.isfinite(pairwise).all(), (case, n, (R, S, C), slices)
+            err = np.abs(pairwise - one_sided).max() / (np.abs(one_sided).max() + 1e-30)
+            assert err < (2e-5 if dtype == np.float32 else 1e-12), (case, n, (R, S, C), slices, np.dtype(dtype).name, kind, err, plan.applies)
+    finally:
+        gpu.set_pair_plan_override(0, 0, 0, 0)
+        gpu.set_pair_slices_override(0)
+    assert ran_sliced >= 5
