@@ -157,7 +157,12 @@ template <typename T> PairChoice choose_pair_layout(unsigned n, int mode, size_t
         }
         if (forced == 1) return c;
     }
-    for (unsigned k = forced > 1 ? static_cast<unsigned>(forced) : 2u; k <= (forced > 1 ? static_cast<unsigned>(forced) : 15u); ++k) {
+    // The fewest slices that fit -- tried as 2, 4, 8 first: a number of slices that is a power of two steps as fast as one
+    // tournament (1 Mi bodies in 2 / 4 / 8 slices: 157.7 / 158.5 / 158.6 ms against 158.3), any other count leaves ragged rounds
+    // of workgroups and costs 6-10 % (3 slices of 524 288 bodies 42.9 ms, 4 slices 39.8; profiles/round4_shard_plan_times.txt).
+    static constexpr unsigned kOrder[] = {2, 4, 8, 3, 5, 6, 7, 9, 10, 11, 12, 13, 14, 15};
+    for (unsigned k : kOrder) {
+        if (forced > 1 && k != static_cast<unsigned>(forced)) continue;
         const nb::PairSlicing sl = nb::plan_pair_sliced<T>(n, k, r, w, g);
         if (sl.slices < 2 || sl.workspace_bytes > limit) continue;
         c.slices = sl.slices, c.sliced = sl, c.bytes = sl.workspace_bytes;
