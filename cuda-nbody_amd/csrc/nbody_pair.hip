@@ -534,10 +534,9 @@ inline double resident_workgroups(int S) { return 256.0 * std::max(1, 8 / S); } 
 // The units the busiest SIMD of a workgroup works through (eight waves: SIMD s holds waves s and s + 4): U units dealt to C*S slots,
 // the first U mod (C*S) slots taking one more -- interleaved (slot = wave*C + c: the longer waves are the low wave ids of every
 // workgroup) or blocked (slot = c*S + wave: all the waves of the first workgroups), as launch_pair_tile decides.
-inline unsigned busiest_simd_units(unsigned U, unsigned C, int S, bool* interleave = nullptr) {
+inline unsigned busiest_simd_units(unsigned U, unsigned C, int S) {
     const unsigned slots = C * static_cast<unsigned>(S), base = U / slots, rem = U % slots;
     const bool     inter = C > 1 && rem != 0 && base < 34;  // (the rule of launch_pair_tile)
-    if (interleave) *interleave = inter;
     if (rem == 0) return 2 * base;
     const unsigned longer = (inter || C == 1) ? (rem + C - 1) / C : std::min(rem, static_cast<unsigned>(S));  // longer waves in the worst workgroup
     return 2 * base + (longer <= 4 ? 1u : 2u);
