@@ -144,7 +144,7 @@ def test_default_line_carries_every_baseline_config():
     assert roof["step_frac"] <= roof["frac"]
     if roof["chip"] is not None:  # (sysfs readable: the clock the chip ran at, and the fraction of what it could issue at THAT clock)
         assert 500 < roof["chip"]["sclk_mhz"] <= 2500 and roof["chip"]["samples"] >= 1
-        assert 0.98 * roof["step_frac"] <= roof["frac_at_delivered_clock"] < 1.05
+        assert 0.98 * roof["step_frac"] <= roof["frac_at_delivered_clock"] < 1.25  # (algorithmic flop: may pass 1, see frac_counts)
     # algorithmic HBM bytes are the bodies in and out; the workspace traffic is stated next to them
     assert roof["algorithmic_hbm_bytes_per_launch"] == 64 * 262144
     assert roof["workspace_rw_bytes_per_step"] == 2 * line["config"]["kernel_plan"]["workspace_bytes"]
