@@ -212,6 +212,10 @@ def other_configs(pkg, lib, headline):
         ("configs[0]'s system on the GPU", 1024, False, "fast", 2000),
         ("configs[0]'s system on the GPU", 1024, False, "strict", 500),
         ("small system", 16384, False, "fast", 1000),
+        # between the powers of two: the launch geometry (R, and any number of workgroups per block) comes from plan_pair's cost model
+        ("between the powers of two", 50000, False, "fast", 300),
+        ("between the powers of two", 100000, False, "fast", 100),
+        ("between the powers of two", 300000, False, "fast", 10),
         # beyond BASELINE's sizes: one tournament would want 206 GB of reaction slots; the tournament cut into slices inside 16 GB
         ("4 Mi bodies, workspace capped at 16 GB", 4194304, False, "fast", 2),
     ]

@@ -133,7 +133,8 @@ def test_default_line_carries_every_baseline_config():
     got = {(c["bodies"], c["dtype"], c["mode"], c["layout"]) for c in line["configs"]}
     assert {(65536, "f32", "fast", "pairwise"), (65536, "f32", "fast", "one-sided"), (262144, "f64", "fast", "pairwise"), (262144, "f64", "fast", "one-sided"),
             (1048576, "f32", "fast", "pairwise"), (1048576, "f32", "fast", "one-sided"), (262144, "f32", "strict", "strict"), (262144, "f64", "strict", "strict"),
-            (1024, "f32", "fast", "one-sided"), (1024, "f32", "strict", "strict"), (262144, "f32", "fast", "one-sided")} <= got
+            (1024, "f32", "fast", "one-sided"), (1024, "f32", "strict", "strict"), (262144, "f32", "fast", "one-sided"),
+            (50000, "f32", "fast", "pairwise"), (100000, "f32", "fast", "pairwise"), (300000, "f32", "fast", "pairwise")} <= got
     assert (262144, "f32", "fast", "pairwise") not in got  # that one IS the headline
     assert line["config"]["step_entry_point"] == "nb_integrate_ws_*" and line["config"]["kernel_plan"]["layout"] == "pairwise"
     roof = line["roofline"]
