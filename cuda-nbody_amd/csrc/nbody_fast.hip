@@ -656,13 +656,31 @@ template <typename T> Plan plan_fast(unsigned i_count, unsigned j_count, int cu_
     // (profiles/round2_plan_sweep.txt: 65 536 bodies 0.92 vs 0.94-0.97 ms, 32 768-body shard 0.246 vs 0.26-0.28 ms).
     const long blocks_at_i = (static_cast<long>(i_count) + 64L * I - 1) / (64L * I);
     int        S           = blocks_at_i <= 2L * cu_count ? 16 : 8;
-    // The wave-split layout has no such quantisation (its workgroups are 64-256x smaller) but runs at ~0.78 (fp32) /
-    // ~0.62 (fp64) of the tile layout's full rate (tools/layout_crossover.py): take it when the tile layout would
-    // fill the chip worse than that.
-    const double wave_split_eff = sizeof(T) == 4 ? 0.78 : 0.62;
-    if (best_eff < wave_split_eff) {
+    // The wave-split layout runs at ~0.78 (fp32) / ~0.62 (fp64) of the tile layout's full rate (tools/layout_crossover.py) and its
+    // workgroups are 4-16x smaller, so its last round is fuller -- but not full: round 4's sweep of 33 body counts
+    // (profiles/round4_one_sided_plan_sweep.txt) showed the old rule (wave-split whenever the tile layout fills under 0.78, two vectors
+    // per wave from 16 384 bodies) losing up to 45 %: 18 000 bodies as 282 workgroups of 64 bodies are two rounds for the work of
+    // 1.1; with one vector per wave they are 563 workgroups, 2.2 of 3.  Both layouts are now held to the same fill estimate --
+    // a launch costs ceil(workgroups / CUs) rounds (nbody_pair.hip) -- and the better one is taken.
+    const double wave_split_rate = sizeof(T) == 4 ? 0.78 : 0.62;
+    auto wave_split_block = [&](int vectors) {  // the largest workgroup that still leaves one per CU (as below)
+        for (int cand : {1024, 512}) {
+            if ((static_cast<long>(i_count) + cand / 64 * vectors - 1) / (cand / 64 * vectors) >= cu_count) return cand;
+        }
+        return 256;
+    };
+    auto wave_split_fill = [&](int vectors) {
+        const long   per    = wave_split_block(vectors) / 64 * vectors;
+        const long   blocks = (static_cast<long>(i_count) + per - 1) / per;
+        const long   rounds = (blocks + cu_count - 1) / cu_count;
+        return static_cast<double>(blocks) / static_cast<double>(rounds * cu_count);
+    };
+    int wave_split_i = W;  // 2 vectors per wave while that leaves >= 4 workgroups per CU and fills the rounds as well
+    if (static_cast<long>(i_count) / (4 * 2 * W) >= 4L * cu_count && wave_split_fill(2 * W) >= wave_split_fill(W) - 0.005) wave_split_i = 2 * W;
+    // (up to 8 192 bodies the wave-split layout always: the tile layout has under half a round of workgroups there)
+    if (i_count <= 8192 ? best_eff < wave_split_rate : best_eff < wave_split_rate * wave_split_fill(wave_split_i)) {
         S = kWaveSplit;
-        I = (static_cast<long>(i_count) / (4 * 2 * W) >= 4L * cu_count) ? 2 * W : W;  // 2 vectors per wave while that leaves >= 4 workgroups per CU
+        I = wave_split_i;
     }
     if (ovr_i > 0) I = std::min(std::max(ovr_i / W * W, W), kMaxI);
     if (ovr_s > 0) S = ovr_s;
@@ -671,7 +689,8 @@ template <typename T> Plan plan_fast(unsigned i_count, unsigned j_count, int cu_
         Plan p;
         p.bodies_per_lane = I;  // per WAVE in this layout
         p.lanes_per_body  = kWaveSplit;
-        p.tile_bodies     = (ovr_tile == 512 || ovr_tile == 1024) ? ovr_tile : (j_count > 512 ? 1024 : 512);
+        // (fp64: 512 bodies j per tile -- 32 KB of LDS instead of 64 -- was the better tile at every size of round 4's sweep, by 3-8 %)
+        p.tile_bodies     = (ovr_tile == 512 || ovr_tile == 1024) ? ovr_tile : ((j_count > 512 && sizeof(T) == 4) ? 1024 : 512);
         // the largest workgroup that still leaves one per CU: a tile is staged once per workgroup whatever its size, so bigger
         // workgroups mean less L2 traffic (-4 ... -8 % at 4 096 ... 16 384 bodies, profiles/round2_wavesplit_experiments.txt)
         p.block_threads = 256;
@@ -688,6 +707,7 @@ template <typename T> Plan plan_fast(unsigned i_count, unsigned j_count, int cu_
     }
     const int block = block_threads_for(S);
     int       tile  = 128 * S;
+    if (S == 8 && j_count >= 2048) tile = 2048;  // 256 bodies j per wave and chunk: 1-3 % over 128 at every size of round 4's sweep (262 144 bodies 14.72 -> 14.58 ms)
     if (ovr_tile > 0) tile = ovr_tile;
     if (tile < block) tile = block;
 

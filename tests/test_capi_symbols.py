@@ -79,10 +79,10 @@ def test_launch_plan_heuristics_without_gpu(pkg):
         return p.bodies_per_lane, p.lanes_per_body, p.tile_bodies, p.block_threads, p.grid_blocks
 
     # full-size fp32 systems: 8 waves per 512-thread workgroup (two workgroups per CU), 4 bodies (2 packed pairs) per lane,
-    # 128 bodies j per wave and chunk
-    assert plan(262144, 262144) == (4, 8, 1024, 512, 1024)
+    # 256 bodies j per wave and chunk (round 4: 1-3 % over 128 at every size of the sweep)
+    assert plan(262144, 262144) == (4, 8, 2048, 512, 1024)
     assert plan(65536, 65536) == (4, 16, 2048, 1024, 256)  # one workgroup per CU: 1024 threads, so that every SIMD still holds four waves
-    assert plan(1048576, 1048576) == (4, 8, 1024, 512, 4096)
+    assert plan(1048576, 1048576) == (4, 8, 2048, 512, 4096)
     # strong-scaling shards of 262 144 bodies on 2 / 4 / 8 GPUs keep whole rounds of 256 workgroups
     assert plan(131072, 262144)[:2] + plan(131072, 262144)[4:] == (4, 16, 512)
     assert plan(65536, 262144)[:2] + plan(65536, 262144)[4:] == (4, 16, 256)
@@ -91,8 +91,12 @@ def test_launch_plan_heuristics_without_gpu(pkg):
     for n, block in ((1, 256), (1024, 256), (2048, 256), (4096, 512), (8192, 1024), (16384, 1024), (40960, 1024)):
         assert plan(n, n)[1] == 64 and plan(n, n)[3] == block, (n, plan(n, n))
         assert plan(n, n)[4] == -(-n // (plan(n, n)[0] * block // 64))
+    # between the powers of two both layouts are held to the same estimate -- a launch costs ceil(workgroups / 256) rounds -- (round 4:
+    # the rule before lost up to 45 %): 18 000 bodies are 563 wave-split workgroups of 32 bodies (282 of 64 would be two rounds for
+    # the work of 1.1), 50 000 bodies 196 tile-layout workgroups (782 wave-split ones would be four rounds for the work of 3.05)
+    assert plan(18000, 18000) == (2, 64, 1024, 1024, 563) and plan(50000, 50000)[:2] == (4, 16) and plan(50000, 50000)[4] == 196
     # fp64: one body per vector, up to 4 per lane
-    assert plan(262144, 262144, np.float64) == (4, 8, 1024, 512, 1024)
+    assert plan(262144, 262144, np.float64) == (4, 8, 2048, 512, 1024)
     assert plan(1024, 1024, np.float64)[1] == 64
     # overrides are validated and reversible
     pkg.set_plan_override(2, 4, 512)
