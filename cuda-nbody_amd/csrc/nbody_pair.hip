@@ -556,11 +556,13 @@ inline unsigned busiest_simd_units(unsigned U, unsigned C, int S) {
 // rounds: 50 000 bodies are 49 blocks of 1 024 -- x 5 = 245 workgroups, one round (0.67 -> 0.80 of the peak); 33 000 bodies
 // 0.59 -> 0.71.  Only the ratios of the constants matter (box clocks differ).
 template <typename T> struct PairCost;
-template <> struct PairCost<float> {
-    static constexpr double unit[3] = {4.53, 9.17, 17.72}, wg[3] = {0.0, 1.45, 6.86}, slot = 14.1;
+template <> struct PairCost<float> {  // by R = 1, 2, 4, 8
+    // (R = 1 -- two bodies i per lane, 25 instructions for 4 pair evaluations -- pays only where nothing else fills a round: 8 500-10 000
+    // bodies, three workgroups per block of 128 bodies, 32 us against 40; its constant is from those sizes alone)
+    static constexpr double unit[4] = {2.2, 4.53, 9.17, 17.72}, wg[4] = {0.0, 0.0, 1.45, 6.86}, slot = 14.1;
 };
 template <> struct PairCost<double> {
-    static constexpr double unit[3] = {5.12, 10.39, 20.72}, wg[3] = {0.0, 0.0, 0.0}, slot = 21.9;  // (the sweep does not resolve wg: fitted freely it comes out negative)
+    static constexpr double unit[4] = {0.0, 5.12, 10.39, 20.72}, wg[4] = {0.0, 0.0, 0.0, 0.0}, slot = 21.9;  // (unit 0: not a candidate; the sweep does not resolve wg: fitted freely it comes out negative)
 };
 
 template <typename T> PairPlan plan_pair(unsigned n, int cu_count, int ovr_r, int ovr_s, int ovr_c) {
@@ -592,14 +594,15 @@ template <typename T> PairPlan plan_pair(unsigned n, int cu_count, int ovr_r, in
     PairPlan best{};
     double   best_cost = 0;
     for (int R : {1, 2, 4, 8}) {  // (near-ties go to the smaller R -- 32 768 bodies: R = 4, C = 4 178 us, R = 8, C = 8 184 us -- and the smaller C)
-        if (fixed_r ? R != ovr_r : R == 1) continue;  // (R = 1 through the override only: 25 instructions for 4 pair evaluations)
+        const int k = R == 1 ? 0 : (R == 2 ? 1 : (R == 4 ? 2 : 3));
+        if (fixed_r ? R != ovr_r : PairCost<T>::unit[k] == 0.0) continue;
         for (unsigned C = 1; C <= 16; ++C) {  // (any C, not only powers of two: 50 000 bodies are 49 blocks of 1 024 -- x 5 = 245 workgroups, one round)
             const PairPlan p = ovr_c > 0 ? with_units(R, static_cast<unsigned>(ovr_c)) : geometry(R, C);
             const unsigned U = units_of(p);
             if (ovr_c <= 0 && C > 1 && U < 2 * C * static_cast<unsigned>(S)) continue;  // every wave at least two units (a workgroup's set-up and fold cost about one)
             const double rounds = std::ceil(p.grid_blocks / resident_workgroups(S));
-            const int    k      = R <= 2 ? 0 : (R == 4 ? 1 : 2);
-            const double cost   = rounds * (busiest_simd_units(U, p.splits, S) * PairCost<T>::unit[k] * (R == 1 ? 0.61 : 1.0) + PairCost<T>::wg[k]) +
+            const double unit   = PairCost<T>::unit[k] > 0.0 ? PairCost<T>::unit[k] : 0.5 * PairCost<T>::unit[1];  // (an R the search would not take, forced by the override)
+            const double cost   = rounds * (busiest_simd_units(U, p.splits, S) * unit + PairCost<T>::wg[k]) +
                                 PairCost<T>::slot * 1e-6 * static_cast<double>(n) * (p.slots + p.splits);
             if (best.blocks == 0 || cost < 0.995 * best_cost) best = p, best_cost = cost;
             if (ovr_c > 0) break;

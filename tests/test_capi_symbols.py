@@ -221,7 +221,8 @@ def test_pair_plan_heuristics_without_gpu(pkg):
     assert plan(8192)[0] == 0 and plan(10240)[0] == 1
     assert plan(262144, np.float64) == (1, 8, 8, 1, 512)
     assert plan(4096, np.float64)[0] == 0 and plan(6144, np.float64)[0] == 1
-    assert plan(600, np.float32)[4] == 3 and plan(64, np.float32)[4] == 1  # odd block counts, a single block
+    assert plan(600, np.float32)[4] == 5 and plan(64, np.float32)[4] == 1  # odd block counts (blocks of 128 bodies: R = 1), a single block
+    assert plan(9000) == (1, 2, 8, 3, 71)          # 8 200-10 500 bodies: two bodies i per lane, three workgroups per block of 128: 213 workgroups, one round
     need = ctypes.c_size_t(7)
     lib = pkg.lib()
     assert lib.nb_workspace_bytes_f32(262144, pkg.NB_MODE_FAST, ctypes.byref(need)) == 0 and need.value == 128 * 3 * 262144 * 4
@@ -487,7 +488,7 @@ def test_pair_plan_fills_whole_rounds_at_any_body_count(pkg):
             p = pkg.pair_plan(n, dtype)
             if not p.applies:
                 continue
-            assert p.waves_per_block == 8 and 1 <= p.splits <= 16 and p.bodies_per_lane // W in (2, 4, 8), (n, p.bodies_per_lane, p.splits)
+            assert p.waves_per_block == 8 and 1 <= p.splits <= 16 and p.bodies_per_lane // W in ((1, 2, 4, 8) if W == 2 else (2, 4, 8)), (n, p.bodies_per_lane, p.splits)
             units = (p.blocks // 2 + 1) * p.bodies_per_lane
             assert p.splits == 1 or units >= 2 * p.splits * 8, (n, units, p.splits)
             rounds = p.grid_blocks / 256
