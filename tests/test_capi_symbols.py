@@ -220,7 +220,7 @@ def test_pair_plan_heuristics_without_gpu(pkg):
     assert plan(16384) == (1, 4, 8, 4, 64)         # small systems: half the bodies per lane, twice the blocks
     assert plan(8192)[0] == 0 and plan(10240)[0] == 1
     assert plan(262144, np.float64) == (1, 8, 8, 1, 512)
-    assert plan(4096, np.float64)[0] == 0 and plan(6144, np.float64)[0] == 1
+    assert plan(4096, np.float64)[0] == 0 and plan(6144, np.float64)[0] == 0 and plan(6145, np.float64)[0] == 1
     assert plan(600, np.float32)[4] == 5 and plan(64, np.float32)[4] == 1  # odd block counts (blocks of 128 bodies: R = 1), a single block
     assert plan(9000) == (1, 2, 8, 3, 71)          # 8 200-10 500 bodies: two bodies i per lane, three workgroups per block of 128: 213 workgroups, one round
     need = ctypes.c_size_t(7)

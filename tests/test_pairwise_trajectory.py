@@ -4,7 +4,7 @@ tests/test_gpu_parity.py.  The reference's own acceptance check compares the GPU
 after stepping both from one state (/root/reference/src/nbody/compute_cuda.cpp:294-333); the arithmetic being compared with is
 BodySystemCPU<T>::update (bodysystemcpu.cpp:149-243 fp32, :245-299 fp64) as restated in oracle/nbody_oracle.c.
 
-The layout applies by default above 8 192 bodies (fp32) / from 6 144 (fp64), and the committed full trajectories stop at
+The layout applies by default above 8 192 bodies (fp32) / above 6 144 (fp64), and the committed full trajectories stop at
 4 096 bodies, so: (a) the layout is FORCED at the golden sizes, in every compiled geometry (nb_set_pair_plan_override with
 min_bodies = 1); (b) a fixture at 16 384 bodies, where the layout applies by itself, pins the default plan; (c) the
 fp64-truth and conservation checks of the one-sided kernel run here through nb_integrate_ws_* too.  (BASELINE sizes: the FAST half
