@@ -656,29 +656,39 @@ template <typename T> Plan plan_fast(unsigned i_count, unsigned j_count, int cu_
     // (profiles/round2_plan_sweep.txt: 65 536 bodies 0.92 vs 0.94-0.97 ms, 32 768-body shard 0.246 vs 0.26-0.28 ms).
     const long blocks_at_i = (static_cast<long>(i_count) + 64L * I - 1) / (64L * I);
     int        S           = blocks_at_i <= 2L * cu_count ? 16 : 8;
-    // The wave-split layout runs at ~0.78 (fp32) / ~0.62 (fp64) of the tile layout's full rate (tools/layout_crossover.py) and its
+    // The wave-split layout runs at ~0.8 of the tile layout's full rate (round 2: 0.78 fp32 / 0.62 fp64, tools/layout_crossover.py; fp64 caught up with tiles of 512 bodies) and its
     // workgroups are 4-16x smaller, so its last round is fuller -- but not full: round 4's sweep of 33 body counts
     // (profiles/round4_one_sided_plan_sweep.txt) showed the old rule (wave-split whenever the tile layout fills under 0.78, two vectors
     // per wave from 16 384 bodies) losing up to 45 %: 18 000 bodies as 282 workgroups of 64 bodies are two rounds for the work of
     // 1.1; with one vector per wave they are 563 workgroups, 2.2 of 3.  Both layouts are now held to the same fill estimate --
     // a launch costs ceil(workgroups / CUs) rounds (nbody_pair.hip) -- and the better one is taken.
-    const double wave_split_rate = sizeof(T) == 4 ? 0.78 : 0.62;
-    auto wave_split_block = [&](int vectors) {  // the largest workgroup that still leaves one per CU (as below)
-        for (int cand : {1024, 512}) {
-            if ((static_cast<long>(i_count) + cand / 64 * vectors - 1) / (cand / 64 * vectors) >= cu_count) return cand;
+    // (round 4, both precisions: 32 768 bodies fp32 0.244 against 0.300 ms, 16 384 bodies fp64 145 against 178 us with tiles of 512 bodies; past 40 000
+    // bodies every one of thousands of workgroups staging every tile starts to show: 50 000 bodies fp64 1.70 against 1.64 ms at equal estimates)
+    const double wave_split_rate = i_count > 40000 ? 0.76 : 0.80;
+    // Wave-split geometry: a wave takes `vectors` bodies i, a workgroup of b waves b * vectors.  The layout is issue-bound from 16
+    // waves per CU on, so a launch costs max over CUs of (waves on it) x vectors = ceil(workgroups / CUs) x b x vectors: 8 193
+    // bodies as 257 workgroups of 16 waves put 32 waves on one CU (41.0 us against 23.4 for 8 192 bodies), as 1 025 workgroups of 4
+    // waves 20 (30.5 us).  Smaller workgroups stage every tile more often (+2 % at 8 waves, +6 % at 4: L2 traffic); two vectors per
+    // wave are 2.5 % cheaper per body from 16 384 bodies (8 192 fp64).  (profiles/round4_one_sided_plan_sweep.txt, part 2.)
+    const int  wave_split_tile = (j_count > 512 && sizeof(T) == 4) ? 1024 : 512;  // (fp64: 512 bodies j -- 32 KB of LDS instead of 64 -- by 3-8 % at every size)
+    const bool two_vectors_ok  = static_cast<long>(i_count) / (4 * 2 * W) >= 4L * cu_count;
+    int        wave_split_i = W, wave_split_block = 256;
+    double     wave_split_cost = 0;
+    for (int vectors : {W, 2 * W}) {
+        if (vectors != W && !two_vectors_ok) continue;
+        for (int block : {1024, 512, 256}) {
+            if (wave_split_tile % block) continue;
+            if (block == 256 && i_count > 20480) continue;  // (every workgroup stages every tile: the traffic of four-wave workgroups was measured up to 20 000 bodies only)
+            const long   per    = block / 64 * vectors;
+            const long   blocks = (static_cast<long>(i_count) + per - 1) / per;
+            const long   rounds = (blocks + cu_count - 1) / cu_count;
+            const double cost   = static_cast<double>(rounds * per) * (vectors == W ? 1.0 : 0.975) * (block == 1024 ? 1.0 : (block == 512 ? 1.02 : (sizeof(T) == 4 ? 1.06 : 1.08)));
+            if (wave_split_cost == 0 || cost < wave_split_cost) wave_split_cost = cost, wave_split_i = vectors, wave_split_block = block;
         }
-        return 256;
-    };
-    auto wave_split_fill = [&](int vectors) {
-        const long   per    = wave_split_block(vectors) / 64 * vectors;
-        const long   blocks = (static_cast<long>(i_count) + per - 1) / per;
-        const long   rounds = (blocks + cu_count - 1) / cu_count;
-        return static_cast<double>(blocks) / static_cast<double>(rounds * cu_count);
-    };
-    int wave_split_i = W;  // 2 vectors per wave while that leaves >= 4 workgroups per CU and fills the rounds as well
-    if (static_cast<long>(i_count) / (4 * 2 * W) >= 4L * cu_count && wave_split_fill(2 * W) >= wave_split_fill(W) - 0.005) wave_split_i = 2 * W;
+    }
+    const double wave_split_fill = static_cast<double>(i_count) / cu_count / wave_split_cost;  // bodies per CU over what the busiest CU is charged
     // (up to 8 192 bodies the wave-split layout always: the tile layout has under half a round of workgroups there)
-    if (i_count <= 8192 ? best_eff < wave_split_rate : best_eff < wave_split_rate * wave_split_fill(wave_split_i)) {
+    if (i_count <= 8192 ? best_eff < wave_split_rate : best_eff < wave_split_rate * wave_split_fill) {
         S = kWaveSplit;
         I = wave_split_i;
     }
@@ -689,15 +699,17 @@ template <typename T> Plan plan_fast(unsigned i_count, unsigned j_count, int cu_
         Plan p;
         p.bodies_per_lane = I;  // per WAVE in this layout
         p.lanes_per_body  = kWaveSplit;
-        // (fp64: 512 bodies j per tile -- 32 KB of LDS instead of 64 -- was the better tile at every size of round 4's sweep, by 3-8 %)
-        p.tile_bodies     = (ovr_tile == 512 || ovr_tile == 1024) ? ovr_tile : ((j_count > 512 && sizeof(T) == 4) ? 1024 : 512);
-        // the largest workgroup that still leaves one per CU: a tile is staged once per workgroup whatever its size, so bigger
-        // workgroups mean less L2 traffic (-4 ... -8 % at 4 096 ... 16 384 bodies, profiles/round2_wavesplit_experiments.txt)
+        p.tile_bodies     = (ovr_tile == 512 || ovr_tile == 1024) ? ovr_tile : wave_split_tile;
+        // the workgroup size of the search above; with an override (another I or tile): the largest workgroup that still leaves one per CU
         p.block_threads = 256;
-        for (int cand : {1024, 512}) {
-            if (p.tile_bodies % cand == 0 && (static_cast<long>(i_count) + cand / 64 * I - 1) / (cand / 64 * I) >= cu_count) {
-                p.block_threads = cand;
-                break;
+        if (I == wave_split_i && p.tile_bodies == wave_split_tile) {
+            p.block_threads = wave_split_block;
+        } else {
+            for (int cand : {1024, 512}) {
+                if (p.tile_bodies % cand == 0 && (static_cast<long>(i_count) + cand / 64 * I - 1) / (cand / 64 * I) >= cu_count) {
+                    p.block_threads = cand;
+                    break;
+                }
             }
         }
         const unsigned bodies_per_block = static_cast<unsigned>(p.block_threads / 64 * I);

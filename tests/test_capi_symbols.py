@@ -87,14 +87,16 @@ def test_launch_plan_heuristics_without_gpu(pkg):
     assert plan(131072, 262144)[:2] + plan(131072, 262144)[4:] == (4, 16, 512)
     assert plan(65536, 262144)[:2] + plan(65536, 262144)[4:] == (4, 16, 256)
     assert plan(32768, 262144)[:2] + plan(32768, 262144)[4:] == (2, 16, 256)
-    # small or awkward sizes: wave-split layout (lanes_per_body == 64); the largest workgroup that still leaves one per CU
-    for n, block in ((1, 256), (1024, 256), (2048, 256), (4096, 512), (8192, 1024), (16384, 1024), (40960, 1024)):
+    # small or awkward sizes: wave-split layout (lanes_per_body == 64).  Its launch costs max over CUs of the waves on it (round 4):
+    # whole rounds of 16-wave workgroups where the bodies allow (8 192 bodies = 256 workgroups of 32), smaller workgroups where one
+    # more 16-wave workgroup would put 32 waves on a CU (8 193 bodies: 1 025 workgroups of 4 waves, 30 us instead of 41)
+    for n, block in ((1, 256), (1024, 256), (2048, 256), (4096, 512), (8192, 1024), (8193, 256), (12000, 512), (16384, 1024), (40960, 512)):
         assert plan(n, n)[1] == 64 and plan(n, n)[3] == block, (n, plan(n, n))
         assert plan(n, n)[4] == -(-n // (plan(n, n)[0] * block // 64))
-    # between the powers of two both layouts are held to the same estimate -- a launch costs ceil(workgroups / 256) rounds -- (round 4:
-    # the rule before lost up to 45 %): 18 000 bodies are 563 wave-split workgroups of 32 bodies (282 of 64 would be two rounds for
-    # the work of 1.1), 50 000 bodies 196 tile-layout workgroups (782 wave-split ones would be four rounds for the work of 3.05)
-    assert plan(18000, 18000) == (2, 64, 1024, 1024, 563) and plan(50000, 50000)[:2] == (4, 16) and plan(50000, 50000)[4] == 196
+    # between the powers of two both layouts are held to the same estimate (round 4: the rule before lost up to 45 %): 18 000 bodies
+    # are 2 250 wave-split workgroups of 8 bodies, 50 000 bodies 196 tile-layout workgroups of 256 (782 wave-split ones of 64
+    # would be four rounds for the work of 3.05)
+    assert plan(18000, 18000) == (2, 64, 1024, 256, 2250) and plan(50000, 50000)[:2] == (4, 16) and plan(50000, 50000)[4] == 196
     # fp64: one body per vector, up to 4 per lane
     assert plan(262144, 262144, np.float64) == (4, 8, 2048, 512, 1024)
     assert plan(1024, 1024, np.float64)[1] == 64
