@@ -3,7 +3,8 @@
 #     gpurun --timeout 1100 -- 'bash tools/gpu_evidence.sh gpurun_out/r4'
 # (1) the GPU test suite, (2) smoke, (3) the default bench line and the one-sided one, (4) rocprofv3 kernel trace + the separate
 # PMC passes (tools/profile.sh) of every BASELINE size through the bench command itself.  Afterwards, here:
-#     python tools/summarize_prof.py gpurun_out/r4/f32 profiles/round4_n262144_f32_pairwise pair_forces      (and so on per size)
+#     python tools/summarize_prof.py gpurun_out/r4/f32 profiles/round4_n262144_f32_pairwise pair_forces      (and so on per size;
+#     one_sided -> profiles/roundN_n262144_f32 integrate_bodies, strict -> ..._strict integrate_bodies_strict)
 # Steps are joined so that a GPU step that fails or times out stops the run (never start GPU work after a timeout).
 set -o pipefail
 OUT=${1:-gpurun_out/evidence}
@@ -19,4 +20,6 @@ run_prof n65536 --steps 200 --warmup 10 --bodies 65536 &&
 run_prof n16384 --steps 400 --warmup 20 --bodies 16384 &&
 run_prof f64 --steps 8 --warmup 2 --fp64 &&
 run_prof n1m --steps 4 --warmup 1 --bodies 1048576 &&
-run_prof strict --steps 8 --warmup 2 --mode strict
+run_prof strict --steps 8 --warmup 2 --mode strict &&
+run_prof n50000 --steps 200 --warmup 10 --bodies 50000 &&
+run_prof one_sided --steps 20 --warmup 3 --layout one-sided
