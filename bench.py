@@ -383,7 +383,9 @@ def main():
             torch.cuda.synchronize()
 
     # ------------------------------------------------------------------------------------------------ the timed region
-    chip = ChipWatch(None if args.no_chip_watch or rank != 0 else pci_address(torch, local_rank))  # (a child process reading two sysfs files; see bench_support.ChipWatch)
+    # (a child process per rank reading two sysfs files of the rank's own card; see bench_support.ChipWatch.  Rank 0's goes into `roofline`,
+    # every rank's into `ranks_seen`: on a multi-GPU node the cards need not be granted the same clock)
+    chip = ChipWatch(None if args.no_chip_watch else pci_address(torch, local_rank))
     for _ in range(args.warmup):
         step()
     fence()
@@ -493,6 +495,7 @@ def main():
             roofline["frac_at_delivered_clock"] = roofline["step_frac"] * ChipWatch.PEAK_CLOCK_MHZ / roofline["chip"]["sclk_mhz"]
             if world == 1 and roofline["chip"]["socket_power_w"]:
                 roofline["chip"]["interactions_per_joule"] = value / roofline["chip"]["socket_power_w"]
+        chip_summary = roofline["chip"]
         line = {
             "metric": "body-body interactions/s, all-pairs N-body step (reference convention N^2 per step)",
             "value": value,
@@ -581,8 +584,10 @@ def main():
         extra = {}
         try:
             seen = [None] * world
+            clock = chip_summary if rank == 0 else chip.summary()  # (this rank's card while the headline was timed)
+            clock = None if clock is None else {k: clock[k] for k in ("sclk_mhz", "sclk_mhz_min", "socket_power_w", "samples")}
             dist.all_gather_object(seen, dict(capi_rank.info(), pairwise=capi_rank.pairwise(), one_group=capi_rank.exchange_grouping(), workspace_bytes=work_bytes,
-                                              cuda_device=torch.cuda.current_device()) if capi_rank is not None else {"rank": rank, "path": "sharded.py"})
+                                              cuda_device=torch.cuda.current_device(), chip=clock) if capi_rank is not None else {"rank": rank, "path": "sharded.py", "chip": clock})
             extra["ranks_seen"] = seen
             if not args.no_diagnostics:
                 extra["diagnostics"] = multi_gpu_diagnostics(pkg, lib, dist, torch, args, capi_rank, system, sharded, launch, fence, step, finish, lend, stream_ptr,

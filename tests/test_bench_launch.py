@@ -194,6 +194,7 @@ def test_n_rank_line_rehearsed_on_one_gpu_through_the_capi(ranks):
     assert line["config"]["exchange_grouping"].startswith("one RCCL group for all")
     seen = line["ranks_seen"]
     assert [r["rank"] for r in seen] == list(range(ranks)) and all(r["world"] == ranks and r["pairwise"] and r["one_group"] and r["workspace_bytes"] > 0 for r in seen)
+    assert all("chip" in r for r in seen)  # (every rank's own card: clock and power while the headline was timed; None where sysfs says nothing)
     diag = line["diagnostics"]
     assert set(diag["step_ms"]) == {"pairwise_one_group", "pairwise_group_per_round", "one_sided_one_group", "one_sided_group_per_round"} and diag["headline_was"] == "pairwise_one_group"
     assert all(v > 0 for v in diag["step_ms"].values())
