@@ -478,7 +478,7 @@ def test_makefile_rebuilds_an_object_when_any_header_it_includes_changes():
 def test_pair_plan_fills_whole_rounds_at_any_body_count(pkg):
     """The geometry search of plan_pair (csrc/nbody_pair.hip): a launch of eight-wave workgroups costs ceil(grid / 256) rounds, so
     at ANY body count the plan must not leave much of its last round empty (the fixed table it replaces put 284 workgroups on
-    256 CUs at 36 000 bodies: two rounds for the work of 1.1), must give every wave of a shared block at least two units, and must
+    256 CUs at 36 000 bodies: two rounds for the work of 1.1 -- the sample here never fills its last round under 0.88), must give every wave of a shared block at least two units, and must
     keep the choices measured at the powers of two.  Pure host logic."""
     import numpy as np
 
@@ -496,8 +496,8 @@ def test_pair_plan_fills_whole_rounds_at_any_body_count(pkg):
             rounds = p.grid_blocks / 256
             fill = rounds / -(-p.grid_blocks // 256)
             if p.grid_blocks > 256:
-                assert fill >= 0.80, (n, dtype.__name__, p.bodies_per_lane, p.splits, p.blocks, fill)
+                assert fill >= 0.88, (n, dtype.__name__, p.bodies_per_lane, p.splits, p.blocks, fill)
                 worst[dtype.__name__] = min(worst.get(dtype.__name__, 1.0), fill)
             if n >= 200000:
                 assert p.bodies_per_lane // W == 8, (n, p.bodies_per_lane)  # large systems: sixteen (eight) bodies i per lane
-    assert worst["float32"] >= 0.80 and worst["float64"] >= 0.80
+    assert worst["float32"] >= 0.88 and worst["float64"] >= 0.88
