@@ -71,14 +71,14 @@ def read(name):
 end = time.time() + 900
 with open(out, "a", buffering=1) as fh:
     while os.getppid() == parent and time.time() < end:
-        fh.write("%.6f %s %s\n" % (time.time(), read("freq1_input") or "-", read("power1_input") or "-"))
+        fh.write("%.6f %s %s\n" % (time.time(), read("freq1_input") or "-", read("power1_input") or read("power1_average") or "-"))
         time.sleep(0.025)
 """
 
 
 class ChipWatch:
     """The chip's shader clock and socket power WHILE the timed region runs, read from the amdgpu driver's sysfs files of the card
-    with this device's PCI address (hwmon freq1_input / power1_input; an ordinary user may read them).  Why it is in the line: the
+    with this device's PCI address (hwmon freq1_input / power1_input, or power1_average where the driver names it so; an ordinary user may read them).  Why it is in the line: the
     pairwise kernel keeps the vector ALUs ~97 % busy and the socket sits at its power cap (measured: 1 337-1 354 W of 1 400 W), so
     the clock the power management grants -- 2.04 ... 2.29 GHz by box, against the 2.4 GHz the peak is computed at -- decides
     `roofline.frac` between 0.85 and 0.93 for the same binary.
