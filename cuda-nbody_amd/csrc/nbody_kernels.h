@@ -78,6 +78,17 @@ inline unsigned splits_to_fill(unsigned blocks, unsigned units_per_block, int wa
     return 1;
 }
 
+// LDS of one pair_forces workgroup: the waves' second-level sums / the fold buffer, the progress words, and -- when the units left
+// over after an equal deal are run as quarters (PairArgs::deal == 2) -- the quarters' sums of the workgroup's tail units.
+inline constexpr unsigned kPairLdsLimit = 160u * 1024u;
+inline unsigned pair_tail_units(unsigned units, unsigned splits, int waves) {  // tail units of the busiest workgroup of a block
+    const unsigned rem = units % (splits * static_cast<unsigned>(waves));
+    return (rem + splits - 1) / splits;
+}
+inline unsigned pair_lds_bytes(int vectors_per_lane, int lane_width, int waves, unsigned element_bytes, unsigned tail_units) {
+    return static_cast<unsigned>(static_cast<size_t>(waves) * 3 * vectors_per_lane * lane_width * 64 * element_bytes) + 256u + tail_units * 4u * 3u * 64u * element_bytes;
+}
+
 struct PairGeom {
     int      vectors_per_lane;  // R
     int      waves;             // S
@@ -115,7 +126,8 @@ template <typename T> struct PairArgs {
     unsigned blocks;        // NB = ceil(i_count / (64*I))
     unsigned splits;        // C workgroups per block
     unsigned diag, keep;
-    unsigned interleave;    // unit -> wave map: 0: workgroup c of a block takes slots c*S .. c*S+S-1, 1: slot = wave * C + c (set by launch_pair_tile)
+    unsigned deal;          // how the units reach the waves (set by launch_pair_tile; see pair_forces): 0 whole units, slots blocked; 1 whole units, slots
+                            // interleaved; 2 whole units in equal numbers and the units left over as quarters, one per SIMD of one workgroup
     unsigned self_first, self_origin, self_plane;
     unsigned react_origin, react_plane;
     T        eps2;

@@ -208,12 +208,29 @@ template <typename T, int R, int S> __global__ __launch_bounds__(64 * S) __attri
     const unsigned j_end   = s.j_begin + s.j_count;
     const unsigned n_units = diag ? (Q + 1) * TB : (s.j_count + 63) / 64;
     const unsigned G       = s.splits * S;
-    // Which units are this wave's: unit u belongs to slot u mod (C*S).  Blocked (slot = c*S + wave): a workgroup takes consecutive
-    // units.  Interleaved (slot = wave*C + c): when the units do not divide evenly -- 528 over 32 waves at 65 536 bodies -- the waves
-    // with one unit more are the low wave ids of EVERY workgroup, one or two per SIMD, instead of all the waves of the first workgroups
-    // (65 536 bodies 653 -> 634 us, 98 304 bodies 1 566 -> 1 494 us, same box); where the remainder is under 3 % of a wave's units the
-    // blocked map is kept (196 608 bodies: 5.60 against 5.70 ms).  launch_pair_tile decides.
-    const unsigned g       = s.interleave ? static_cast<unsigned>(wave) * s.splits + c : c * S + static_cast<unsigned>(wave);
+    // Which units are this wave's.  s.deal == 2 (what launch_pair_tile takes when the LDS allows): the first floor(n_units / (C*S)) * C*S
+    // units are dealt whole, unit u to slot u mod (C*S) = c*S + wave -- every wave the same number --, and each of the units left over
+    // (the "tail": fewer than C*S) goes to ONE workgroup (tail unit t to workgroup t mod C) which runs it as FOUR QUARTERS of sixteen
+    // rotation steps, one per SIMD (quarter p on a wave with wave % 4 == p, the workgroup's tail units taking turns between the
+    // S/4 waves of a SIMD): a quarter's lanes load the tile rotated by 16p lanes, so that sixteen steps bring lane l exactly the
+    // bodies that the steps 16p .. 16p+15 of a whole unit would have, and the four partial reaction sums of a body meet in LDS
+    // (fixed order) before one store.  Every SIMD of a block's workgroups then carries the same load to a quarter of a unit:
+    // 16 384 bodies are 33 units per 8-wave workgroup -- 8.25 per SIMD instead of 9 for the one that held the wave with five.
+    // s.deal == 0 / 1: every unit whole, unit u to slot u mod (C*S), the slots blocked (c*S + wave) or interleaved (wave*C + c: the
+    // waves with one unit more are the low wave ids of EVERY workgroup; round 4's first answer to the remainder, kept for launches
+    // whose LDS has no room for the quarters' sums).
+    const bool     quartered = s.deal == 2;
+    const unsigned g         = s.deal == 1 ? static_cast<unsigned>(wave) * s.splits + c : c * S + static_cast<unsigned>(wave);
+    const unsigned dealt     = quartered ? n_units / G * G : n_units;                                   // units below this are dealt whole
+    const unsigned n_whole   = g < dealt ? (dealt - g + G - 1) / G : 0;                                 // ... u = g, g + G, ...
+    const unsigned wg_tail   = (n_units - dealt) > c ? (n_units - dealt - c + s.splits - 1) / s.splits : 0;  // tail units of this workgroup (<= S)
+    constexpr unsigned kPerSimd = S / 4;                                                              // waves of a workgroup per SIMD
+    const unsigned my_quarter = static_cast<unsigned>(wave) & 3u, my_turn = static_cast<unsigned>(wave) >> 2;
+    const unsigned n_quarters = wg_tail > my_turn ? (wg_tail - my_turn + kPerSimd - 1) / kPerSimd : 0;
+    const unsigned n_items    = n_whole + n_quarters;
+    auto item_tail = [&](unsigned it) { return my_turn + (it - n_whole) * kPerSimd; };                  // which of the workgroup's tail units
+    auto item_unit = [&](unsigned it) { return it < n_whole ? g + it * G : dealt + c + item_tail(it) * s.splits; };
+    auto item_shift = [&](unsigned it) { return it < n_whole ? 0u : 16u * my_quarter; };
 
     auto tile_first = [&](unsigned u) {
         if (!diag) return s.j_begin + u * 64;
@@ -221,8 +238,8 @@ template <typename T, int R, int S> __global__ __launch_bounds__(64 * S) __attri
         if (jb >= NB) jb -= NB;
         return s.j_begin + jb * BLOCK + (u % TB) * 64;
     };
-    auto load_tile = [&](unsigned u) {
-        const unsigned j = tile_first(u) + lane;
+    auto load_tile = [&](unsigned u, unsigned shift) {  // lane l takes the tile's body (l - shift) mod 64
+        const unsigned j = tile_first(u) + ((static_cast<unsigned>(lane) - shift) & 63u);
         vec4           p = old_pos[j < j_end ? j : j_end - 1];
         if (j >= j_end) p.w = 0;
         return p;
@@ -264,9 +281,9 @@ template <typename T, int R, int S> __global__ __launch_bounds__(64 * S) __attri
         if constexpr (MJ) jm = rotate(jm);
         rx = rotate(rx), ry = rotate(ry), rz = rotate(rz);
     };
-    auto sixty_four_steps = [&]<bool MI, bool MJ>(T& jx, T& jy, T& jz, T& jm, vec& rx, vec& ry, vec& rz, const vec (&mi)[R]) {
+    auto rotation_steps = [&]<bool MI, bool MJ>(int trips, T& jx, T& jy, T& jz, T& jm, vec& rx, vec& ry, vec& rz, const vec (&mi)[R]) {  // trips x UNR steps: 64 for a unit, 16 for a quarter
 #pragma unroll 1
-        for (int it = 0; it < 64 / UNR; ++it) {
+        for (int it = 0; it < trips; ++it) {
 #pragma unroll
             for (int v = 0; v < UNR; ++v) step.template operator()<MI, MJ>(jx, jy, jz, jm, rx, ry, rz, mi);
         }
@@ -275,9 +292,14 @@ template <typename T, int R, int S> __global__ __launch_bounds__(64 * S) __attri
 #ifdef NB_PAIR_STAMPS
     const unsigned long long stamp_loop = __builtin_amdgcn_s_memtime();
 #endif
-    vec4 cur = g < n_units ? load_tile(g) : vec4{};
-    for (unsigned u = g; u < n_units; u += G) {
-        const vec4 next = (u + G) < n_units ? load_tile(u + G) : cur;  // in flight across the 64 steps below
+    // the sums of the quarters, per tail unit of the workgroup: [wg_tail <= S][quarter][component][body of the tile]
+    T* const tail_sums = reinterpret_cast<T*>(smem_raw + kSumBytes + 256);
+    vec4     cur       = n_items > 0 ? load_tile(item_unit(0), item_shift(0)) : vec4{};
+    for (unsigned item = 0; item < n_items; ++item) {
+        const unsigned u     = item_unit(item);
+        const unsigned shift = item_shift(item);
+        const bool     whole = item < n_whole;
+        const vec4     next  = (item + 1) < n_items ? load_tile(item_unit(item + 1), item_shift(item + 1)) : cur;  // in flight across the steps below
 #ifndef NB_NO_BALANCE
         {
             unsigned least = done;
@@ -292,7 +314,7 @@ template <typename T, int R, int S> __global__ __launch_bounds__(64 * S) __attri
 #endif
         const unsigned q     = u / TB;  // (diag: the block offset)
         const unsigned first = tile_first(u);
-        const unsigned j     = first + lane;
+        const unsigned j     = first + ((static_cast<unsigned>(lane) - shift) & 63u);  // the body this lane holds at the start
         // Is the tile ONE species -- every body j real and of one usable mass?  Then no mass multiplies the i side: the wave's
         // i-side sums are in units of the tile's mass.  Likewise the block: its mass multiplies the reaction sums when they are stored.
         const T    m_tile       = first_lane(cur.w);
@@ -301,11 +323,12 @@ template <typename T, int R, int S> __global__ __launch_bounds__(64 * S) __attri
         vec rx = LT::splat(0), ry = LT::splat(0), rz = LT::splat(0);
         if (tile_uniform && __builtin_bit_cast(bits, m_tile) != __builtin_bit_cast(bits, unit)) change_unit(m_tile);
         if (!tile_uniform) jm = cur.w / unit;  // mixed masses: m_j / unit travels with the body j
-        const T scale = block_uniform ? m_block : T(1);  // what the reaction sums are still to be multiplied by
+        const T   scale = block_uniform ? m_block : T(1);  // what the reaction sums are still to be multiplied by
+        const int trips = whole ? 64 / UNR : 16 / UNR;
         if (block_uniform) {
             vec none[R] = {};  // (these loops never read the masses of the bodies i)
-            if (tile_uniform) sixty_four_steps.template operator()<false, false>(jx, jy, jz, jm, rx, ry, rz, none);
-            else sixty_four_steps.template operator()<false, true>(jx, jy, jz, jm, rx, ry, rz, none);
+            if (tile_uniform) rotation_steps.template operator()<false, false>(trips, jx, jy, jz, jm, rx, ry, rz, none);
+            else rotation_steps.template operator()<false, true>(trips, jx, jy, jz, jm, rx, ry, rz, none);
         } else {
             vec mi[R];  // the masses of the bodies i: only these paths hold them, and only while they run
 #pragma unroll
@@ -313,17 +336,24 @@ template <typename T, int R, int S> __global__ __launch_bounds__(64 * S) __attri
                 const unsigned i = block_base + k * 64 + lane;
                 LT::set(mi[k / W], k % W, i < i_end ? old_pos[i].w : T(0));
             }
-            if (tile_uniform) sixty_four_steps.template operator()<true, false>(jx, jy, jz, jm, rx, ry, rz, mi);
-            else sixty_four_steps.template operator()<true, true>(jx, jy, jz, jm, rx, ry, rz, mi);
+            if (tile_uniform) rotation_steps.template operator()<true, false>(trips, jx, jy, jz, jm, rx, ry, rz, mi);
+            else rotation_steps.template operator()<true, true>(trips, jx, jy, jz, jm, rx, ry, rz, mi);
         }
         // 64 steps on: every sum is back in the lane of its body j.  Keep the reaction only when the partner does not list the pair too.
         const bool     symmetric = diag ? (q != 0 && !(even && q == Q)) : (s.keep != 0);
         const unsigned slot_of   = diag ? q - 1 : a;
-        if (symmetric && j < j_end) {
-            T* const out = s.react + static_cast<size_t>(slot_of) * 3 * s.react_plane + (j - s.react_origin);
-            out[0]                                      = both_halves(rx) * scale;
-            out[static_cast<size_t>(s.react_plane)]     = both_halves(ry) * scale;
-            out[2 * static_cast<size_t>(s.react_plane)] = both_halves(rz) * scale;
+        if (whole) {
+            if (symmetric && j < j_end) {
+                T* const out = s.react + static_cast<size_t>(slot_of) * 3 * s.react_plane + (j - s.react_origin);
+                out[0]                                      = both_halves(rx) * scale;
+                out[static_cast<size_t>(s.react_plane)]     = both_halves(ry) * scale;
+                out[2 * static_cast<size_t>(s.react_plane)] = both_halves(rz) * scale;
+            }
+        } else if (symmetric) {
+            // a quarter: sixteen steps on the lane holds the body that started sixteen lanes back; its sums wait in LDS for the other three
+            const unsigned m   = (static_cast<unsigned>(lane) - shift - 16u) & 63u;
+            T* const       out = tail_sums + (static_cast<size_t>(item_tail(item)) * 4 + my_quarter) * 3 * 64 + m;
+            out[0] = both_halves(rx), out[64] = both_halves(ry), out[128] = both_halves(rz);
         }
         cur = next;
         ++done;
@@ -364,6 +394,19 @@ template <typename T, int R, int S> __global__ __launch_bounds__(64 * S) __attri
 
     // fold the S partial sums (waves 1..S-1 -> wave 0) through LDS, fixed order; the second-level sums are done with
     __syncthreads();
+    // the tail units of the workgroup: a body's four quarter sums, in quarter order, then the one store a whole unit would have made
+    for (unsigned k = static_cast<unsigned>(wave); k < wg_tail; k += S) {
+        const unsigned u         = dealt + c + k * s.splits;
+        const unsigned q         = u / TB;
+        const bool     symmetric = diag ? (q != 0 && !(even && q == Q)) : (s.keep != 0);
+        const unsigned j         = tile_first(u) + lane;
+        if (!symmetric || j >= j_end) continue;
+        const T        scale     = block_uniform ? m_block : T(1);
+        const T* const in        = tail_sums + static_cast<size_t>(k) * 4 * 3 * 64 + lane;
+        T* const       out       = s.react + static_cast<size_t>(diag ? q - 1 : a) * 3 * s.react_plane + (j - s.react_origin);
+#pragma unroll
+        for (int comp = 0; comp < 3; ++comp) out[static_cast<size_t>(comp) * s.react_plane] = (((in[comp * 64] + in[(3 + comp) * 64]) + in[(6 + comp) * 64]) + in[(9 + comp) * 64]) * scale;
+    }
     T* const red = sums;  // [(S-1)][3][I][64]
     if (wave > 0) {
 #pragma unroll
@@ -531,15 +574,19 @@ template <typename T, int R> hipError_t launch_r(const PairArgs<T>& args, int wa
 // R = 4 took 359 us -- two rounds -- against 181 us for the 256 workgroups of 32 768 bodies; profiles/round4_plan_sweep.txt).
 inline double resident_workgroups(int S) { return 256.0 * std::max(1, 8 / S); }  // (four waves: two workgroups saturate a CU)
 
-// The units the busiest SIMD of a workgroup works through (eight waves: SIMD s holds waves s and s + 4): U units dealt to C*S slots,
-// the first U mod (C*S) slots taking one more -- interleaved (slot = wave*C + c: the longer waves are the low wave ids of every
-// workgroup) or blocked (slot = c*S + wave: all the waves of the first workgroups), as launch_pair_tile decides.
-inline unsigned busiest_simd_units(unsigned U, unsigned C, int S) {
+// The units the busiest SIMD of a block's workgroups works through (eight waves: SIMD s holds waves s and s + 4): U units over C*S
+// slots -- floor(U / (C*S)) whole units per wave, and the units left over as quarters, one per SIMD of the workgroup that takes the
+// unit (pair_forces, PairArgs::deal == 2): a workgroup with t tail units adds t / 4 to each of its SIMDs.  Without room in the LDS
+// for the quarters' sums the units stay whole: the first U mod (C*S) slots take one more, interleaved (slot = wave*C + c: the longer
+// waves are the low wave ids of every workgroup) or blocked (slot = c*S + wave), as launch_pair_tile decides.
+inline double busiest_simd_units(unsigned U, unsigned C, int S, bool quarters) {
     const unsigned slots = C * static_cast<unsigned>(S), base = U / slots, rem = U % slots;
+    const double   per_simd = static_cast<double>(S) / 4;  // waves of a workgroup per SIMD
+    if (quarters) return per_simd * base + pair_tail_units(U, C, S) / 4.0;
     const bool     inter = C > 1 && rem != 0 && base < 34;  // (the rule of launch_pair_tile)
-    if (rem == 0) return 2 * base;
+    if (rem == 0) return per_simd * base;
     const unsigned longer = (inter || C == 1) ? (rem + C - 1) / C : std::min(rem, static_cast<unsigned>(S));  // longer waves in the worst workgroup
-    return 2 * base + (longer <= 4 ? 1u : 2u);
+    return per_simd * base + (longer <= 4 ? 1.0 : 2.0);
 }
 
 // Geometry of the single-GPU tournament: R (vectors per lane: blocks of 64*R*W bodies) and C (workgroups sharing a block, any
@@ -581,7 +628,8 @@ template <typename T> PairPlan plan_pair(unsigned n, int cu_count, int ovr_r, in
         p.block_bodies     = block;
         p.slots            = blocks < 2 ? 0u : ((blocks & 1u) ? blocks / 2 : blocks / 2 - 1);
         p.grid_blocks      = blocks * C;
-        p.lds_bytes        = static_cast<unsigned>(static_cast<size_t>(S) * 3 * R * W * 64 * sizeof(T)) + 256u;
+        p.lds_bytes        = pair_lds_bytes(R, W, S, sizeof(T), pair_tail_units((blocks / 2 + 1) * static_cast<unsigned>(R * W), C, S));
+        if (p.lds_bytes > kPairLdsLimit) p.lds_bytes = pair_lds_bytes(R, W, S, sizeof(T), 0);  // (no room for the quarters' sums: whole units only)
         p.workspace_bytes  = (static_cast<size_t>(C) + p.slots) * 3 * static_cast<size_t>(blocks) * block * sizeof(T);
         return p;
     };
@@ -602,7 +650,8 @@ template <typename T> PairPlan plan_pair(unsigned n, int cu_count, int ovr_r, in
             if (ovr_c <= 0 && C > 1 && U < 2 * C * static_cast<unsigned>(S)) continue;  // every wave at least two units (a workgroup's set-up and fold cost about one)
             const double rounds = std::ceil(p.grid_blocks / resident_workgroups(S));
             const double unit   = PairCost<T>::unit[k] > 0.0 ? PairCost<T>::unit[k] : 0.5 * PairCost<T>::unit[1];  // (an R the search would not take, forced by the override)
-            const double cost   = rounds * (busiest_simd_units(U, p.splits, S) * unit + PairCost<T>::wg[k]) +
+            const bool   quarters = pair_lds_bytes(R, W, S, sizeof(T), pair_tail_units(U, p.splits, S)) <= kPairLdsLimit;
+            const double cost   = rounds * (busiest_simd_units(U, p.splits, S, quarters) * unit + PairCost<T>::wg[k]) +
                                 PairCost<T>::slot * 1e-6 * static_cast<double>(n) * (p.slots + p.splits);
             if (best.blocks == 0 || cost < 0.995 * best_cost) best = p, best_cost = cost;
             if (ovr_c > 0) break;
@@ -617,12 +666,24 @@ template <typename T> hipError_t launch_pair_tile(const PairArgs<T>& args, const
     const unsigned block     = 64u * static_cast<unsigned>(g.vectors_per_lane * W);
     a.blocks                 = (a.i_count + block - 1) / block;
     a.splits                 = g.splits;
-    {   // interleave the workgroups of a block when the units leave a remainder worth spreading (see the kernel)
-        const unsigned units = a.diag ? (a.blocks / 2 + 1) * static_cast<unsigned>(g.vectors_per_lane * W) : (a.j_count + 63) / 64;
+    const unsigned units = a.diag ? (a.blocks / 2 + 1) * static_cast<unsigned>(g.vectors_per_lane * W) : (a.j_count + 63) / 64;
+    unsigned       lds_bytes;
+    {   // how the units reach the waves (see the kernel): equal whole units + quarters of the rest when the LDS has room for the quarters' sums
         const unsigned slots = g.splits * static_cast<unsigned>(g.waves), each = units / slots;
-        a.interleave         = (g.splits > 1 && units % slots != 0 && each < 34) ? 1u : 0u;
+        const unsigned tail  = pair_tail_units(units, g.splits, g.waves);
+        lds_bytes            = pair_lds_bytes(g.vectors_per_lane, W, g.waves, sizeof(T), tail);
+#ifdef NB_PAIR_NO_QUARTERS
+        const bool quarters = false;
+#else
+        const bool quarters = lds_bytes <= kPairLdsLimit;
+#endif
+        if (quarters) {
+            a.deal = 2u;
+        } else {
+            a.deal    = (g.splits > 1 && units % slots != 0 && each < 34) ? 1u : 0u;  // (interleaved where the remainder is worth spreading)
+            lds_bytes = pair_lds_bytes(g.vectors_per_lane, W, g.waves, sizeof(T), 0);
+        }
     }
-    const unsigned lds_bytes = static_cast<unsigned>(static_cast<size_t>(g.waves) * 3 * g.vectors_per_lane * W * 64 * sizeof(T)) + 256u;
     if (a.blocks == 0) return hipSuccess;
     switch (g.vectors_per_lane) {
         case 1: return launch_r<T, 1>(a, g.waves, a.blocks * a.splits, lds_bytes, stream, prepare_only);

@@ -288,7 +288,7 @@ def test_pairwise_inner_loops_keep_their_instruction_mix():
 def test_pairwise_headline_kernels_register_budget():
     """The register budget of the kernels the headline numbers come from (round 4: R = 8 vectors per lane) -- pair_forces<float, 8, 8>
     (65 536 bodies and more, fp32: 256 VGPRs, two waves per SIMD, one 8-wave workgroup per CU), pair_forces<float, 8, 12> (reachable
-    through the plan override: 168 VGPRs under launch_bounds(768), three waves per SIMD), pair_forces<double, 8, 8> (fp64: 252 VGPRs, nothing spilled) -- and of
+    through the plan override: 168 VGPRs under launch_bounds(768), three waves per SIMD), pair_forces<double, 8, 8> (fp64: 254 VGPRs, four registers spilled outside the loops) -- and of
     pair_forces<float, 4, 8> (32 768 .. 65 535 bodies, slices and shards under 131 072: 128 VGPRs, four waves per SIMD): the
     occupancy asked for with amdgpu_waves_per_eu is what the compiler delivers, no AGPRs, and the VGPR spills that
     the per-tile prologue and epilogue carry neither grow nor reach the rotation loops: not one scratch_* instruction between a
@@ -299,8 +299,8 @@ def test_pairwise_headline_kernels_register_budget():
     subprocess.run(["make", "-s", "-C", csrc, "asm"], check=True, capture_output=True)
     text = open(os.path.join(csrc, "nbody_pair.s")).read()
     lines = text.split("\n")
-    for template, vgprs, occupancy, spill_limit, scratch_limit, ops_limit in (("IfLi8ELi8E", 256, 2, 44, 92, 56), ("IfLi8ELi12E", 168, 3, 192, 464, 240), ("IdLi8ELi8E", 252, 2, 0, 0, 0),
-                                                                                  ("IfLi4ELi8E", 128, 4, 53, 152, 64)):
+    for template, vgprs, occupancy, spill_limit, scratch_limit, ops_limit in (("IfLi8ELi8E", 256, 2, 52, 104, 56), ("IfLi8ELi12E", 168, 3, 192, 464, 240), ("IdLi8ELi8E", 254, 2, 6, 16, 6),
+                                                                                  ("IfLi4ELi8E", 128, 4, 58, 168, 64)):
         start = next(i for i, l in enumerate(lines) if re.match(r"_ZN2nb\S*pair_forces%sE\S*:" % template, l))
         end = next(i for i in range(start, len(lines)) if lines[i].startswith(".Lfunc_end"))
         name = lines[start].split(":")[0]
@@ -325,7 +325,7 @@ def test_pairwise_headline_kernels_register_budget():
         assert int(re.search(r"; ScratchSize: (\d+)", tail).group(1)) <= scratch_limit, template
         meta = re.search(r"  - \.agpr_count:(?:(?!  - \.agpr_count:).)*?\.name: +%s\n.*?\.wavefront_size: +\d+" % re.escape(name), text, re.S).group(0)
         field = lambda key: int(re.search(r"\.%s: +(\d+)" % key, meta).group(1))  # noqa: E731
-        assert field("vgpr_count") == vgprs and field("sgpr_spill_count") <= 8, template  # (a few scalars parked in VGPR lanes outside the loops: v_writelane, no memory)
+        assert field("vgpr_count") == vgprs and field("sgpr_spill_count") <= 28, template  # (scalars parked in VGPR lanes outside the loops: v_writelane, no memory; more of them since the work items of a wave are whole units AND quarters)
         assert field("vgpr_spill_count") <= spill_limit, (template, field("vgpr_spill_count"))
         assert field("private_segment_fixed_size") <= scratch_limit, template
 
