@@ -489,12 +489,25 @@ template <typename T> __global__ __launch_bounds__(256) void pair_finish(FinishA
         v  = reinterpret_cast<const vec4*>(s.vel)[body];
         pn = reinterpret_cast<const vec4*>(s.old_pos)[body];
         if (s.extra != nullptr) e = reinterpret_cast<const vec4*>(s.extra)[body];
+        // the body's own sums: one plane per workgroup that shared its block (up to 16), added in slot order; the loads go out four
+        // slots x three components at a time (a chain of dependent loads cost 10 us of a 34 us finish at C = 13)
+        for (unsigned m = 0; m < s.n_self; ++m) {
+            const auto& set = s.self_set[m];
+            if (k < set.first || k - set.first >= set.count) continue;
+            for (unsigned c0 = 0; c0 < set.slots; c0 += 4) {
+                T x[4][3];
 #pragma unroll
-        for (int comp = 0; comp < 3; ++comp) {
-            for (unsigned m = 0; m < s.n_self; ++m) {
-                const auto& set = s.self_set[m];
-                if (k < set.first || k - set.first >= set.count) continue;
-                for (unsigned c = 0; c < set.slots; ++c) own[comp] += s.self[(static_cast<size_t>(set.slot + c) * 3 + comp) * s.self_plane + k];
+                for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                    for (int comp = 0; comp < 3; ++comp) x[i][comp] = (c0 + i) < set.slots ? s.self[(static_cast<size_t>(set.slot + c0 + i) * 3 + comp) * s.self_plane + k] : T(0);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if ((c0 + i) < set.slots) {  // (a missing slot must not add +0 to a -0 sum: keep the additions exactly those of the plain loop)
+#pragma unroll
+                        for (int comp = 0; comp < 3; ++comp) own[comp] += x[i][comp];
+                    }
+                }
             }
         }
     }
