@@ -518,14 +518,22 @@ template <typename T> __global__ __launch_bounds__(256) void pair_finish(FinishA
     }
     __syncthreads();
     if (!closer) return;
+    // what arrived from the other ranks / slices (up to kMaxRecv arrays): all loads first, then the additions in array order
+    T    got[kMaxRecv][3];
+    bool has[kMaxRecv];
+#pragma unroll
+    for (int m = 0; m < kMaxRecv; ++m) {
+        has[m] = static_cast<unsigned>(m) < s.n_recv && k >= s.recv_set[m].first && k - s.recv_set[m].first < s.recv_set[m].count;
+#pragma unroll
+        for (int comp = 0; comp < 3; ++comp) got[m][comp] = has[m] ? s.recv[(static_cast<size_t>(m) * 3 + comp) * s.recv_plane + k] : T(0);
+    }
     T f[3];
 #pragma unroll
     for (int comp = 0; comp < 3; ++comp) {
         T others = (t[comp] + part[0][comp][lane]) + (part[1][comp][lane] + part[2][comp][lane]);
-        for (unsigned m = 0; m < s.n_recv; ++m) {
-            const auto& set = s.recv_set[m];
-            if (k < set.first || k - set.first >= set.count) continue;
-            others += s.recv[(static_cast<size_t>(m) * 3 + comp) * s.recv_plane + k];
+#pragma unroll
+        for (int m = 0; m < kMaxRecv; ++m) {
+            if (has[m]) others += got[m][comp];
         }
         f[comp] = own[comp] - others;  // d = p_j - p_i: what body j feels from body i is -m_i d w
     }
