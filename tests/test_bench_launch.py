@@ -142,7 +142,7 @@ def test_default_line_carries_every_baseline_config():
     # the dominant kernel is timed on its own (an event between the two launches of a step); the two kernels add up to the step
     assert roof["kernel"] == "pair_forces" and roof["kernel_ms"] == roof["pair_forces_ms"] > 10 * roof["pair_finish_ms"] > 0
     assert abs(roof["pair_forces_ms"] + roof["pair_finish_ms"] - roof["stream_ms_per_step"]) < 0.05 * roof["stream_ms_per_step"]
-    assert roof["step_frac"] <= roof["frac"]
+    assert roof["step_frac"] <= 1.03 * roof["frac"]  # (the kernel is timed apart, AFTER the region the step comes from: the clock may have drifted a per cent or two)
     if roof["chip"] is not None:  # (sysfs readable: the clock the chip ran at, and the fraction of what it could issue at THAT clock)
         assert 500 < roof["chip"]["sclk_mhz"] <= 2500 and roof["chip"]["samples"] >= 1
         assert 0.98 * roof["step_frac"] <= roof["frac_at_delivered_clock"] < 1.25  # (algorithmic flop: may pass 1, see frac_counts)
