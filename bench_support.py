@@ -303,19 +303,21 @@ def pair_kernel_split(pkg, lib, step, stream, reps=10):
     """Average duration of the two kernels of the pairwise step, each on its own: pair_forces (the dominant kernel) and pair_finish,
     from HIP events on the launch stream -- one before the step, one the library records BETWEEN the two launches
     (nb_set_pair_probe_event, tuning header), one after.  Taken after the timed region."""
-    before, between, after = pkg.Event(), pkg.Event(), pkg.Event()
-    forces = finish = 0.0
-    pkg.check(lib.nb_set_pair_probe_event(between.h), "nb_set_pair_probe_event")
+    # The reps are queued back to back (an event triple per rep, the probe event switched on the host before each call) and read
+    # after ONE synchronisation: a synchronisation per rep idled the chip between steps, and the forces kernel then read 0.5 % slower
+    # than the timed steps it belongs to.
+    events = [(pkg.Event(), pkg.Event(), pkg.Event()) for _ in range(reps)]
     try:
-        for _ in range(reps):
+        for before, between, after in events:
+            pkg.check(lib.nb_set_pair_probe_event(between.h), "nb_set_pair_probe_event")
             before.record(stream)
             step()
             after.record(stream)
-            after.synchronize()
-            forces += before.elapsed_ms(between)
-            finish += between.elapsed_ms(after)
+        events[-1][2].synchronize()
     finally:
         pkg.check(lib.nb_set_pair_probe_event(None), "nb_set_pair_probe_event")
+    forces = sum(before.elapsed_ms(between) for before, between, _ in events)
+    finish = sum(between.elapsed_ms(after) for _, between, after in events)
     return forces / reps, finish / reps
 
 
