@@ -214,8 +214,9 @@ template <typename T, int R, int S> __global__ __launch_bounds__(64 * S) __attri
     // rotation steps, one per SIMD (quarter p on a wave with wave % 4 == p, the workgroup's tail units taking turns between the
     // S/4 waves of a SIMD): a quarter's lanes load the tile rotated by 16p lanes, so that sixteen steps bring lane l exactly the
     // bodies that the steps 16p .. 16p+15 of a whole unit would have, and the four partial reaction sums of a body meet in LDS
-    // (fixed order) before one store.  (Waves land on the SIMDs round robin -- wave w on SIMD w % 4, as the stamps of
-    // profiles/round4_wave_exit_stamps.txt show; only the balance rests on that, not the result.)  Every SIMD of a block's workgroups then carries the same load to a quarter of a unit:
+    // (fixed order) before one store.  (The waves 0-3 of a workgroup sit on four different SIMDs and wave w + 4 on the SIMD of
+    // wave w -- in all 256 workgroups of a launch, by the stamps of tools/pair_stamps.py, profiles/round4_wave_exit_stamps.txt; only the
+    // balance rests on that, not the result.)  Every SIMD of a block's workgroups then carries the same load to a quarter of a unit:
     // 16 384 bodies are 33 units per 8-wave workgroup -- 8.25 per SIMD instead of 9 for the one that held the wave with five.
     // s.deal == 0 / 1: every unit whole, unit u to slot u mod (C*S), the slots blocked (c*S + wave) or interleaved (wave*C + c: the
     // waves with one unit more are the low wave ids of EVERY workgroup; round 4's first answer to the remainder, kept for launches

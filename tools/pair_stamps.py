@@ -72,3 +72,12 @@ print("last exit per SIMD us:", pct(per_simd_last), " first exit per SIMD us:", 
 print("spread of exits inside a SIMD us:", pct(per_simd_last - per_simd_first))
 busy = per_simd_last - np.array([start[where == i].min() for i in ids])
 print("us per unit and SIMD (last exit - first start) / units:", pct(busy / per_simd_units))
+# which SIMD does wave w of a workgroup land on?  (the quarters of pair_forces give quarter p to a wave with w % 4 == p: one per SIMD if w -> w % 4)
+wave_in_wg = (st[:, 4] >> 32).astype(int)
+table = {}
+for w, sd in zip(wave_in_wg.tolist(), simd.tolist()):
+    table.setdefault(w, {}).setdefault(sd, 0)
+    table[w][sd] += 1
+print("SIMD by wave of the workgroup (wave: {simd: count}):", {w: table[w] for w in sorted(table)})
+distinct = [len({int(simd[i]) for i in range(b, b + 4)}) for b in range(0, len(simd) - 3, pl.waves_per_block) if wave_in_wg[b] == 0]
+print("workgroups whose waves 0-3 sit on four different SIMDs:", sum(1 for d in distinct if d == 4), "of", len(distinct))
