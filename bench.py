@@ -74,25 +74,42 @@ def parse_args():
                          "applied to both, csrc/nbody_pair.hip); one-sided = nb_integrate_* (every directed interaction, as the reference kernel)")
     ap.add_argument("--dump-state", type=str, default="", help="rank 0 writes its initial and final positions (.npz) here (tests)")
     ap.add_argument("--no-configs", action="store_true", help="skip the extra BASELINE configs timed after the headline measurement (N=1)")
-    ap.add_argument("--launch-timeout", type=float, default=600.0,
-                    help="plain `bench.py --gpus N`: seconds the launcher waits for the N ranks before ending them (see self_launch)")
+    ap.add_argument("--launch-timeout", type=float, default=150.0,
+                    help="plain `bench.py --gpus N`: seconds the launcher gives ONE attempt of the N ranks before ending them (see self_launch)")
+    ap.add_argument("--launch-budget", type=float, default=560.0,
+                    help="plain `bench.py --gpus N`: seconds for the whole command -- the first attempt and up to three plainer exchanges (under the driver's 600 s)")
+    ap.add_argument("--bringup-timeout", type=float, default=60.0,
+                    help="plain `bench.py --gpus N`: an attempt is ended when no rank has its exchange up this long after the first rank imported torch")
+    ap.add_argument("--headline-timeout", type=float, default=240.0,
+                    help="N>1: seconds a rank allows bring-up + warm-up + the timed steps before it says where it is stuck and leaves (status 5) -- "
+                         "under torch.distributed.run nothing else would end a rank that sits inside a collective")
     ap.add_argument("--rehearse-one-gpu", action="store_true",
                     help="REHEARSAL of the N-rank C-ABI path on a one-GPU box: every rank uses device 0 and RCCL is replaced by the test double "
                          "(NBODY_RCCL_LIB=tests/fake_rccl/libfake_rccl.so with FAKE_RCCL_IPC=1, set here when absent).  Never a performance number.")
     ap.add_argument("--no-chip-watch", action="store_true", help="do not sample the card's clock and power (sysfs) during the timed region")
     ap.add_argument("--no-diagnostics", action="store_true", help="N>1: skip the A/B timings and BASELINE configs[3] after the timed region")
-    ap.add_argument("--diagnostics-timeout", type=float, default=240.0, help="N>1: seconds the post-headline measurements may take before the line is printed without them")
+    ap.add_argument("--diagnostics-timeout", type=float, default=150.0, help="N>1: seconds the post-headline measurements may take before the line is printed without them")
     return ap.parse_args()
 
 
-def self_launch(n_ranks: int, explicit_exchange: bool, limit_s: float) -> int:
+BRINGUP_MARK = "] up:"          # every rank writes "[bench rank R] up: ..." to stderr once its exchange is up, before the warm-up
+IMPORTED_MARK = "] torch imported"  # ... and "[bench rank R] torch imported" right after the import (a fresh box pages torch in for a minute or two)
+
+
+def self_launch(n_ranks: int, explicit_exchange: bool, attempt_s: float, budget_s: float = 560.0, bringup_s: float = 60.0, import_s: float = 150.0, make_cmd=None) -> int:
     """Run this same command line as `n_ranks` ranks under torch.distributed.run (one process per GPU, rendezvous on
     127.0.0.1) as a CHILD process group and relay its output.  The >1-GPU path has not run on hardware yet, so the launcher
-    carries one safety net: when the ranks fail or go `limit_s` seconds without finishing before rank 0 printed its line,
-    and the exchange was not chosen on the command line, their process group is ended (by its exact id) and the job is
-    started again with a plainer exchange: `--exchange torch` (the tile schedule over torch.distributed), `--exchange allgather`
-    (one all-gather per step), then `--exchange staged` (gloo through host memory, no RCCL) -- at most those three further
-    attempts, each marked "exchange_fallback": true in its JSON line."""
+    carries one safety net: when the ranks fail, or stall, before rank 0 printed its line, and the exchange was not chosen on
+    the command line, their process group is ended (by its exact id) and the job is started again with a plainer exchange:
+    `--exchange torch` (the tile schedule over torch.distributed), `--exchange allgather` (one all-gather per step), then
+    `--exchange staged` (gloo through host memory, no RCCL) -- at most those three further attempts, each marked
+    "exchange_fallback": true in its JSON line.
+
+    The net has to close INSIDE what the caller allows the whole command (the driver: 600 s), so time is rationed: the command
+    as a whole gets `budget_s`; an attempt gets `attempt_s` of it at most, and is ended early when no rank has reported its
+    exchange up (BRINGUP_MARK on stderr) `bringup_s` after the first rank imported torch (IMPORTED_MARK; `import_s` at the
+    latest after the start) -- a run that will finish has printed that line within seconds, one that sits in a rendezvous or in
+    RCCL's bring-up never does.  `make_cmd(extra_flags, port) -> argv`: the command of an attempt (tests pass stand-in ranks)."""
     import signal
     import socket
     import subprocess
@@ -101,52 +118,84 @@ def self_launch(n_ranks: int, explicit_exchange: bool, limit_s: float) -> int:
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this pool (RCCL needs it)
     env.setdefault("OMP_NUM_THREADS", "1")
+    started = time.monotonic()
+    if make_cmd is None:
+        def make_cmd(extra, port):
+            return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                    os.path.abspath(__file__)] + sys.argv[1:] + extra
 
-    def attempt(extra):
+    def end_group(child, why):
+        print(f"[bench] {why}: ending process group {child.pid}", file=sys.stderr, flush=True)
+        for sig in (signal.SIGTERM, signal.SIGKILL):
+            try:
+                os.killpg(child.pid, sig)  # the group this call created (start_new_session), nothing else
+            except ProcessLookupError:
+                break
+            try:
+                child.wait(timeout=10)
+                break
+            except subprocess.TimeoutExpired:
+                continue
+        return child.returncode if child.returncode is not None else -9
+
+    def attempt(extra, attempts_left):
+        # what is left of the budget, shared fairly with the attempts that may still have to follow
+        left = budget_s - (time.monotonic() - started)
+        limit = max(5.0, min(attempt_s, left / max(1, attempts_left) if explicit_exchange is False else left))
         with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
             sock.bind(("127.0.0.1", 0))
             port = sock.getsockname()[1]
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}",
-               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:] + extra
-        child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, start_new_session=True)
-        seen = {"metric": False}
+        child = subprocess.Popen(make_cmd(extra, port), env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+        seen = {"metric": False, "up": False, "imported_at": None}
 
-        def relay():
+        def relay_out():
             for line in child.stdout:
                 if line.startswith("{") and '"metric"' in line:
                     seen["metric"] = True
                 sys.stdout.write(line)
                 sys.stdout.flush()
 
-        reader = threading.Thread(target=relay, daemon=True)
-        reader.start()
-        try:
-            rc = child.wait(timeout=limit_s)
-        except subprocess.TimeoutExpired:
-            print(f"[bench] ranks still running after {limit_s:.0f} s: ending process group {child.pid}", file=sys.stderr, flush=True)
-            for sig in (signal.SIGTERM, signal.SIGKILL):
-                try:
-                    os.killpg(child.pid, sig)  # the group this call created (start_new_session), nothing else
-                except ProcessLookupError:
-                    break
-                try:
-                    child.wait(timeout=20)
-                    break
-                except subprocess.TimeoutExpired:
-                    continue
-            rc = child.returncode if child.returncode is not None else -9
-        reader.join(timeout=10)
+        def relay_err():
+            for line in child.stderr:
+                if BRINGUP_MARK in line:
+                    seen["up"] = True
+                elif IMPORTED_MARK in line and seen["imported_at"] is None:
+                    seen["imported_at"] = time.monotonic()
+                sys.stderr.write(line)
+                sys.stderr.flush()
+
+        readers = [threading.Thread(target=relay_out, daemon=True), threading.Thread(target=relay_err, daemon=True)]
+        for r in readers:
+            r.start()
+        begun, rc = time.monotonic(), None
+        while rc is None:
+            try:
+                rc = child.wait(timeout=0.5)
+            except subprocess.TimeoutExpired:
+                now = time.monotonic()
+                if now - begun > limit:
+                    rc = end_group(child, f"ranks still running after {limit:.0f} s")
+                elif not seen["up"] and not seen["metric"]:
+                    clock = seen["imported_at"] if seen["imported_at"] is not None else begun + import_s - bringup_s
+                    if now - clock > bringup_s:
+                        rc = end_group(child, f"no rank has its exchange up {now - begun:.0f} s after the start")
+        for r in readers:
+            r.join(timeout=10)
         return rc, seen["metric"]
 
-    rc, reported = attempt([])
+    plainer = [] if explicit_exchange else ["torch", "allgather", "staged"]
+    rc, reported = attempt([], 1 + len(plainer))
     # plainer and plainer: the tile schedule over torch.distributed, one all-gather per step, then no RCCL at all.  A line
     # produced by a retry says so at its top level ("exchange_fallback": true), not only in config.exchange.
     env["NBODY_BENCH_EXCHANGE_FALLBACK"] = "1"
-    for fallback in ("torch", "allgather", "staged"):
-        if rc == 0 or reported or explicit_exchange:
+    for k, fallback in enumerate(plainer):
+        if rc == 0 or reported:
+            break
+        if budget_s - (time.monotonic() - started) < 10.0:
+            print(f"[bench] the {n_ranks}-rank run ended with status {rc} before reporting and the launcher's budget of {budget_s:.0f} s is spent", file=sys.stderr, flush=True)
             break
         print(f"[bench] the {n_ranks}-rank run ended with status {rc} before reporting; one more attempt with --exchange {fallback}", file=sys.stderr, flush=True)
-        rc, reported = attempt(["--exchange", fallback])
+        rc, reported = attempt(["--exchange", fallback], len(plainer) - k)
     return rc
 
 
@@ -171,7 +220,8 @@ def main():
     if world == 1 and args.gpus > 1 and "RANK" not in os.environ:
         # plain `python3 bench.py --gpus N`: start the N ranks ourselves, BEFORE anything in this process touches the GPU
         # (no torch import, no HIP call so far), relay their output and exit with their status.  Children, never exec.
-        raise SystemExit(self_launch(args.gpus, any(a.startswith("--exchange") for a in sys.argv[1:]) or args.rehearse_one_gpu, args.launch_timeout))
+        raise SystemExit(self_launch(args.gpus, any(a.startswith("--exchange") for a in sys.argv[1:]) or args.rehearse_one_gpu, args.launch_timeout, args.launch_budget,
+                                     args.bringup_timeout))
     if args.gpus != world:
         args.gpus = world
 

@@ -68,6 +68,14 @@ class PairPlan(ctypes.Structure):
                 ("lds_bytes", ctypes.c_uint), ("workspace_bytes", ctypes.c_size_t), ("slices", ctypes.c_uint)]
 
 
+class CommSelftest(ctypes.Structure):
+    """nb_comm_selftest_t (include/nbody_hip_tuning.h): what the self-loop through the real RCCL reported"""
+    _fields_ = [("rccl_version", ctypes.c_int), ("send_recv_status", ctypes.c_int), ("all_gather_status", ctypes.c_int),
+                ("send_recv_ms", ctypes.c_float), ("all_gather_ms", ctypes.c_float),
+                ("send_recv_wrong_bytes", ctypes.c_size_t), ("all_gather_wrong_bytes", ctypes.c_size_t),
+                ("refused_call", ctypes.c_char * 64), ("library_path", ctypes.c_char * 256)]
+
+
 class LaunchPlan(ctypes.Structure):
     _fields_ = [("bodies_per_lane", ctypes.c_int), ("lanes_per_body", ctypes.c_int), ("tile_bodies", ctypes.c_int),
                 ("block_threads", ctypes.c_int), ("grid_blocks", ctypes.c_uint), ("lds_bytes", ctypes.c_uint)]
@@ -162,6 +170,10 @@ TUNING_SIGNATURES = {
     "nb_set_pair_probe_event": (_ci, [_vp]),
     "nb_set_memory_budget": (_ci, [_sz]),
     "nb_lds_optin_count": (_ci, [_P(_ci)]),
+    "nb_comm_selftest_open": (_ci, [_P(_vp), _vp]),
+    "nb_comm_selftest_f32": (_ci, [_vp, _sz, _vp, _P(CommSelftest)]),
+    "nb_comm_self_transfer_f32": (_ci, [_vp, _vp, _vp, _sz, _ci, _ci, _vp, _vp, _vp]),
+    "nb_comm_transport_info": (_ci, [_vp, _P(_ci), ctypes.c_char_p, _sz]),
 }
 
 _lib = None
@@ -492,10 +504,12 @@ class ShardedRank:
         return bool(flag.value)
 
     def info(self) -> dict:
-        """nb_comm_info: what the communicator itself says about this rank"""
+        """nb_comm_info + nb_comm_transport_info: what the communicator itself says about this rank and the RCCL it is bound to"""
         r, w, d = _ci(-1), _ci(-1), _ci(-1)
         check(lib().nb_comm_info(self.comm, ctypes.byref(r), ctypes.byref(w), ctypes.byref(d)), "nb_comm_info")
-        return {"rank": r.value, "world": w.value, "device": d.value}
+        out = {"rank": r.value, "world": w.value, "device": d.value}
+        out.update(comm_transport_info(self.comm))
+        return out
 
     def update(self, delta_time, damping) -> None:
         """pos[1-read][own slice], vel[own slice] <- one step from pos[read]; then the tiles of pos[1-read] start moving."""
@@ -533,6 +547,14 @@ def workspace_bytes(num_bodies: int, dtype=np.float32, mode: int = NB_MODE_FAST,
     else:
         check((lib().nb_workspace_bytes_capped_f32 if f32 else lib().nb_workspace_bytes_capped_f64)(num_bodies, mode, max_bytes, ctypes.byref(need)), "nb_workspace_bytes_capped")
     return need.value
+
+
+def comm_transport_info(comm) -> dict:
+    """nb_comm_transport_info (tuning header): {"rccl_version": 22204, "rccl_library": ".../librccl.so.1"}; 0 / "" when the
+    communicator has no transport bound (a world of one)."""
+    version, path = _ci(0), ctypes.create_string_buffer(512)
+    check(lib().nb_comm_transport_info(comm, ctypes.byref(version), path, len(path)), "nb_comm_transport_info")
+    return {"rccl_version": version.value, "rccl_library": path.value.decode()}
 
 
 def comm_unique_id() -> bytes:

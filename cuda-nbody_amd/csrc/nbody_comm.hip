@@ -24,6 +24,7 @@
 
 #include "nbody_kernels.h"
 #include "rand_stream_guard.h"
+#include "rccl_api.h"
 
 #include <hip/hip_runtime.h>
 
@@ -39,26 +40,27 @@
 
 namespace {
 
-// ---- the few RCCL entry points used, resolved at run time (declarations as in /opt/rocm/include/rccl/rccl.h) ----------
-using ncclComm_t = struct ncclComm*;
-struct ncclUniqueId {
-    char internal[128];
-};
+// ---- the few RCCL entry points used, resolved at run time: their types live in rccl_api.h, which `make check-rccl-abi` holds
+// against /opt/rocm/include/rccl/rccl.h at compile time ----------------------------------------------------------------------
+using ncclComm_t   = nb_rccl::Comm;
+using ncclUniqueId = nb_rccl::UniqueId;
 static_assert(sizeof(ncclUniqueId) == NB_COMM_ID_BYTES, "nb_comm_unique_id hands out exactly one ncclUniqueId");
-enum { ncclFloat32 = 7, ncclFloat64 = 8 };
+enum { ncclFloat32 = nb_rccl::kFloat32, ncclFloat64 = nb_rccl::kFloat64 };
 
 struct Rccl {
-    void* handle = nullptr;
-    int (*GetUniqueId)(ncclUniqueId*)                                                    = nullptr;
-    int (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int)                             = nullptr;
-    int (*CommInitAll)(ncclComm_t*, int, const int*)                                     = nullptr;
-    int (*CommDestroy)(ncclComm_t)                                                       = nullptr;
-    int (*Send)(const void*, size_t, int, int, ncclComm_t, hipStream_t)                  = nullptr;
-    int (*Recv)(void*, size_t, int, int, ncclComm_t, hipStream_t)                        = nullptr;
-    int (*AllGather)(const void*, void*, size_t, int, ncclComm_t, hipStream_t)           = nullptr;
-    int (*GroupStart)()                                                                  = nullptr;
-    int (*GroupEnd)()                                                                    = nullptr;
-    const char* (*GetErrorString)(int)                                                   = nullptr;
+    void*       handle = nullptr;
+    std::string path;  // the file the entry points were bound from (dladdr), for the record
+    nb_rccl::GetVersionFn     GetVersion     = nullptr;  // (optional: only reported)
+    nb_rccl::GetUniqueIdFn    GetUniqueId    = nullptr;
+    nb_rccl::CommInitRankFn   CommInitRank   = nullptr;
+    nb_rccl::CommInitAllFn    CommInitAll    = nullptr;
+    nb_rccl::CommDestroyFn    CommDestroy    = nullptr;
+    nb_rccl::SendFn           Send           = nullptr;
+    nb_rccl::RecvFn           Recv           = nullptr;
+    nb_rccl::AllGatherFn      AllGather      = nullptr;
+    nb_rccl::GroupStartFn     GroupStart     = nullptr;
+    nb_rccl::GroupEndFn       GroupEnd       = nullptr;
+    nb_rccl::GetErrorStringFn GetErrorString = nullptr;
 };
 
 Rccl* rccl() {
@@ -83,6 +85,7 @@ Rccl* rccl() {
         }
         if (lib.handle == nullptr) return;
         auto sym = [](const char* n) { return dlsym(lib.handle, n); };
+        lib.GetVersion     = reinterpret_cast<decltype(lib.GetVersion)>(sym("ncclGetVersion"));
         lib.GetUniqueId    = reinterpret_cast<decltype(lib.GetUniqueId)>(sym("ncclGetUniqueId"));
         lib.CommInitRank   = reinterpret_cast<decltype(lib.CommInitRank)>(sym("ncclCommInitRank"));
         lib.CommInitAll    = reinterpret_cast<decltype(lib.CommInitAll)>(sym("ncclCommInitAll"));
@@ -96,7 +99,10 @@ Rccl* rccl() {
         if (!lib.GetUniqueId || !lib.CommInitRank || !lib.CommInitAll || !lib.CommDestroy || !lib.Send || !lib.Recv || !lib.AllGather || !lib.GroupStart || !lib.GroupEnd) {
             dlclose(lib.handle);
             lib.handle = nullptr;
+            return;
         }
+        Dl_info bound{};
+        if (dladdr(reinterpret_cast<const void*>(lib.Send), &bound) != 0 && bound.dli_fname != nullptr) lib.path = bound.dli_fname;
     });
     return lib.handle != nullptr ? &lib : nullptr;
 }
@@ -670,12 +676,14 @@ int nb_comm_unique_id(void* id) {
     return nccl_status(rc);
 }
 
-int nb_comm_init_rank(nb_comm_t* comm, const void* id, int world, int rank) {
+// `alone_too`: bind RCCL and make a real communicator even for a world of one (nb_comm_selftest_open: the self-loop check)
+static int init_rank(nb_comm_t* comm, const void* id, int world, int rank, bool alone_too) {
     NB_KEEP_RAND_STREAM;
-    if (!comm || (!id && world > 1) || world < 1 || rank < 0 || rank >= world) return NB_ERR_INVALID_ARGUMENT;
+    if (!comm || (!id && (world > 1 || alone_too)) || world < 1 || rank < 0 || rank >= world) return NB_ERR_INVALID_ARGUMENT;
     *comm     = nullptr;
-    Rccl* lib = world > 1 ? rccl() : nullptr;  // a world of one never exchanges anything: no RCCL needed, none loaded
-    if (world > 1 && lib == nullptr) return NB_ERR_UNSUPPORTED;
+    const bool transport = world > 1 || alone_too;
+    Rccl* lib = transport ? rccl() : nullptr;  // a world of one never exchanges anything: no RCCL needed, none loaded
+    if (transport && lib == nullptr) return NB_ERR_UNSUPPORTED;
     auto* c  = new Comm;
     c->rank  = rank;
     c->world = world;
@@ -684,7 +692,7 @@ int nb_comm_init_rank(nb_comm_t* comm, const void* id, int world, int rank) {
         return static_cast<int>(err);
     }
     int rc = 0;
-    if (world > 1) {
+    if (transport) {
         ncclUniqueId uid;
         std::memcpy(uid.internal, id, sizeof(uid.internal));
         rc = nccl_status(lib->CommInitRank(&c->nccl, world, uid, rank));
@@ -700,6 +708,8 @@ int nb_comm_init_rank(nb_comm_t* comm, const void* id, int world, int rank) {
     *comm    = c;
     return 0;
 }
+
+int nb_comm_init_rank(nb_comm_t* comm, const void* id, int world, int rank) { return init_rank(comm, id, world, rank, false); }
 
 int nb_comm_init_all(nb_comm_t* comms, int num_devices, const int* devices) {
     NB_KEEP_RAND_STREAM;
@@ -839,6 +849,143 @@ int nb_comm_set_pair_min_slice(int min_bodies_per_rank) {
     if (min_bodies_per_rank < 0) return NB_ERR_INVALID_ARGUMENT;
     g_pair_shard_min.store(min_bodies_per_rank);
     return 0;
+}
+
+// ---- the REAL transport on one GPU (tuning header): a communicator of one rank that does own an RCCL communicator, and a
+// self-loop through it with the event choreography of exchange_tiles -----------------------------------------------------------
+int nb_comm_selftest_open(nb_comm_t* comm, const void* id) { return init_rank(comm, id, 1, 0, true); }
+
+int nb_comm_transport_info(nb_comm_t comm, int* version, char* library_path, size_t path_bytes) {
+    NB_KEEP_RAND_STREAM;
+    Comm* c = as_comm(comm);
+    if (c == nullptr) return NB_ERR_INVALID_ARGUMENT;
+    if (version) *version = 0;
+    if (library_path && path_bytes) library_path[0] = 0;
+    if (c->nccl == nullptr) return 0;  // a world of one: no transport bound, nothing to report
+    Rccl* lib = rccl();
+    if (lib == nullptr) return NB_ERR_UNSUPPORTED;
+    if (version && lib->GetVersion) (void)lib->GetVersion(version);
+    if (library_path && path_bytes) {
+        std::strncpy(library_path, lib->path.c_str(), path_bytes - 1);
+        library_path[path_bytes - 1] = 0;
+    }
+    return 0;
+}
+
+// `rounds` send/recv pairs from this rank to ITSELF on the communicator's exchange stream -- round k moves `count` floats from
+// src + k * count to dst + k * count -- all in one RCCL group or a group per round, after what `after` holds now; `begin` / `end`
+// (optional) are recorded on the exchange stream around them, and tile event 0 after them (nb_exchange_wait_tile(comm, .., 0)
+// is not usable for it: a rank never waits for its own tile -- the caller waits for `end`).
+int nb_comm_self_transfer_f32(nb_comm_t comm, const float* src, float* dst, size_t count, int rounds, int one_group, nb_stream_t after, nb_event_t begin, nb_event_t end) {
+    NB_KEEP_RAND_STREAM;
+    Comm* c = as_comm(comm);
+    if (c == nullptr || c->nccl == nullptr || src == nullptr || dst == nullptr || count == 0 || rounds < 1) return NB_ERR_INVALID_ARGUMENT;
+    Rccl* lib = rccl();
+    if (lib == nullptr) return NB_ERR_UNSUPPORTED;
+    DeviceScope scope(c->device);
+    auto        err = hipEventRecord(c->ready, reinterpret_cast<hipStream_t>(after));
+    if (err == hipSuccess) err = hipStreamWaitEvent(c->stream, c->ready, 0);
+    if (err == hipSuccess && begin != nullptr) err = hipEventRecord(reinterpret_cast<hipEvent_t>(begin), c->stream);
+    if (err != hipSuccess) return static_cast<int>(err);
+    int rc = one_group ? static_cast<int>(lib->GroupStart()) : 0;
+    for (int k = 0; k < rounds && rc == 0; ++k) {
+        if (!one_group) rc = lib->GroupStart();
+        if (rc == 0) rc = lib->Send(src + static_cast<size_t>(k) * count, count, ncclFloat32, c->rank, c->nccl, c->stream);
+        if (rc == 0) rc = lib->Recv(dst + static_cast<size_t>(k) * count, count, ncclFloat32, c->rank, c->nccl, c->stream);
+        if (!one_group) {
+            const int ended = lib->GroupEnd();
+            if (rc == 0) rc = ended;
+        }
+    }
+    if (one_group) {
+        const int ended = lib->GroupEnd();
+        if (rc == 0) rc = ended;
+    }
+    if (rc != 0) return nccl_status(rc);
+    if (end != nullptr) err = hipEventRecord(reinterpret_cast<hipEvent_t>(end), c->stream);
+    if (err == hipSuccess) err = hipEventRecord(c->arrived[static_cast<size_t>(c->rank)], c->stream);
+    return static_cast<int>(err);
+}
+
+int nb_comm_selftest_f32(nb_comm_t comm, size_t bytes, nb_stream_t stream, nb_comm_selftest_t* report) {
+    NB_KEEP_RAND_STREAM;
+    Comm* c = as_comm(comm);
+    if (c == nullptr || report == nullptr || bytes < 4 || bytes % 4 != 0) return NB_ERR_INVALID_ARGUMENT;
+    std::memset(report, 0, sizeof(*report));
+    if (c->nccl == nullptr || c->world != 1) return NB_ERR_INVALID_ARGUMENT;  // (made by nb_comm_selftest_open)
+    Rccl* lib = rccl();
+    if (lib == nullptr) return NB_ERR_UNSUPPORTED;
+    (void)nb_comm_transport_info(comm, &report->rccl_version, report->library_path, sizeof(report->library_path));
+    DeviceScope  scope(c->device);
+    hipStream_t  on    = reinterpret_cast<hipStream_t>(stream);
+    const size_t count = bytes / 4;
+    std::vector<unsigned> sent(count), got(count);
+    for (size_t k = 0; k < count; ++k) sent[k] = static_cast<unsigned>(k) * 2654435761u + 0x9e3779b9u;
+    float *     src = nullptr, *dst = nullptr, *gathered = nullptr;
+    hipEvent_t  t0 = nullptr, t1 = nullptr;
+    int         result = 0;
+    auto refuse = [&](const char* call, int rc, int* slot) {
+        *slot = nccl_status(rc);
+        if (report->refused_call[0] == 0) std::strncpy(report->refused_call, call, sizeof(report->refused_call) - 1);
+        if (result == 0) result = *slot;
+    };
+    auto wrong_bytes = [&](const float* device) -> size_t {  // what `device` holds against what was sent (after the exchange stream's work)
+        if (hipMemcpyAsync(got.data(), device, bytes, hipMemcpyDeviceToHost, on) != hipSuccess || hipStreamSynchronize(on) != hipSuccess) return bytes;
+        size_t wrong = 0;
+        for (size_t k = 0; k < count; ++k)
+            for (int b = 0; b < 4; ++b) wrong += ((sent[k] >> (8 * b)) & 0xffu) != ((got[k] >> (8 * b)) & 0xffu);
+        return wrong;
+    };
+    hipError_t err = hipMalloc(reinterpret_cast<void**>(&src), bytes);
+    if (err == hipSuccess) err = hipMalloc(reinterpret_cast<void**>(&dst), bytes);
+    if (err == hipSuccess) err = hipMalloc(reinterpret_cast<void**>(&gathered), bytes);
+    if (err == hipSuccess) err = hipEventCreate(&t0);
+    if (err == hipSuccess) err = hipEventCreate(&t1);
+    // what is sent is produced on the CALLER's stream (as a step's positions are); the exchange stream waits for `ready`
+    if (err == hipSuccess) err = hipMemcpyAsync(src, sent.data(), bytes, hipMemcpyHostToDevice, on);
+    if (err == hipSuccess) err = hipMemsetAsync(dst, 0xa5, bytes, on);
+    if (err == hipSuccess) err = hipMemsetAsync(gathered, 0x5a, bytes, on);
+    if (err == hipSuccess) {
+        // (1) GroupStart; Send(to self); Recv(from self); GroupEnd -- exactly one round of exchange_tiles
+        const int rc = nb_comm_self_transfer_f32(comm, src, dst, count, 1, 1, stream, t0, t1);
+        if (rc >= NB_ERR_RCCL_BASE) refuse("ncclSend/ncclRecv (grouped, to self)", rc - NB_ERR_RCCL_BASE, &report->send_recv_status);
+        else if (rc != 0) err = static_cast<hipError_t>(rc);
+        else {
+            err = hipStreamWaitEvent(on, c->arrived[0], 0);  // the consumer of a tile waits for its event, on the compute stream
+            if (err == hipSuccess) report->send_recv_wrong_bytes = wrong_bytes(dst);
+            if (err == hipSuccess) err = hipEventElapsedTime(&report->send_recv_ms, t0, t1);
+        }
+    }
+    if (err == hipSuccess) {
+        // (2) ncclAllGather as nb_allgather_* issues it; out of place first (bytes to check), then in place (the product's form)
+        err = hipEventRecord(c->ready, on);
+        if (err == hipSuccess) err = hipStreamWaitEvent(c->stream, c->ready, 0);
+        if (err == hipSuccess) err = hipEventRecord(t0, c->stream);
+        if (err == hipSuccess) {
+            int rc = lib->AllGather(src, gathered, count, ncclFloat32, c->nccl, c->stream);
+            if (rc == 0) rc = lib->AllGather(gathered, gathered, count, ncclFloat32, c->nccl, c->stream);
+            if (rc != 0) refuse("ncclAllGather", rc, &report->all_gather_status);
+            else {
+                err = hipEventRecord(t1, c->stream);
+                if (err == hipSuccess) err = hipEventRecord(c->arrived[0], c->stream);
+                if (err == hipSuccess) err = hipStreamWaitEvent(on, c->arrived[0], 0);
+                if (err == hipSuccess) report->all_gather_wrong_bytes = wrong_bytes(gathered);
+                if (err == hipSuccess) err = hipEventElapsedTime(&report->all_gather_ms, t0, t1);
+            }
+        }
+    }
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipStreamSynchronize(on);
+    if (t0) (void)hipEventDestroy(t0);
+    if (t1) (void)hipEventDestroy(t1);
+    for (float* p : {src, dst, gathered})
+        if (p) (void)hipFree(p);
+    if (err != hipSuccess) {
+        (void)hipGetLastError();
+        return static_cast<int>(err);
+    }
+    if (result == 0 && (report->send_recv_wrong_bytes != 0 || report->all_gather_wrong_bytes != 0)) result = NB_ERR_UNSUPPORTED;
+    return result;
 }
 
 int nb_comm_info(nb_comm_t comm, int* rank, int* world, int* device) {

@@ -46,6 +46,33 @@ NB_API int nb_emulate_pair_rank_f64(double* new_positions, const double* old_pos
 NB_API int nb_comm_reaction_exchange_f32(nb_comm_t comm, unsigned num_bodies, nb_stream_t stream);
 NB_API int nb_comm_reaction_exchange_f64(nb_comm_t comm, unsigned num_bodies, nb_stream_t stream);
 
+/* ---- the REAL transport on a one-GPU box.  RCCL refuses two ranks on one device, so everything with more than one rank is
+ * tested against a transport double (tests/fake_rccl); what one GPU can still prove against the real library is the binding
+ * itself -- the hand-resolved entry points, the dlopen inside whatever process this is, the stream and event semantics.
+ * nb_comm_selftest_open: a communicator of ONE rank that does own an RCCL communicator (nb_comm_init_rank binds no transport
+ * for a world of one); `id` from nb_comm_unique_id.  nb_comm_selftest_f32: on that communicator, `bytes` of a known pattern
+ * produced on `stream`; on the communicator's exchange stream, after the `ready` event: GroupStart, Send(to self),
+ * Recv(from self), GroupEnd, the tile's event, which `stream` waits for before it reads the bytes back; then ncclAllGather out
+ * of place and in place the same way.  Returns 0 when every call was accepted and every byte arrived; the report says which
+ * call refused (status = NB_ERR_RCCL_BASE + ncclResult_t) or how many bytes differ.  Blocking.
+ * nb_comm_self_transfer_f32: the measuring form (tools/exchange_contention.py): `rounds` self send/recv pairs of `count` floats
+ * each in one group or a group per round, asynchronous, `begin` / `end` recorded on the exchange stream around them.
+ * nb_comm_transport_info: version (ncclGetVersion) and file of the RCCL a communicator is bound to (0 / "" for a world of one
+ * made by nb_comm_init_rank: none bound). */
+typedef struct nb_comm_selftest {
+    int    rccl_version;
+    int    send_recv_status, all_gather_status;
+    float  send_recv_ms, all_gather_ms;            /* on the exchange stream, events around the calls */
+    size_t send_recv_wrong_bytes, all_gather_wrong_bytes;
+    char   refused_call[64];
+    char   library_path[256];
+} nb_comm_selftest_t;
+NB_API int nb_comm_selftest_open(nb_comm_t* comm, const void* id /* NB_COMM_ID_BYTES */);
+NB_API int nb_comm_selftest_f32(nb_comm_t comm, size_t bytes, nb_stream_t stream, nb_comm_selftest_t* report);
+NB_API int nb_comm_self_transfer_f32(nb_comm_t comm, const float* src, float* dst, size_t count, int rounds, int one_group, nb_stream_t after,
+                                     nb_event_t begin, nb_event_t end);
+NB_API int nb_comm_transport_info(nb_comm_t comm, int* rccl_version, char* library_path, size_t path_bytes);
+
 /* An event recorded between the forces kernel and the finish kernel of every ONE-GPU pairwise step from now on (NULL = none):
  * bench.py times the two kernels of the headline step separately with it, after the timed region. */
 NB_API int nb_set_pair_probe_event(nb_event_t event);

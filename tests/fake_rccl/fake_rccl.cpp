@@ -363,6 +363,12 @@ void leave(World* world) {
 
 }  // namespace
 
+FAKE_API int ncclGetVersion(int* version) {  // 0: no RCCL release -- what a record shows when the double was bound
+    if (version == nullptr) return kInvalidArgument;
+    *version = 0;
+    return kSuccess;
+}
+
 FAKE_API int ncclGetUniqueId(ncclUniqueId* id) {
     if (id == nullptr) return kInvalidArgument;
     std::memset(id->internal, 0, sizeof(id->internal));

@@ -65,8 +65,8 @@ def test_strict_translation_unit_has_no_fused_multiply_add():
     mk = open(os.path.join(ROOT, "cuda-nbody_amd", "csrc", "Makefile")).read()
     rule = re.search(r"nbody_strict\.o:.*?\n\t(.*)\n", mk).group(1)
     assert "-ffp-contract=off" in rule
-    fast_rule = re.search(r"nbody_fast\.o:.*?\n\t(.*)\n", mk).group(1)
-    assert "-ffp-contract=off" not in fast_rule
+    fast_rule = re.search(r"^%\.o: %\.hip.*?\n\t(.*)\n", mk, re.M).group(1)  # (every other object: the pattern rule)
+    assert "-ffp-contract=off" not in fast_rule and "-ffp-contract" not in re.search(r"^COMMON\s*:=(.*)$", mk, re.M).group(1)
 
 
 def test_launch_plan_heuristics_without_gpu(pkg):
@@ -450,13 +450,19 @@ def test_sliced_pairwise_plan_without_gpu(pkg):
 
 def test_makefile_rebuilds_an_object_when_any_header_it_includes_changes():
     """PairArgs / FinishArgs / Shard cross translation units BY VALUE: an object built against an older nbody_kernels.h launches
-    kernels with a shifted argument block (round 4 met that as a GPU memory fault after one new field).  Every object rule of
-    csrc/Makefile must therefore list every header its source includes, directly or through another header of ours."""
+    kernels with a shifted argument block (round 4 met that as a GPU memory fault after one new field).  Since round 5 the
+    COMPILER writes the dependencies (-MMD -MP, one .d file per object, included by csrc/Makefile): after a build, every header a
+    source includes -- directly or through another header of ours -- must be in that object's .d file, and touching a header
+    must make `make -q` say the library is out of date."""
     import re
+    import subprocess
 
     csrc = os.path.join(ROOT, "cuda-nbody_amd", "csrc")
     with open(os.path.join(csrc, "Makefile")) as fh:
-        rules = {m.group(1): m.group(2).split() for m in re.finditer(r"^(\w+)\.o:(.*)$", fh.read(), re.M)}
+        mk = fh.read()
+    assert "-MMD -MP" in mk and re.search(r"^-include \$\(OBJS:\.o=\.d\)$", mk, re.M)
+    assert not re.search(r"^\w+\.o:.*\.h\b", mk, re.M), "an object rule lists headers by hand again"
+    subprocess.run(["make", "-s", "-j", "8", "-C", csrc], check=True, capture_output=True)
 
     def includes(path, seen):
         with open(path) as fh:
@@ -468,11 +474,56 @@ def test_makefile_rebuilds_an_object_when_any_header_it_includes_changes():
         return seen
 
     sources = sorted(f for f in os.listdir(csrc) if f.endswith(".hip") and f.startswith("nbody_"))
-    assert {s[:-4] for s in sources} == set(rules), (sources, sorted(rules))
+    objects = re.search(r"^OBJS\s*:=\s*(.*)$", mk, re.M).group(1).split()
+    assert {s[:-4] + ".o" for s in sources} == set(objects), (sources, objects)
     for src in sources:
-        listed = {os.path.normpath(os.path.join(csrc, p)) for p in rules[src[:-4]]}
+        with open(os.path.join(csrc, src[:-4] + ".d")) as fh:
+            words = fh.read().replace("\\\n", " ").split()
+        listed = {os.path.normpath(os.path.join(csrc, w.rstrip(":"))) for w in words}
         missing = includes(os.path.join(csrc, src), set()) - listed
-        assert not missing, f"{src[:-4]}.o does not depend on {sorted(os.path.relpath(m, csrc) for m in missing)}"
+        assert not missing, f"{src[:-4]}.d does not list {sorted(os.path.relpath(m, csrc) for m in missing)}"
+    # and make acts on it: an up-to-date tree, then one header touched
+    assert subprocess.run(["make", "-q", "-C", csrc], capture_output=True).returncode == 0
+    header = os.path.join(csrc, "nbody_kernels.h")
+    stat = os.stat(header)
+    try:
+        os.utime(header, None)
+        assert subprocess.run(["make", "-q", "-C", csrc], capture_output=True).returncode == 1
+        would = subprocess.run(["make", "-n", "-C", csrc], capture_output=True, text=True).stdout
+        for obj in ("nbody_comm.o", "nbody_pair.o", "nbody_capi.o", "nbody_fast.o", "nbody_strict.o"):
+            assert f"-o {obj}" in would, obj
+    finally:
+        os.utime(header, ns=(stat.st_atime_ns, stat.st_mtime_ns))
+    assert subprocess.run(["make", "-q", "-C", csrc], capture_output=True).returncode == 0
+
+
+def test_rccl_entry_points_match_the_rccl_header_at_compile_time(tmp_path):
+    """csrc/rccl_api.h spells the function-pointer types nbody_comm.hip calls RCCL through (the library binds RCCL with dlsym and
+    includes no RCCL header).  `make check-rccl-abi` compiles a host-only unit that includes the image's rccl.h and static_asserts
+    that each type IS decltype(&nccl...), that the enums the product passes as int are 4-byte enums with the values it uses, and
+    that ncclUniqueId is the 128-byte struct it passes by value.  The check has teeth: with one argument of ncclSend's type
+    swapped it no longer compiles."""
+    import shutil
+    import subprocess
+
+    csrc = os.path.join(ROOT, "cuda-nbody_amd", "csrc")
+    if not os.path.exists("/opt/rocm/include/rccl/rccl.h"):
+        import pytest
+
+        pytest.skip("no RCCL header in this image")
+    done = subprocess.run(["make", "-s", "-C", csrc, "check-rccl-abi"], capture_output=True, text=True)
+    assert done.returncode == 0, done.stderr[-3000:]
+    with open(os.path.join(csrc, "nbody_comm.hip")) as fh:
+        product = fh.read()
+    assert '#include "rccl_api.h"' in product and "nb_rccl::SendFn" in product and "(*Send)(" not in product  # (no second spelling of the types)
+    for name in ("rccl_api.h", "rccl_abi_check.cpp"):
+        shutil.copy(os.path.join(csrc, name), tmp_path / name)
+    text = (tmp_path / "rccl_api.h").read_text()
+    good = "using SendFn           = Result (*)(const void*, size_t, DataType, int, Comm, hipStream_t);"
+    assert good in text
+    (tmp_path / "rccl_api.h").write_text(text.replace(good, "using SendFn           = Result (*)(const void*, size_t, int, DataType, Comm, hipStream_t);"))
+    broken = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "rccl_abi_check.cpp"], cwd=tmp_path, capture_output=True, text=True)
+    assert broken.returncode != 0 and "static assertion failed" in broken.stderr
 
 
 def test_pair_plan_fills_whole_rounds_at_any_body_count(pkg):

@@ -213,3 +213,33 @@ print("RC", rc, lib.nb_error_string(rc).decode(), comms[0], comms[1])
 
     m = re.search(r"RC (\d+) (RCCL: .+) (\S+) (\S+)$", out.stdout.strip())
     assert m and 20000 < int(m.group(1)) < 20010 and m.group(3) == "None" and m.group(4) == "None", out.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("torch_first", [False, True])
+def test_real_rccl_self_loop_through_the_hand_resolved_entry_points(torch_first):
+    """VERDICT r4 item 1a.  Everything with more than one rank runs against the transport double; what one GPU can prove against
+    the REAL RCCL is the binding: nb_comm_unique_id + nb_comm_selftest_open make a communicator of one rank that owns a real
+    ncclComm (ncclGetUniqueId, ncclCommInitRank), nb_comm_selftest_f32 sends a pattern to itself through ncclGroupStart /
+    ncclSend / ncclRecv / ncclGroupEnd on the communicator's exchange stream with exchange_tiles' ready / arrived events, then
+    ncclAllGather out of place and in place, and compares every byte.  Once in a plain process (the RCCL under /opt/rocm) and
+    once with torch imported first (torch's own copy, as in bench.py); a child process under a 120 s timeout -- a third-party
+    library must not be able to hang the suite.  First run: profiles/round5_rccl_selfloop.txt."""
+    import json
+    import subprocess
+    import sys
+
+    env = dict(os.environ)
+    for name in ("NBODY_RCCL_LIB", "NCCL_DEBUG", "FAKE_RCCL_IPC"):
+        env.pop(name, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rccl_selfloop.py"), "--bytes", "393216,2097152", *(["--torch"] if torch_first else [])],
+                         capture_output=True, text=True, timeout=120, env=env)
+    lines = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    assert out.returncode == 0 and lines, (out.stdout[-2000:], out.stderr[-2000:])
+    opened, calls, closed = lines[0], lines[1:-1], lines[-1]
+    assert opened["rccl_version"] >= 20000 and "fake" not in opened["rccl_library"] and os.path.basename(opened["rccl_library"]).startswith("librccl.so")
+    assert ("/torch/lib/" in opened["rccl_library"]) == torch_first  # the RCCL that belongs to the process's HIP runtime is the one bound
+    assert len(calls) == 4 and closed["failed_calls"] == 0
+    for c in calls:
+        assert c["rc"] == 0 and c["send_recv_status"] == 0 and c["all_gather_status"] == 0 and c["refused_call"] == ""
+        assert c["send_recv_wrong_bytes"] == 0 and c["all_gather_wrong_bytes"] == 0 and 0 < c["send_recv_ms"] < 50 and 0 < c["all_gather_ms"] < 50
