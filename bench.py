@@ -234,6 +234,26 @@ def main():
     # copy by SONAME.  The other order puts two HIP runtimes in the process and the second sees no device.
     import torch
 
+    distributed_env = world > 1 or "RANK" in os.environ
+    stage = {"name": "start-up", "since": time.monotonic()}
+
+    def enter(name):
+        """where this rank is (for the headline watchdog and the launcher: both read stderr)"""
+        stage["name"], stage["since"] = name, time.monotonic()
+
+    headline_watchdog = None
+    if distributed_env:
+        print(f"[bench rank {rank}] torch imported", file=sys.stderr, flush=True)  # (IMPORTED_MARK: the launcher's bring-up clock starts here)
+
+        def stuck():
+            sys.stderr.write(f"[bench rank {rank}] no headline after {args.headline_timeout:.0f} s: stuck in '{stage['name']}' for {time.monotonic() - stage['since']:.0f} s; leaving with status 5\n")
+            sys.stderr.flush()
+            os._exit(5)
+
+        headline_watchdog = threading.Timer(args.headline_timeout, stuck)
+        headline_watchdog.daemon = True
+        headline_watchdog.start()
+
     # The bodies come from the process-global libc rand() stream (the reference's randomise_bodies does), so they are drawn NOW:
     # while this process has a single thread.  Later, torch.distributed's store and gloo threads are running and may draw from
     # the same stream in between (seen once in round 3: two runs of one command that differed in a few bodies).
@@ -264,6 +284,7 @@ def main():
         # The default process group is gloo, always: rendezvous, barriers, the unique-id broadcast, collective decisions and
         # the time reduction.  The data path is either the product's own RCCL communicator behind the C-ABI (--exchange rccl)
         # or, for the torch.distributed re-implementation (--exchange torch|allgather), a separate "nccl" group.
+        enter("torch.distributed rendezvous (gloo)")
         dist.init_process_group("gloo")
 
         def torch_rccl_group():
@@ -329,6 +350,7 @@ def main():
             return bool(flag.item())
 
         if args.exchange == "rccl":
+            enter("C-ABI communicator bring-up (nb_comm_unique_id / nb_comm_init_rank / nb_comm_set_workspace / first exchange)")
             bufs = [pos_t, pos_t.clone()]
             acc_t = torch.zeros_like(pos_t)
             problem = None
@@ -375,6 +397,7 @@ def main():
 
             finish = capi_rank.finish
         else:
+            enter(f"bring-up of the torch.distributed exchange ({args.exchange})")
             host_gather = None
             if args.exchange in ("host", "staged"):
                 class _Done:
@@ -436,9 +459,13 @@ def main():
     # (a child process per rank reading two sysfs files of the rank's own card; see bench_support.ChipWatch.  Rank 0's goes into `roofline`,
     # every rank's into `ranks_seen`: on a multi-GPU node the cards need not be granted the same clock)
     chip = ChipWatch(None if args.no_chip_watch else pci_address(torch, local_rank))
+    if distributed:  # (BRINGUP_MARK: what the launcher waits for before it trusts an attempt with its full time)
+        print(f"[bench rank {rank}] up: exchange {args.exchange}, {'pairwise across the ranks' if pairwise else 'one-sided'}, {world} rank(s)", file=sys.stderr, flush=True)
+    enter("warm-up steps")
     for _ in range(args.warmup):
         step()
     fence()
+    enter("timed steps")
     chip.start()
     ev0, ev1 = pkg.Event(), pkg.Event()
     t0 = time.perf_counter()
@@ -451,6 +478,9 @@ def main():
     elapsed = time.perf_counter() - t0
     chip.stop()
     ev1.synchronize()
+    if headline_watchdog is not None:
+        headline_watchdog.cancel()
+    enter("after the timed region")
     stream_ms_per_step = ev0.elapsed_ms(ev1) / args.steps  # HIP events on the launch stream: this rank's step, kernels only at N = 1
 
     if distributed:

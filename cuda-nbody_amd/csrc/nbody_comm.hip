@@ -128,7 +128,11 @@ struct Comm {
     std::vector<hipEvent_t> react_ready;   // [world/2 + 1] pairwise step: "the reaction sums for partner s are in the send buffer" (compute stream)
     std::vector<hipEvent_t> react_arrived; // [world/2 + 1] ... "round s of the reaction exchange is done" (exchange stream)
     std::vector<Comm*> group;              // all local ranks of this communicator (just {this} with one process per GPU)
+    bool        loopback = false;          // nb_comm_loopback_open (tuning header): rank / world are NOMINAL, the ncclComm has one rank and every peer is this rank itself
 };
+
+// the RCCL rank behind rank `logical` of the communicator (a loopback rank sends to, and receives from, itself)
+inline int peer_of(const Comm* c, int logical) { return c->loopback ? 0 : logical; }
 
 constexpr int kNoteWords = 8;  // {workspace bytes, min slice, pair plan overrides R S C, spare}
 
@@ -246,8 +250,8 @@ int exchange_tiles(const std::vector<Comm*>& locals, void* const* positions, uns
             Comm*      c    = locals[k];
             const int  dst  = (c->rank - s + G) % G, src = (c->rank + s) % G;
             char*      base = static_cast<char*>(positions[k]);
-            rc              = lib->Send(base + static_cast<size_t>(c->rank) * slice_bodies * bytes_per_body, slice_values, nccl_type, dst, c->nccl, c->stream);
-            if (rc == 0) rc = lib->Recv(base + static_cast<size_t>(src) * slice_bodies * bytes_per_body, slice_values, nccl_type, src, c->nccl, c->stream);
+            rc              = lib->Send(base + static_cast<size_t>(c->rank) * slice_bodies * bytes_per_body, slice_values, nccl_type, peer_of(c, dst), c->nccl, c->stream);
+            if (rc == 0) rc = lib->Recv(base + static_cast<size_t>(src) * slice_bodies * bytes_per_body, slice_values, nccl_type, peer_of(c, src), c->nccl, c->stream);
         }
         if (one_group) continue;
         const int end = lib->GroupEnd();
@@ -450,8 +454,8 @@ template <typename T> int reaction_exchange(const std::vector<Comm*>& locals, co
             Comm*     c    = locals[k];
             T* const  work = static_cast<T*>(c->workspace);
             const int to = (c->rank + static_cast<int>(s)) % G, from = (c->rank - static_cast<int>(s) + G) % G;
-            rc              = lib->Send(work + plan.send_at + (s - 1) * plane3, plane3, Api<T>::nccl_type, to, c->nccl, c->stream);
-            if (rc == 0) rc = lib->Recv(work + plan.recv_at + (s - 1) * plane3, plane3, Api<T>::nccl_type, from, c->nccl, c->stream);
+            rc              = lib->Send(work + plan.send_at + (s - 1) * plane3, plane3, Api<T>::nccl_type, peer_of(c, to), c->nccl, c->stream);
+            if (rc == 0) rc = lib->Recv(work + plan.recv_at + (s - 1) * plane3, plane3, Api<T>::nccl_type, peer_of(c, from), c->nccl, c->stream);
         }
         const int end = lib->GroupEnd();
         if (rc == 0) rc = end;
@@ -676,8 +680,9 @@ int nb_comm_unique_id(void* id) {
     return nccl_status(rc);
 }
 
-// `alone_too`: bind RCCL and make a real communicator even for a world of one (nb_comm_selftest_open: the self-loop check)
-static int init_rank(nb_comm_t* comm, const void* id, int world, int rank, bool alone_too) {
+// `alone_too`: bind RCCL and make a real communicator even for a world of one (nb_comm_selftest_open: the self-loop check);
+// `loopback`: the ncclComm has ONE rank whatever `world` says -- rank r of a nominal world whose every peer is itself
+static int init_rank(nb_comm_t* comm, const void* id, int world, int rank, bool alone_too, bool loopback = false) {
     NB_KEEP_RAND_STREAM;
     if (!comm || (!id && (world > 1 || alone_too)) || world < 1 || rank < 0 || rank >= world) return NB_ERR_INVALID_ARGUMENT;
     *comm     = nullptr;
@@ -695,8 +700,9 @@ static int init_rank(nb_comm_t* comm, const void* id, int world, int rank, bool 
     if (transport) {
         ncclUniqueId uid;
         std::memcpy(uid.internal, id, sizeof(uid.internal));
-        rc = nccl_status(lib->CommInitRank(&c->nccl, world, uid, rank));
+        rc = nccl_status(loopback ? lib->CommInitRank(&c->nccl, 1, uid, 0) : lib->CommInitRank(&c->nccl, world, uid, rank));
     }
+    c->loopback = loopback;
     if (rc == 0) rc = make_resources(c);
     if (rc != 0) {
         if (c->nccl) (void)lib->CommDestroy(c->nccl);
@@ -791,8 +797,8 @@ int nb_comm_set_workspace(nb_comm_t comm, void* workspace, size_t workspace_byte
     int rc = lib->GroupStart();
     for (int s = 1; s < G && rc == 0; ++s) {
         const int dst = (c->rank - s + G) % G, src = (c->rank + s) % G;
-        rc              = lib->Send(c->notes + static_cast<size_t>(c->rank) * kNoteWords, kNoteWords * 2, ncclFloat32, dst, c->nccl, c->stream);  // (8 bytes = two 4-byte values)
-        if (rc == 0) rc = lib->Recv(c->notes + static_cast<size_t>(src) * kNoteWords, kNoteWords * 2, ncclFloat32, src, c->nccl, c->stream);
+        rc              = lib->Send(c->notes + static_cast<size_t>(c->rank) * kNoteWords, kNoteWords * 2, ncclFloat32, peer_of(c, dst), c->nccl, c->stream);  // (8 bytes = two 4-byte values)
+        if (rc == 0) rc = lib->Recv(c->notes + static_cast<size_t>(src) * kNoteWords, kNoteWords * 2, ncclFloat32, peer_of(c, src), c->nccl, c->stream);
     }
     const int end = lib->GroupEnd();
     if (rc == 0) rc = end;
@@ -854,6 +860,10 @@ int nb_comm_set_pair_min_slice(int min_bodies_per_rank) {
 // ---- the REAL transport on one GPU (tuning header): a communicator of one rank that does own an RCCL communicator, and a
 // self-loop through it with the event choreography of exchange_tiles -----------------------------------------------------------
 int nb_comm_selftest_open(nb_comm_t* comm, const void* id) { return init_rank(comm, id, 1, 0, true); }
+int nb_comm_loopback_open(nb_comm_t* comm, const void* id, int nominal_world, int nominal_rank) {
+    if (nominal_world < 2) return NB_ERR_INVALID_ARGUMENT;
+    return init_rank(comm, id, nominal_world, nominal_rank, true, true);
+}
 
 int nb_comm_transport_info(nb_comm_t comm, int* version, char* library_path, size_t path_bytes) {
     NB_KEEP_RAND_STREAM;
@@ -890,8 +900,8 @@ int nb_comm_self_transfer_f32(nb_comm_t comm, const float* src, float* dst, size
     int rc = one_group ? static_cast<int>(lib->GroupStart()) : 0;
     for (int k = 0; k < rounds && rc == 0; ++k) {
         if (!one_group) rc = lib->GroupStart();
-        if (rc == 0) rc = lib->Send(src + static_cast<size_t>(k) * count, count, ncclFloat32, c->rank, c->nccl, c->stream);
-        if (rc == 0) rc = lib->Recv(dst + static_cast<size_t>(k) * count, count, ncclFloat32, c->rank, c->nccl, c->stream);
+        if (rc == 0) rc = lib->Send(src + static_cast<size_t>(k) * count, count, ncclFloat32, peer_of(c, c->rank), c->nccl, c->stream);
+        if (rc == 0) rc = lib->Recv(dst + static_cast<size_t>(k) * count, count, ncclFloat32, peer_of(c, c->rank), c->nccl, c->stream);
         if (!one_group) {
             const int ended = lib->GroupEnd();
             if (rc == 0) rc = ended;
@@ -1033,6 +1043,7 @@ static int allgather_one(nb_comm_t comm, void* positions, unsigned num_bodies, s
     Comm* c = as_comm(comm);
     if (c == nullptr || positions == nullptr || c->group.size() != 1 || num_bodies % static_cast<unsigned>(c->world)) return NB_ERR_INVALID_ARGUMENT;
     if (c->world == 1) return 0;
+    if (c->loopback) return NB_ERR_UNSUPPORTED;  // (a collective over the nominal world has no one-rank form)
     Rccl* lib = rccl();
     if (lib == nullptr) return NB_ERR_UNSUPPORTED;
     DeviceScope  scope(c->device);

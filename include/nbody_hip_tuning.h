@@ -68,6 +68,13 @@ typedef struct nb_comm_selftest {
     char   library_path[256];
 } nb_comm_selftest_t;
 NB_API int nb_comm_selftest_open(nb_comm_t* comm, const void* id /* NB_COMM_ID_BYTES */);
+/* A LOOPBACK rank: rank `nominal_rank` of a `nominal_world`-rank communicator whose RCCL communicator has one rank -- every
+ * send goes to, every receive comes from, the rank itself.  nb_sharded_step_* on it launches exactly the kernels, RCCL calls,
+ * events and waits of that rank of a real multi-GPU step, on one GPU, with the real RCCL kernels competing for the chip; what
+ * "arrives" is the rank's own data, so the positions are meaningless after the first step and only the TIME means anything:
+ * a real step minus what the xGMI links would add (tools/exchange_contention.py, bench.py's one-GPU projection).
+ * nb_comm_set_workspace stays the collective it is (the notes travel to the rank itself). */
+NB_API int nb_comm_loopback_open(nb_comm_t* comm, const void* id /* NB_COMM_ID_BYTES */, int nominal_world, int nominal_rank);
 NB_API int nb_comm_selftest_f32(nb_comm_t comm, size_t bytes, nb_stream_t stream, nb_comm_selftest_t* report);
 NB_API int nb_comm_self_transfer_f32(nb_comm_t comm, const float* src, float* dst, size_t count, int rounds, int one_group, nb_stream_t after,
                                      nb_event_t begin, nb_event_t end);

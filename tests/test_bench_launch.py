@@ -24,7 +24,7 @@ def test_launcher_falls_back_and_reports_failure():
 
     if torch.cuda.is_available():
         pytest.skip("needs a host without a GPU: on a GPU box the first attempt would go on to RCCL")
-    out = run_bench("--gpus", "2", "--steps", "1", "--warmup", "0", "--bodies", "1024", "--no-cpu-baseline", "--launch-timeout", "240")
+    out = run_bench("--gpus", "2", "--steps", "1", "--warmup", "0", "--bodies", "1024", "--no-cpu-baseline", "--launch-timeout", "120", "--launch-budget", "480")
     assert out.returncode != 0
     order = [out.stderr.find(f"one more attempt with --exchange {name}") for name in ("torch", "allgather", "staged")]
     assert all(at >= 0 for at in order) and order == sorted(order), out.stderr[-2000:]
@@ -40,6 +40,61 @@ def test_launcher_does_not_retry_an_exchange_the_caller_chose():
     out = run_bench("--gpus", "2", "--steps", "1", "--warmup", "0", "--bodies", "1024", "--no-cpu-baseline", "--exchange", "allgather", "--launch-timeout", "240")
     assert out.returncode != 0
     assert "one more attempt" not in out.stderr
+
+
+def test_launcher_ends_hung_attempts_inside_its_budget(tmp_path):
+    """the launcher's fallbacks must be reachable inside what the caller allows the whole command.  Stand-in
+    ranks (self_launch's make_cmd): the first attempt imports and then never brings its exchange up (ended `bringup_s` after the
+    import mark), `--exchange torch` comes up and then hangs (ended at the attempt's limit), `--exchange allgather` reports.
+    The launcher must end both hung process groups, reach the third attempt, relay its line, return 0 -- all inside the budget."""
+    import time
+
+    rank = tmp_path / "stand_in_rank.py"
+    rank.write_text(
+        "import sys, time\n"
+        "print('[bench rank 0] torch imported', file=sys.stderr, flush=True)\n"
+        "how = sys.argv[sys.argv.index('--exchange') + 1] if '--exchange' in sys.argv else 'rccl'\n"
+        "if how == 'rccl':\n"
+        "    time.sleep(600)\n"
+        "print(f'[bench rank 0] up: exchange {how}', file=sys.stderr, flush=True)\n"
+        "if how == 'torch':\n"
+        "    time.sleep(600)\n"
+        "print('{\"metric\": \"stand-in\", \"exchange\": \"%s\"}' % how, flush=True)\n")
+    driver = tmp_path / "driver.py"
+    driver.write_text(
+        f"import sys, time\nsys.path.insert(0, {ROOT!r})\nimport bench\n"
+        f"t0 = time.monotonic()\n"
+        f"rc = bench.self_launch(2, False, attempt_s=8.0, budget_s=60.0, bringup_s=2.0, import_s=5.0, make_cmd=lambda extra, port: [sys.executable, {str(rank)!r}] + extra)\n"
+        f"print('LAUNCHER', rc, round(time.monotonic() - t0, 1), flush=True)\n")
+    t0 = time.monotonic()
+    out = subprocess.run([sys.executable, str(driver)], capture_output=True, text=True, timeout=120)
+    took = time.monotonic() - t0
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert "LAUNCHER 0 " in out.stdout and out.stdout.count('"metric"') == 1 and '"exchange": "allgather"' in out.stdout
+    at = [out.stderr.find(text) for text in ("no rank has its exchange up", "one more attempt with --exchange torch", "ranks still running after 8 s", "one more attempt with --exchange allgather")]
+    assert all(a >= 0 for a in at) and at == sorted(at), out.stderr[-3000:]
+    assert "--exchange staged" not in out.stderr  # (the third attempt reported: nothing plainer was needed)
+    assert took < 40, took  # 2-3 s (no bring-up) + 8 s (hung after bring-up) + the attempt that reports: well inside the 60 s budget
+
+
+def test_launcher_stops_when_its_budget_is_spent(tmp_path):
+    """Every attempt hangs after bring-up: the launcher shares what is left of the budget among the attempts that may follow, ends
+    each, and returns a failure INSIDE the budget instead of running into the caller's own limit."""
+    import time
+
+    rank = tmp_path / "stand_in_rank.py"
+    rank.write_text("import sys, time\nprint('[bench rank 0] torch imported', file=sys.stderr, flush=True)\nprint('[bench rank 0] up: x', file=sys.stderr, flush=True)\ntime.sleep(600)\n")
+    driver = tmp_path / "driver.py"
+    driver.write_text(
+        f"import sys\nsys.path.insert(0, {ROOT!r})\nimport bench\n"
+        f"rc = bench.self_launch(2, False, attempt_s=100.0, budget_s=16.0, bringup_s=2.0, import_s=5.0, make_cmd=lambda extra, port: [sys.executable, {str(rank)!r}] + extra)\n"
+        f"print('LAUNCHER', rc, flush=True)\n")
+    t0 = time.monotonic()
+    out = subprocess.run([sys.executable, str(driver)], capture_output=True, text=True, timeout=120)
+    took = time.monotonic() - t0
+    assert out.returncode == 0 and "LAUNCHER 0" not in out.stdout and "LAUNCHER" in out.stdout, out.stderr[-3000:]
+    assert out.stderr.count("ranks still running after") >= 2 and '"metric"' not in out.stdout
+    assert took < 16.0 + 12.0, took  # the budget, plus ending the last group and the interpreter start-ups
 
 
 def test_chip_watch_reads_the_card_with_the_devices_pci_address(tmp_path):
