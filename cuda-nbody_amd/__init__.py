@@ -169,6 +169,7 @@ TUNING_SIGNATURES = {
     "nb_comm_reaction_exchange_f64": (_ci, [_vp, _cu, _vp]),
     "nb_set_pair_probe_event": (_ci, [_vp]),
     "nb_set_memory_budget": (_ci, [_sz]),
+    "nb_set_alloc_limit": (_ci, [_sz]),
     "nb_lds_optin_count": (_ci, [_P(_ci)]),
     "nb_comm_selftest_open": (_ci, [_P(_vp), _vp]),
     "nb_comm_loopback_open": (_ci, [_P(_vp), _vp, _ci, _ci]),

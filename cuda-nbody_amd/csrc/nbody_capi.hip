@@ -36,6 +36,7 @@ std::atomic<int>   g_pair_slices{0};                                    // nb_se
 // without ever being the call that triggers a lazy initialisation.
 std::atomic<size_t> g_total_memory[64] = {};  // per device, filled by the one-time warm-up below (0: unknown)
 std::atomic<size_t> g_memory_budget{0};       // nb_set_memory_budget: what to assume instead (0: the device's own figure)
+std::atomic<size_t> g_alloc_limit{0};         // nb_set_alloc_limit: nb_alloc requests above this are made to fail IN THE RUNTIME (0: none)
 
 int current_device_ready() {
     static std::atomic<int> cu_count[64] = {};
@@ -359,7 +360,14 @@ int nb_alloc(void** device_ptr, size_t bytes) {
     NB_KEEP_RAND_STREAM;
     if (!device_ptr) return NB_ERR_INVALID_ARGUMENT;
     (void)current_device_ready();
-    return static_cast<int>(hipMalloc(device_ptr, bytes));
+    // (tests of the out-of-memory fall-backs: a request above the limit is turned into one the runtime itself refuses, so that what
+    // follows -- the status, the thread's last error -- is exactly what a real refusal leaves behind)
+    if (const size_t limit = g_alloc_limit.load(); limit != 0 && bytes > limit) bytes = ~size_t{0} >> 4;
+    const auto err = hipMalloc(device_ptr, bytes);
+    // The caller gets the status; the thread's "last error" is cleared, so that the fall-backs built on a refused allocation
+    // (halve the workspace and try again, step without one) do not see it again as the status of their next launch.
+    if (err != hipSuccess) (void)hipGetLastError();
+    return static_cast<int>(err);
 }
 int nb_free(void* device_ptr) {
     NB_KEEP_RAND_STREAM; return static_cast<int>(hipFree(device_ptr)); }
@@ -388,7 +396,10 @@ int nb_host_alloc_mapped(void** host_ptr, void** device_ptr, size_t bytes) {
     if (!host_ptr || !device_ptr) return NB_ERR_INVALID_ARGUMENT;
     (void)current_device_ready();
     auto err = hipHostMalloc(host_ptr, bytes, hipHostMallocMapped | hipHostMallocPortable);
-    if (err != hipSuccess) return static_cast<int>(err);
+    if (err != hipSuccess) {
+        (void)hipGetLastError();  // (as nb_alloc: the status goes to the caller, not to the next launch)
+        return static_cast<int>(err);
+    }
     err = hipHostGetDevicePointer(device_ptr, *host_ptr, 0);
     if (err != hipSuccess) {
         (void)hipHostFree(*host_ptr);
@@ -534,6 +545,11 @@ int nb_set_pair_slices_override(int slices) {
 
 int nb_set_memory_budget(size_t bytes) {
     g_memory_budget.store(bytes);
+    return 0;
+}
+
+int nb_set_alloc_limit(size_t bytes) {
+    g_alloc_limit.store(bytes);
     return 0;
 }
 

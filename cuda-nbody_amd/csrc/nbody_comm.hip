@@ -120,6 +120,7 @@ struct Comm {
     void*       workspace = nullptr;       // caller-owned scratch memory (nb_comm_set_workspace)
     size_t      workspace_bytes = 0;
     size_t      agreed_bytes    = 0;       // one process per rank: the SMALLEST amount any rank of the communicator was lent (set_workspace's exchange)
+    size_t      agreed_budget   = 0;       // ... and the smallest device memory budget of any rank (0 until that exchange: this rank's own)
     bool        one_group       = true;    // nb_comm_set_exchange_grouping: all G-1 position rounds of a step in one RCCL group
     unsigned long long* notes   = nullptr; // [world][kNoteWords] device memory of the communicator: what set_workspace's ranks tell each other
     hipStream_t aux       = nullptr;       // pairwise step: every other rectangle runs here, so that the tails and launch gaps of
@@ -134,7 +135,7 @@ struct Comm {
 // the RCCL rank behind rank `logical` of the communicator (a loopback rank sends to, and receives from, itself)
 inline int peer_of(const Comm* c, int logical) { return c->loopback ? 0 : logical; }
 
-constexpr int kNoteWords = 8;  // {workspace bytes, min slice, pair plan overrides R S C, spare}
+constexpr int kNoteWords = 8;  // {workspace bytes, min slice, pair plan overrides R S C, device memory budget, spare}
 
 bool default_one_group() {  // NBODY_EXCHANGE_ONE_GROUP=0 flips the default of nb_comm_set_exchange_grouping
     const char* v = std::getenv("NBODY_EXCHANGE_ONE_GROUP");
@@ -318,7 +319,7 @@ struct PairShard {
     size_t       self_at = 0, react_d_at = 0, react_r_at = 0, send_at = 0, recv_at = 0, elements = 0;  // offsets in T
 };
 
-template <typename T> PairShard plan_pair_shard(unsigned num_bodies, int G, int min_slice) {
+template <typename T> PairShard plan_pair_shard(unsigned num_bodies, int G, int min_slice, size_t budget) {
     constexpr unsigned W = sizeof(T) == 4 ? 2 : 1;
     PairShard          p;
     if (G < 2 || num_bodies % static_cast<unsigned>(G)) return p;
@@ -358,9 +359,9 @@ template <typename T> PairShard plan_pair_shard(unsigned num_bodies, int G, int 
     p.recv_at    = p.send_at + p.H * plane3;
     p.elements   = p.recv_at + p.H * plane3;
     // as on one GPU: a workspace beyond a third of the device's memory is never asked for (it grows with the square of the slice:
-    // ~16 GB per rank at 1 Mi bodies over 2 ranks) -- the step is then the one-sided tile schedule
-    const size_t budget = nb::device_memory_budget();
-    p.applies           = budget == 0 || p.elements * sizeof(T) <= budget / 3;
+    // ~16 GB per rank at 1 Mi bodies over 2 ranks) -- the step is then the one-sided tile schedule.  `budget` is the SMALLEST
+    // memory of any rank's device (budget_everywhere): the answer must be the communicator's, not this rank's.
+    p.applies = budget == 0 || p.elements * sizeof(T) <= budget / 3;
     return p;
 }
 
@@ -508,10 +509,28 @@ size_t lent_everywhere(const std::vector<Comm*>& locals) {
     return least;
 }
 
+// The device memory a workspace is held against (a third of it at most): the smallest figure of any rank of the communicator, so
+// that every rank reaches the same verdict -- ranks on devices of different sizes, or with different nb_set_memory_budget figures,
+// would otherwise disagree about the layout of a step, which is the one thing they must never do.
+size_t own_budget(const Comm* c) {
+    DeviceScope scope(c->device);
+    return nb::device_memory_budget();
+}
+size_t budget_everywhere(const std::vector<Comm*>& locals) {
+    const Comm* first = locals.front();
+    size_t      least = ~size_t{0};
+    if (static_cast<int>(first->group.size()) == first->world) {
+        for (const Comm* c : first->group) least = std::min(least, own_budget(c));
+    } else {
+        for (const Comm* c : locals) least = std::min(least, c->agreed_budget != 0 ? std::min(c->agreed_budget, own_budget(c)) : own_budget(c));
+    }
+    return least == ~size_t{0} ? 0 : least;
+}
+
 template <typename T> bool step_is_pairwise(const std::vector<Comm*>& locals, unsigned num_bodies, int mode, PairShard* plan_out) {
     const int G = locals.front()->world;
     if (G < 2 || mode != NB_MODE_FAST) return false;
-    const PairShard plan = plan_pair_shard<T>(num_bodies, G, g_pair_shard_min.load());
+    const PairShard plan = plan_pair_shard<T>(num_bodies, G, g_pair_shard_min.load(), budget_everywhere(locals));
     if (!plan.applies || lent_everywhere(locals) < plan.elements * sizeof(T)) return false;
     if (plan_out != nullptr) *plan_out = plan;
     return true;
@@ -596,7 +615,7 @@ template <typename T> int comm_workspace_bytes(nb_comm_t comm, unsigned num_bodi
     *bytes = 0;
     if (c->world == 1) return sizeof(T) == 4 ? nb_workspace_bytes_f32(num_bodies, mode, bytes) : nb_workspace_bytes_f64(num_bodies, mode, bytes);
     if (mode != NB_MODE_FAST) return 0;
-    const PairShard plan = plan_pair_shard<T>(num_bodies, c->world, g_pair_shard_min.load());
+    const PairShard plan = plan_pair_shard<T>(num_bodies, c->world, g_pair_shard_min.load(), budget_everywhere(std::vector<Comm*>{c}));
     if (plan.applies) *bytes = plan.elements * sizeof(T);
     return 0;
 }
@@ -604,7 +623,7 @@ template <typename T> int comm_workspace_bytes(nb_comm_t comm, unsigned num_bodi
 // no communicator and no exchange (what would arrive from other ranks is whatever the workspace holds), on one GPU.
 template <typename T> int emulate_pair_rank(T* new_pos, const T* old_pos, T* vel, void* workspace, size_t* workspace_bytes, unsigned num_bodies, int world, int rank, T dt, T damping, T eps2, nb_stream_t stream) {
     if (workspace_bytes == nullptr || world < 2 || rank < 0 || rank >= world) return NB_ERR_INVALID_ARGUMENT;
-    const PairShard plan = plan_pair_shard<T>(num_bodies, world, g_pair_shard_min.load());
+    const PairShard plan = plan_pair_shard<T>(num_bodies, world, g_pair_shard_min.load(), nb::device_memory_budget());
     if (!plan.applies) return NB_ERR_UNSUPPORTED;
     const size_t need = plan.elements * sizeof(T);
     if (workspace == nullptr || *workspace_bytes < need) {  // a size query
@@ -657,9 +676,15 @@ template <typename T> int comm_layout(nb_comm_t comm, unsigned num_bodies, int m
     Comm* c = as_comm(comm);
     if (c == nullptr || pairwise == nullptr || num_bodies == 0) return NB_ERR_INVALID_ARGUMENT;
     if (c->world == 1) {
-        size_t need = 0;
-        const int rc = sizeof(T) == 4 ? nb_workspace_bytes_f32(num_bodies, mode, &need) : nb_workspace_bytes_f64(num_bodies, mode, &need);
-        *pairwise    = (rc == 0 && need != 0 && c->workspace != nullptr && c->workspace_bytes >= need) ? 1 : 0;
+        // the step hands nb_integrate_ws_* whatever was lent, and that takes the form with the fewest slices that FIT (one tournament
+        // or the sliced one): the same question, asked the same way -- not "is there room for one tournament"
+        size_t fits = 0;
+        if (c->workspace == nullptr || c->workspace_bytes == 0) {
+            *pairwise = 0;
+            return 0;
+        }
+        const int rc = sizeof(T) == 4 ? nb_workspace_bytes_capped_f32(num_bodies, mode, c->workspace_bytes, &fits) : nb_workspace_bytes_capped_f64(num_bodies, mode, c->workspace_bytes, &fits);
+        *pairwise    = (rc == 0 && fits != 0) ? 1 : 0;
         return rc;
     }
     *pairwise = step_is_pairwise<T>(std::vector<Comm*>{c}, num_bodies, mode, nullptr) ? 1 : 0;
@@ -790,7 +815,7 @@ int nb_comm_set_workspace(nb_comm_t comm, void* workspace, size_t workspace_byte
     int         ovr_r = 0, ovr_s = 0, ovr_c = 0;
     nb::pair_plan_overrides(&ovr_r, &ovr_s, &ovr_c);
     unsigned long long mine[kNoteWords] = {static_cast<unsigned long long>(workspace_bytes), static_cast<unsigned long long>(g_pair_shard_min.load()), static_cast<unsigned long long>(ovr_r),
-                                           static_cast<unsigned long long>(ovr_s), static_cast<unsigned long long>(ovr_c), 0, 0, 0};
+                                           static_cast<unsigned long long>(ovr_s), static_cast<unsigned long long>(ovr_c), static_cast<unsigned long long>(nb::device_memory_budget()), 0, 0};
     auto err = hipMemcpyAsync(c->notes + static_cast<size_t>(c->rank) * kNoteWords, mine, sizeof(mine), hipMemcpyHostToDevice, c->stream);
     if (err == hipSuccess) err = hipStreamSynchronize(c->stream);  // (`mine` is pageable stack memory: the copy must be over before it goes away)
     if (err != hipSuccess) return static_cast<int>(err);
@@ -807,15 +832,17 @@ int nb_comm_set_workspace(nb_comm_t comm, void* workspace, size_t workspace_byte
     err = hipMemcpyAsync(all.data(), c->notes, all.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream);
     if (err == hipSuccess) err = hipStreamSynchronize(c->stream);
     if (err != hipSuccess) return static_cast<int>(err);
-    unsigned long long least = ~0ull;
+    unsigned long long least = ~0ull, least_budget = ~0ull;
     bool               same  = true;
     for (int r = 0; r < G; ++r) {
         const unsigned long long* note = all.data() + static_cast<size_t>(r) * kNoteWords;
         least = std::min(least, note[0]);
+        if (note[5] != 0) least_budget = std::min(least_budget, note[5]);  // (0: that rank knows no figure -- no bound from it)
         for (int w = 1; w < 5; ++w) same = same && note[w] == mine[w];
     }
     if (!same) return NB_ERR_INVALID_ARGUMENT;  // (every rank sees the same notes, so every rank returns this)
-    c->agreed_bytes = static_cast<size_t>(least);
+    c->agreed_bytes  = static_cast<size_t>(least);
+    c->agreed_budget = least_budget == ~0ull ? 0 : static_cast<size_t>(least_budget);
     return 0;
 }
 

@@ -580,6 +580,7 @@ template <typename T, int R, int LPT, int BLOCK> hipError_t launch_wavesplit(con
         if (const auto err = allow_large_lds<&integrate_bodies_wavesplit<T, R, LPT, BLOCK>>(); err != hipSuccess) return err;
     }
     if (prepare_only) return hipSuccess;
+    (void)hipGetLastError();  // a launch reports ITS OWN error: the call returns, and clears, the thread's last error whatever left it (a refused allocation, say)
     hipLaunchKernelGGL((integrate_bodies_wavesplit<T, R, LPT, BLOCK>), dim3(p.grid_blocks), dim3(BLOCK), p.lds_bytes, stream, s);
     return hipGetLastError();
 }
@@ -600,6 +601,7 @@ template <typename T, int R, int S, int LPT> hipError_t launch_one(const Shard<T
         if (const auto err = allow_large_lds<&integrate_bodies_fast<T, R, S, LPT>>(); err != hipSuccess) return err;
     }
     if (prepare_only) return hipSuccess;  // graph capture arms the attribute before hipStreamBeginCapture
+    (void)hipGetLastError();  // a launch reports ITS OWN error: the call returns, and clears, the thread's last error whatever left it (a refused allocation, say)
     hipLaunchKernelGGL((integrate_bodies_fast<T, R, S, LPT>), dim3(p.grid_blocks), dim3(block_threads_for(S)), p.lds_bytes, stream, s);
     return hipGetLastError();
 }

@@ -11,7 +11,7 @@
 //     one-sided kernel does.  The bodies j come 64 at a time, ONE PER LANE (a coalesced vector load), together with three
 //     reaction sums per lane, and ROTATE through the wave: after each step everything that belongs to the body j moves on
 //     by one lane with DPP wave_ror:1 (a full 64-lane rotation exists on gfx9/CDNA; checked on the chip,
-//     tools/scratch/wave_ror_check.hip).  After 64 steps every body i of the wave has met every body j of the tile and the
+//     tools/wave_ror_check.hip).  After 64 steps every body i of the wave has met every body j of the tile and the
 //     reaction sums are back in their home lanes.  Per step and lane: R x (14 v_pk_* + 2 v_rsq_f32) + 9 v_mov_b32_dpp for
 //     4R directed interactions; measured in isolation (tools/sym_microbench.hip, profiles/round3_pairwise_loop_microbench.txt)
 //     275 SIMD cycles per step at R = 4 with 4 waves per SIMD = 17.2 cycles per directed interaction against 30.75.
@@ -574,6 +574,7 @@ template <typename T, int R, int S> hipError_t launch_rs(const PairArgs<T>& args
         if (const auto err = allow_large_lds<&pair_forces<T, R, S>>(); err != hipSuccess) return err;
     }
     if (prepare_only) return hipSuccess;
+    (void)hipGetLastError();  // a launch reports ITS OWN error: the call returns, and clears, the thread's last error whatever left it (a refused allocation, say)
     hipLaunchKernelGGL((pair_forces<T, R, S>), dim3(grid), dim3(64 * S), lds_bytes, stream, args);
     return hipGetLastError();
 }
@@ -719,12 +720,14 @@ template <typename T> hipError_t launch_pair_tile(const PairArgs<T>& args, const
 
 template <typename T> hipError_t launch_pair_reduce(const T* react, unsigned react_plane, unsigned slots, T* out, unsigned out_plane, unsigned count, hipStream_t stream) {
     if (count == 0) return hipSuccess;
+    (void)hipGetLastError();  // a launch reports ITS OWN error: the call returns, and clears, the thread's last error whatever left it (a refused allocation, say)
     hipLaunchKernelGGL(pair_reduce<T>, dim3((count + 63) / 64), dim3(256), 0, stream, react, react_plane, slots, out, out_plane, count);
     return hipGetLastError();
 }
 
 template <typename T> hipError_t launch_pair_finish(const FinishArgs<T>& args, hipStream_t stream) {
     if (args.count == 0) return hipSuccess;
+    (void)hipGetLastError();  // a launch reports ITS OWN error: the call returns, and clears, the thread's last error whatever left it (a refused allocation, say)
     hipLaunchKernelGGL(pair_finish<T>, dim3((args.count + 63) / 64), dim3(256), 0, stream, args);
     return hipGetLastError();
 }

@@ -412,6 +412,7 @@ template <typename T> hipError_t launch_strict(const Shard<T>& s, int block_size
         if (const auto err = allow_large_lds<&integrate_bodies_strict<T>>(); err != hipSuccess) return err;
     }
     if (prepare_only) return hipSuccess;  // graph capture arms the attribute before hipStreamBeginCapture
+    (void)hipGetLastError();  // a launch reports ITS OWN error: the call returns, and clears, the thread's last error whatever left it (a refused allocation, say)
     hipLaunchKernelGGL(integrate_bodies_strict<T>, dim3(blocks), dim3(p), smem, stream, s);
     return hipGetLastError();
 }

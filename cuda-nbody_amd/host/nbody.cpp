@@ -6,9 +6,11 @@
 //                     --tipsy=<file> -i,--iterations=<n> --blockSize=<n>      (single-dash spellings accepted too)
 //   extensions      : --numdevices=<n> | --devices=<list> (the NVIDIA sample's -numdevices, which this fork of it dropped)
 //                     --mode=fast|strict  --config=shell|random|expand  --demo=<0..6>  --steps=<n>  --dump=<file>
-//                     --seed=<n>  --graph  --no-workspace  --workspace-mib=<n>  --inject-error=<x> (test hook for --compare)
+//                     --seed=<n>  --graph  --no-workspace  --workspace-mib=<n>  --inject-error=<x> (test hook for --compare)  --alloc-limit-mib=<n> (test hook)
 #include "compute.hpp"
 #include "integrate_nbody_hip.hpp"
+
+#include "../../include/nbody_hip_tuning.h"  // (the --alloc-limit-mib test hook)
 
 #include <charconv>
 #include <cstdio>
@@ -50,6 +52,7 @@ struct Options {
     bool                  graph = false;
     bool                  no_workspace = false;
     std::size_t           workspace_mib = 0;  // 0: no bound of our own
+    std::size_t           alloc_limit_mib = 0;  // test hook: device allocations above this are refused (0: none)
     std::vector<int>      devices;  // --numdevices=<n> (devices 0..n-1) or --devices=<a,b,...>: bodies sharded over several GPUs
     std::optional<std::size_t> demo;   // row of Compute::demo_params (the reference reaches them from the viewer's keys only)
     double                inject_error = 0.0;
@@ -86,6 +89,7 @@ Options:
   --workspace-mib UINT        Spend at most this many MiB on that workspace (the pair tournament is then cut into slices that share
                               one region of reaction planes; default: what the library asks for, at most a third of the device's memory)
   --inject-error FLOAT        Test hook: added to body 0's x of the fast result before --compare checks it
+  --alloc-limit-mib UINT      Test hook: device allocations above this many MiB are refused (the out-of-memory fall-backs)
 )";
 
 template <typename I> auto parse_number(std::string_view text, I& out) -> bool {
@@ -160,6 +164,9 @@ auto parse_args(int argc, char** argv) -> std::pair<Status, Options> {
         } else if (name == "workspace-mib" || name == "workspace_mib") {
             const auto v = take_value();
             ok           = v && parse_number(*v, options.workspace_mib);
+        } else if (name == "alloc-limit-mib") {
+            const auto v = take_value();
+            ok           = v && parse_number(*v, options.alloc_limit_mib);
         } else if (name == "seed") {
             const auto v = take_value();
             unsigned   s = 0;
@@ -252,6 +259,7 @@ auto main(int argc, char** argv) -> int {
         nbody_hip::integration_mode() = cmd_options.mode;
         nbody_hip::use_workspace()    = !cmd_options.no_workspace;
         nbody_hip::workspace_cap_bytes() = cmd_options.workspace_mib << 20;
+        if (cmd_options.alloc_limit_mib != 0) (void)nb_set_alloc_limit(cmd_options.alloc_limit_mib << 20);
 
         const auto compare_to_cpu = (cmd_options.compare || cmd_options.qatest) && (!cmd_options.cpu);
         const auto headless_run   = cmd_options.benchmark || compare_to_cpu || cmd_options.steps > 0 || !cmd_options.dump.empty();

@@ -88,6 +88,11 @@ NB_API int nb_set_pair_probe_event(nb_event_t event);
  * for): 0 = the device's own total; tests of the guard set a small figure. */
 NB_API int nb_set_memory_budget(size_t bytes);
 
+/* Tests of the out-of-memory fall-backs (halve the workspace and ask again; step without one): every nb_alloc request above
+ * `bytes` is refused BY THE RUNTIME (the request is replaced by one no device can serve), 0 = no limit.  The CLI's
+ * --alloc-limit-mib sets it. */
+NB_API int nb_set_alloc_limit(size_t bytes);
+
 /* How many (kernel, device) pairs have been granted more than 64 KiB of dynamic LDS so far (the opt-in is made once per
  * kernel instantiation and device, on first use, and before any graph capture). */
 NB_API int nb_lds_optin_count(int* count);

@@ -15,6 +15,8 @@ What the vectors are (and are not):
     velocity .w 0 are the start-up values and never change) of the positions after 1 and 10 steps (fp32: the velocities after
     10 steps too), and the SHA-256 of the initial arrays instead of the arrays: the test draws them with the oracle's
     randomise_bodies restatement (pinned to the reference's code, see above) and checks the digest.
+    PARITY UNPINNED like the others: its later states are the restatement's own output -- only the initial state, through the
+    digest of randomise_bodies' arrays, goes back to reference code.
 Parameters: SHELL config, demo_params[0] (dt 0.016, softening 0.1, damping 1.0), cluster/velocity scale by N
 (src/nbody/compute.cpp:74-92).  Sizes: N = 8, 256, 1024 (steps 0/1/10/100) and 4096 (steps 0/1/10 -- the fixtures stay small),
 the four sizes SURVEY 8(c) names.

@@ -3,6 +3,9 @@ to the CPU path's trajectories on one GPU, with exactly the envelope the one-sid
 tests/test_gpu_parity.py.  The reference's own acceptance check compares the GPU system's positions with the CPU system's
 after stepping both from one state (/root/reference/src/nbody/compute_cuda.cpp:294-333); the arithmetic being compared with is
 BodySystemCPU<T>::update (bodysystemcpu.cpp:149-243 fp32, :245-299 fp64) as restated in oracle/nbody_oracle.c.
+PARITY UNPINNED: every golden trajectory used here (tests/golden/*.npz, the 16 384-body compact fixtures included) is that
+restatement's own output -- the reference holds no fixture for `update` and its translation unit cannot be built unmodified in
+this image (oracle section); only the initial states are pinned to reference code (randomise_bodies).
 
 The layout applies by default above 8 192 bodies (fp32) / above 6 144 (fp64), and the committed full trajectories stop at
 4 096 bodies, so: (a) the layout is FORCED at the golden sizes, in every compiled geometry (nb_set_pair_plan_override with
@@ -94,6 +97,43 @@ def test_pairwise_fp64_vs_golden_every_geometry(gpu, n, plan):
     with forced_pairwise(gpu, plan):
         errs, _ = trajectory_errors(gpu, n, np.float64, g, golden_steps(g))
     assert_fp64_envelope(errs)
+
+
+def _dealing(n, R, S, C):
+    """launch_pair_tile's rule for the diagonal launch of an fp32 system (csrc/nbody_pair.hip, nbody_kernels.h), restated: 2 = equal
+    whole units + QUARTERS of the units left over (needs LDS for the quarters' sums), 1 / 0 = every unit whole, slots interleaved /
+    blocked -- what is left when 3 072 B per tail unit no longer fit under the 160 KiB"""
+    block = 64 * R * 2
+    blocks = -(-n // block)
+    units = (blocks // 2 + 1) * R * 2
+    slots = C * S
+    tail = -(-(units % slots) // C)
+    lds = S * 3 * R * 2 * 64 * 4 + 256 + tail * 4 * 3 * 64 * 4
+    if lds <= 160 * 1024:
+        return 2, tail
+    return (1 if (C > 1 and units % slots != 0 and units // slots < 34) else 0), tail
+
+
+@pytest.mark.parametrize("n,plan,deal", [(2048, (8, 12, 1), 0), (3072, (8, 12, 1), 0), (1024, (8, 12, 2), 1), (7168, (8, 12, 2), 1), (16384, (8, 12, 7), 1), (16384, (8, 12, 5), 2)])
+def test_pairwise_whole_unit_dealing_when_the_lds_has_no_room_for_quarters(gpu, oracle, n, plan, deal):
+    """twelve waves of R = 8 leave 16 128 B of the 160 KiB for the quarters' sums -- five tail units; with more, the
+    PRODUCT build deals every unit whole (PairArgs::deal 0: blocked, one workgroup per block; 1: interleaved), the branch that
+    otherwise only the NB_PAIR_NO_QUARTERS build takes.  Each case is checked to take the dealing it is here for, then held to the
+    CPU path over 1 and 10 steps like every other geometry."""
+    assert _dealing(n, *plan)[0] == deal, _dealing(n, *plan)
+    assert (_dealing(n, *plan)[1] > 5) == (deal != 2)
+    pos0, vel0 = oracle.startup_state(n, np.float32)
+    ref = {0: (pos0.copy(), vel0.copy())}
+    p, v = pos0.copy(), vel0.copy()
+    for s in (1, 10):
+        oracle.update(p, v, DT, steps=s - max(k for k in ref if k < s))
+        ref[s] = (p.copy(), v.copy())
+    g = {"pos_0": pos0, "vel_0": vel0, "pos_1": ref[1][0], "pos_10": ref[10][0]}
+    with forced_pairwise(gpu, plan):
+        errs, _ = trajectory_errors(gpu, n, np.float32, g, [1, 10])
+        again, _ = trajectory_errors(gpu, n, np.float32, g, [1, 10])
+    assert_fp32_envelope(errs)
+    assert errs[10].tobytes() == again[10].tobytes()  # (bit-reproducible: the dealing is a fixed function of the geometry)
 
 
 @pytest.mark.parametrize("n", [8, 63, 200])

@@ -69,7 +69,7 @@ def main():
         pos0, vel0 = make_bodies(n, np.float32)
         bufs = [pkg.DeviceBuffer(pos0.nbytes) for _ in range(4)]  # pos a, pos b, vel, acc
         bufs[0].upload(pos0), bufs[1].upload(pos0), bufs[2].upload(vel0)
-        job = pkg.ShardedRank(None, G, r, [bufs[0].ptr, bufs[1].ptr], bufs[2].ptr, bufs[3].ptr, n, np.float32, pkg.NB_MODE_FAST, 256, stream, comm=comm)
+        job = pkg.ShardedRank(None, G, r, [bufs[0].ptr.value, bufs[1].ptr.value], bufs[2].ptr.value, bufs[3].ptr.value, n, np.float32, pkg.NB_MODE_FAST, 256, stream, comm=comm)
         need = job.workspace_bytes()
         work = pkg.DeviceBuffer(need) if need else None
         for reserve in [int(x) for x in args.reserve.split(",")]:
