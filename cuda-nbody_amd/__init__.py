@@ -163,6 +163,7 @@ TUNING_SIGNATURES = {
     "nb_set_pair_plan_override": (_ci, [_ci, _ci, _ci, _ci]),
     "nb_set_pair_slices_override": (_ci, [_ci]),
     "nb_comm_set_pair_min_slice": (_ci, [_ci]),
+    "nb_set_late_diagonal": (_ci, [_ci]),
     "nb_emulate_pair_rank_f32": (_ci, [_vp, _vp, _vp, _vp, _P(_sz), _cu, _ci, _ci, _cf, _cf, _vp]),
     "nb_emulate_pair_rank_f64": (_ci, [_vp, _vp, _vp, _vp, _P(_sz), _cu, _ci, _ci, _cd, _cd, _vp]),
     "nb_comm_reaction_exchange_f32": (_ci, [_vp, _cu, _vp]),

@@ -135,7 +135,7 @@ struct Comm {
 // the RCCL rank behind rank `logical` of the communicator (a loopback rank sends to, and receives from, itself)
 inline int peer_of(const Comm* c, int logical) { return c->loopback ? 0 : logical; }
 
-constexpr int kNoteWords = 8;  // {workspace bytes, min slice, pair plan overrides R S C, device memory budget, spare}
+constexpr int kNoteWords = 8;  // {workspace bytes, min slice, pair plan overrides R S C, device memory budget, late diagonal, spare}
 
 bool default_one_group() {  // NBODY_EXCHANGE_ONE_GROUP=0 flips the default of nb_comm_set_exchange_grouping
     const char* v = std::getenv("NBODY_EXCHANGE_ONE_GROUP");
@@ -313,18 +313,22 @@ template <> struct Api<double> {
 // tiles' kernels; the position exchange is unchanged, so every rank still ends a step with all positions).
 struct PairShard {
     bool         applies = false;
-    nb::PairGeom diag{}, rect{}, rect_upper{};  // rect_upper: the split rectangle as the HIGHER partner runs it (half of its blocks of bodies i: twice the workgroups per block)
+    nb::PairGeom diag{}, diag_late{}, rect{}, rect_upper{};  // rect_upper: the split rectangle as the HIGHER partner runs it (half of its blocks of bodies i: twice the workgroups per block)
     unsigned     ni = 0, block = 0, blocks = 0, plane = 0, half = 0, H = 0, diag_slots = 0;
+    unsigned     early_units = 0, late_units = 0;  // the diagonal's units per block as two launches: block offsets q < q_split first, the rest LAST (late_units == 0: one launch)
     bool         even = false;
     size_t       self_at = 0, react_d_at = 0, react_r_at = 0, send_at = 0, recv_at = 0, elements = 0;  // offsets in T
 };
 
+std::atomic<int> g_late_diagonal{1};  // nb_set_late_diagonal (tuning header): 0 = the diagonal as ONE launch, first (the order up to round 4), for A/B timings
+
 template <typename T> PairShard plan_pair_shard(unsigned num_bodies, int G, int min_slice, size_t budget) {
+    const bool late_diagonal = g_late_diagonal.load() != 0;
     constexpr unsigned W = sizeof(T) == 4 ? 2 : 1;
     PairShard          p;
     if (G < 2 || num_bodies % static_cast<unsigned>(G)) return p;
     p.ni = num_bodies / static_cast<unsigned>(G);
-    if (p.ni < static_cast<unsigned>(min_slice > 0 ? min_slice : 2048) || G / 2 > nb::kMaxRecv || G / 2 + 1 > nb::kMaxSelfSets) return p;
+    if (p.ni < static_cast<unsigned>(min_slice > 0 ? min_slice : 2048) || G / 2 > nb::kMaxRecv || G / 2 + 2 > nb::kMaxSelfSets) return p;
     int ovr_r = 0, ovr_s = 0, ovr_c = 0;
     nb::pair_plan_overrides(&ovr_r, &ovr_s, &ovr_c);  // (tuning sweeps: tools/pair_rank_probe.py)
     // R = 8 from slices of 32 768 bodies (round 4, one rank's kernels alone on one GPU: 65 536-body slices 2.54 -> 2.45 ms, 32 768-body
@@ -347,13 +351,24 @@ template <typename T> PairShard plan_pair_shard(unsigned num_bodies, int G, int 
         while (C > 1 && units < C * static_cast<unsigned>(S)) C /= 2;
         return C;
     };
-    p.diag = {R, S, splits((p.blocks / 2 + 1) * static_cast<unsigned>(R) * W)};
+    // The diagonal -- the one piece of a rank's work that needs nothing from another rank and owes nothing to one -- goes out as
+    // TWO launches (round 5): the block offsets q = 0 .. q_split-1 first, under which the position tiles arrive, and the rest as
+    // the rank's LAST force kernel, under which the last rectangle's reaction sums travel to their owner (the finish kernel of
+    // that owner waits for them: with the diagonal whole and first, that hop sat bare at the end of every step).  Whole offsets
+    // per launch keep their reaction slots apart; each launch has its own i-side sums.  nb_comm_set_late_diagonal(comm, 0): one launch.
+    {
+        const unsigned tiles = static_cast<unsigned>(R) * W, offsets = p.blocks / 2 + 1;
+        const unsigned first = late_diagonal && offsets >= 2 ? (offsets + 1) / 2 : offsets;
+        p.early_units = first * tiles, p.late_units = (offsets - first) * tiles;
+    }
+    p.diag      = {R, S, splits(p.early_units)};
+    p.diag_late = {R, S, p.late_units != 0 ? splits(p.late_units) : 0u};
     p.rect = {R, S, splits((p.ni + 63) / 64)};
     p.rect_upper = p.rect;
     if (p.even && p.blocks >= 2 && (p.ni + 63) / 64 >= p.rect.splits * 2 * static_cast<unsigned>(S) * 2) p.rect_upper.splits = p.rect.splits * 2;
     const size_t plane3 = 3 * static_cast<size_t>(p.plane);
     p.self_at    = 0;
-    p.react_d_at = p.self_at + (p.diag.splits + static_cast<size_t>(p.H - 1) * p.rect.splits + p.rect_upper.splits) * plane3;  // (the last rectangle is the one that may be split)
+    p.react_d_at = p.self_at + (p.diag.splits + p.diag_late.splits + static_cast<size_t>(p.H - 1) * p.rect.splits + p.rect_upper.splits) * plane3;  // (the last rectangle is the one that may be split)
     p.react_r_at = p.react_d_at + p.diag_slots * plane3;
     p.send_at    = p.react_r_at + 2 * p.blocks * plane3;  // (two regions: the rectangles alternate between two streams)
     p.recv_at    = p.send_at + p.H * plane3;
@@ -370,11 +385,36 @@ std::atomic<int> g_pair_shard_min{0};  // nb_set_pair_plan_override(.., min_bodi
 // The kernels ONE rank launches in a pairwise step, up to (not including) the finish kernel: the diagonal, then per partner
 // the rectangle and the fold of its reaction sums into the send buffer.  `c` == nullptr: no communicator (nb_emulate_pair_rank_*:
 // kernel-time projection of a rank of a G-rank system on one GPU) -- no waits for tiles, no events.
+// `part`: kWholeStep = everything; kBeforeSends = up to the folds of the rectangles (what the reaction sends wait for), kAfterSends =
+// the late diagonal launch and the join of the second stream -- a communicator enqueues its reaction rounds between the two, so that
+// the last of them is under way before the rank's last force kernel.
+enum RankPart { kWholeStep = 0, kBeforeSends = 1, kAfterSends = 2 };
 template <typename T>
 int pair_rank_tiles(Comm* c, unsigned r, int G, const PairShard& plan, T* work, T* new_pos, const T* old_pos, T* vel, unsigned num_bodies, T dt, T damping, T eps2, hipStream_t stream, bool waiting, nb::FinishArgs<T>& f,
-                    hipStream_t aux, hipEvent_t aux_begin, hipEvent_t aux_done) {
+                    hipStream_t aux, hipEvent_t aux_begin, hipEvent_t aux_done, RankPart part = kWholeStep) {
     const unsigned ni     = plan.ni, own = r * ni;
     const size_t   plane3 = 3 * static_cast<size_t>(plan.plane);
+    nb::PairArgs<T> a{};
+    a.old_pos = old_pos, a.self = work + plan.self_at, a.n = num_bodies, a.eps2 = eps2;
+    a.self_origin = own, a.self_plane = plan.plane, a.react_plane = plan.plane;
+    // the diagonal: the rank's own slice against itself (its positions are local: nothing to wait for), as two launches (plan_pair_shard)
+    a.react = work + plan.react_d_at, a.react_origin = own;
+    a.i_begin = a.j_begin = own, a.i_count = a.j_count = ni, a.diag = 1, a.keep = 1;
+    auto late_diagonal_and_join = [&]() -> int {
+        if (plan.late_units != 0) {
+            a.self_first = plan.diag.splits, a.unit_begin = plan.early_units, a.unit_count = plan.late_units;
+            if (const auto err = nb::launch_pair_tile<T>(a, plan.diag_late, stream); err != hipSuccess) return static_cast<int>(err);
+            f.self_set[f.n_self++] = {plan.diag.splits, plan.diag_late.splits, 0u, ni};
+        }
+        if (aux != nullptr) {  // the finish kernel (on `stream`) needs the second stream's sums too
+            auto err = hipEventRecord(aux_done, aux);
+            if (err == hipSuccess) err = hipStreamWaitEvent(stream, aux_done, 0);
+            if (err != hipSuccess) return static_cast<int>(err);
+        }
+        return 0;
+    };
+    if (part == kAfterSends) return late_diagonal_and_join();
+
     f = {};
     f.old_pos = old_pos, f.new_pos = new_pos, f.vel = vel;
     f.self = work + plan.self_at, f.react = work + plan.react_d_at, f.recv = work + plan.recv_at, f.extra = nullptr;
@@ -382,18 +422,12 @@ int pair_rank_tiles(Comm* c, unsigned r, int G, const PairShard& plan, T* work, 
     f.self_plane = f.react_plane = f.recv_plane = plan.plane;
     f.react_slots = plan.diag_slots;
     f.dt = dt, f.damping = damping;
-
-    nb::PairArgs<T> a{};
-    a.old_pos = old_pos, a.self = work + plan.self_at, a.n = num_bodies, a.eps2 = eps2;
-    a.self_origin = own, a.self_plane = plan.plane, a.react_plane = plan.plane;
-    // the diagonal: the rank's own slice against itself (its positions are local: nothing to wait for)
-    a.react = work + plan.react_d_at, a.react_origin = own;
-    a.i_begin = a.j_begin = own, a.i_count = a.j_count = ni, a.diag = 1, a.keep = 1, a.self_first = 0;
     if (aux != nullptr) {  // the second stream joins in here: after everything the step's own stream has done so far
         auto err = hipEventRecord(aux_begin, stream);
         if (err == hipSuccess) err = hipStreamWaitEvent(aux, aux_begin, 0);
         if (err != hipSuccess) return static_cast<int>(err);
     }
+    a.self_first = 0, a.unit_begin = 0, a.unit_count = plan.late_units != 0 ? plan.early_units : 0u;
     if (const auto err = nb::launch_pair_tile<T>(a, plan.diag, stream); err != hipSuccess) return static_cast<int>(err);
     f.self_set[f.n_self++] = {0u, plan.diag.splits, 0u, ni};
     // the rectangles against the partners r+1 .. r+H, each as its positions arrive
@@ -407,14 +441,14 @@ int pair_rank_tiles(Comm* c, unsigned r, int G, const PairShard& plan, T* work, 
         if (c != nullptr && waiting) {
             if (const auto err = hipStreamWaitEvent(on, c->arrived[p], 0); err != hipSuccess) return static_cast<int>(err);
         }
-        a.diag = 0, a.keep = 1, a.react = work + plan.react_r_at + (other ? plan.blocks * plane3 : size_t{0});
+        a.diag = 0, a.keep = 1, a.unit_begin = a.unit_count = 0, a.react = work + plan.react_r_at + (other ? plan.blocks * plane3 : size_t{0});
         a.i_begin = own, a.i_count = ni, a.j_begin = p * ni, a.j_count = ni;
         if (plan.even && s == plan.H) {  // both partners list this pair of ranks: split the rectangle
             if (r < p) a.j_count = plan.half;
             else a.i_begin = own + plan.half, a.i_count = ni - plan.half;
         }
         a.react_origin = a.j_begin;
-        a.self_first   = plan.diag.splits + (s - 1) * plan.rect.splits;
+        a.self_first   = plan.diag.splits + plan.diag_late.splits + (s - 1) * plan.rect.splits;
         const nb::PairGeom& geom = (plan.even && s == plan.H && !(r < p)) ? plan.rect_upper : plan.rect;
         if (const auto err = nb::launch_pair_tile<T>(a, geom, on); err != hipSuccess) return static_cast<int>(err);
         f.self_set[f.n_self++] = {a.self_first, geom.splits, a.i_begin - own, a.i_count};
@@ -428,12 +462,11 @@ int pair_rank_tiles(Comm* c, unsigned r, int G, const PairShard& plan, T* work, 
         const unsigned q = (r + static_cast<unsigned>(G) - s) % static_cast<unsigned>(G);
         f.recv_set[f.n_recv++] = {0u, (plan.even && s == plan.H && q < r) ? plan.half : ni};
     }
-    if (aux != nullptr) {  // the finish kernel (on `stream`) needs the second stream's sums too
-        auto err = hipEventRecord(aux_done, aux);
-        if (err == hipSuccess) err = hipStreamWaitEvent(stream, aux_done, 0);
-        if (err != hipSuccess) return static_cast<int>(err);
-    }
-    return 0;
+    if (part == kBeforeSends) return 0;
+    // (no sends to place: the diagonal's second launch is simply the last force kernel)
+    a.diag = 1, a.keep = 1, a.react = work + plan.react_d_at, a.react_origin = own;
+    a.i_begin = a.j_begin = own, a.i_count = a.j_count = ni;
+    return late_diagonal_and_join();
 }
 
 // The reaction leg of a pairwise step: round s = send to rank r+s what was summed for its bodies, receive from r-s what it
@@ -479,10 +512,18 @@ int pair_sharded_step(const std::vector<Comm*>& locals, const PairShard& plan, T
         DeviceScope scope(c->device);
         const bool  waiting = c->in_flight == static_cast<const void*>(old_pos[k]);
         const int   rc = pair_rank_tiles<T>(c, static_cast<unsigned>(c->rank), G, plan, static_cast<T*>(c->workspace), new_pos[k], old_pos[k], vel[k], num_bodies, dt, damping, eps2,
-                                            reinterpret_cast<hipStream_t>(streams[k]), waiting, finish[k], c->aux, c->aux_begin, c->aux_done);
+                                            reinterpret_cast<hipStream_t>(streams[k]), waiting, finish[k], c->aux, c->aux_begin, c->aux_done, kBeforeSends);
         if (rc != 0) return rc;
     }
+    // every reaction round is enqueued (each waits for the fold of its rectangle) BEFORE the ranks' last force kernel: the late half of the diagonal
     if (const int rc = reaction_exchange<T>(locals, plan); rc != 0) return rc;
+    for (size_t k = 0; k < locals.size(); ++k) {
+        Comm*       c = locals[k];
+        DeviceScope scope(c->device);
+        const int   rc = pair_rank_tiles<T>(c, static_cast<unsigned>(c->rank), G, plan, static_cast<T*>(c->workspace), new_pos[k], old_pos[k], vel[k], num_bodies, dt, damping, eps2,
+                                            reinterpret_cast<hipStream_t>(streams[k]), false, finish[k], c->aux, c->aux_begin, c->aux_done, kAfterSends);
+        if (rc != 0) return rc;
+    }
     for (size_t k = 0; k < locals.size(); ++k) {
         Comm*       c = locals[k];
         DeviceScope scope(c->device);
@@ -815,7 +856,8 @@ int nb_comm_set_workspace(nb_comm_t comm, void* workspace, size_t workspace_byte
     int         ovr_r = 0, ovr_s = 0, ovr_c = 0;
     nb::pair_plan_overrides(&ovr_r, &ovr_s, &ovr_c);
     unsigned long long mine[kNoteWords] = {static_cast<unsigned long long>(workspace_bytes), static_cast<unsigned long long>(g_pair_shard_min.load()), static_cast<unsigned long long>(ovr_r),
-                                           static_cast<unsigned long long>(ovr_s), static_cast<unsigned long long>(ovr_c), static_cast<unsigned long long>(nb::device_memory_budget()), 0, 0};
+                                           static_cast<unsigned long long>(ovr_s), static_cast<unsigned long long>(ovr_c), static_cast<unsigned long long>(nb::device_memory_budget()),
+                                           static_cast<unsigned long long>(g_late_diagonal.load()), 0};
     auto err = hipMemcpyAsync(c->notes + static_cast<size_t>(c->rank) * kNoteWords, mine, sizeof(mine), hipMemcpyHostToDevice, c->stream);
     if (err == hipSuccess) err = hipStreamSynchronize(c->stream);  // (`mine` is pageable stack memory: the copy must be over before it goes away)
     if (err != hipSuccess) return static_cast<int>(err);
@@ -839,6 +881,7 @@ int nb_comm_set_workspace(nb_comm_t comm, void* workspace, size_t workspace_byte
         least = std::min(least, note[0]);
         if (note[5] != 0) least_budget = std::min(least_budget, note[5]);  // (0: that rank knows no figure -- no bound from it)
         for (int w = 1; w < 5; ++w) same = same && note[w] == mine[w];
+        same = same && note[6] == mine[6];
     }
     if (!same) return NB_ERR_INVALID_ARGUMENT;  // (every rank sees the same notes, so every rank returns this)
     c->agreed_bytes  = static_cast<size_t>(least);
@@ -878,6 +921,11 @@ int nb_emulate_pair_rank_f64(double* new_positions, const double* old_positions,
 }
 int nb_comm_reaction_exchange_f32(nb_comm_t comm, unsigned num_bodies, nb_stream_t stream) { return reaction_exchange_only<float>(comm, num_bodies, stream); }
 int nb_comm_reaction_exchange_f64(nb_comm_t comm, unsigned num_bodies, nb_stream_t stream) { return reaction_exchange_only<double>(comm, num_bodies, stream); }
+int nb_set_late_diagonal(int on) {
+    if (on != 0 && on != 1) return NB_ERR_INVALID_ARGUMENT;
+    g_late_diagonal.store(on);
+    return 0;
+}
 int nb_comm_set_pair_min_slice(int min_bodies_per_rank) {
     if (min_bodies_per_rank < 0) return NB_ERR_INVALID_ARGUMENT;
     g_pair_shard_min.store(min_bodies_per_rank);

@@ -126,6 +126,9 @@ template <typename T> struct PairArgs {
     unsigned blocks;        // NB = ceil(i_count / (64*I))
     unsigned splits;        // C workgroups per block
     unsigned diag, keep;
+    unsigned unit_begin, unit_count;  // diag = 1: the launch takes units [unit_begin, unit_begin + unit_count) of the tournament's (blocks/2 + 1) * I per block
+                                      // (unit u = tile u % I of block a + u / I); unit_count = 0: all of them.  Whole offsets q (multiples of I) keep the
+                                      // reaction slots of two such launches apart.  diag = 0: both 0.
     unsigned deal;          // how the units reach the waves (set by launch_pair_tile; see pair_forces): 0 whole units, slots blocked; 1 whole units, slots
                             // interleaved; 2 whole units in equal numbers and the units left over as quarters, one per SIMD of one workgroup
     unsigned self_first, self_origin, self_plane;

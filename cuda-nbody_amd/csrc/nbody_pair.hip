@@ -206,7 +206,7 @@ template <typename T, int R, int S> __global__ __launch_bounds__(64 * S) __attri
     const bool     even    = (NB & 1u) == 0;
     const bool     diag    = s.diag != 0;
     const unsigned j_end   = s.j_begin + s.j_count;
-    const unsigned n_units = diag ? (Q + 1) * TB : (s.j_count + 63) / 64;
+    const unsigned n_units = diag ? (s.unit_count != 0 ? s.unit_count : (Q + 1) * TB) : (s.j_count + 63) / 64;  // (a diagonal launch may take a RANGE of the tournament's units: PairArgs::unit_begin)
     const unsigned G       = s.splits * S;
     // Which units are this wave's.  s.deal == 2 (what launch_pair_tile takes when the LDS allows): the first floor(n_units / (C*S)) * C*S
     // units are dealt whole, unit u to slot u mod (C*S) = c*S + wave -- every wave the same number --, and each of the units left over
@@ -231,7 +231,7 @@ template <typename T, int R, int S> __global__ __launch_bounds__(64 * S) __attri
     const unsigned n_quarters = wg_tail > my_turn ? (wg_tail - my_turn + kPerSimd - 1) / kPerSimd : 0;
     const unsigned n_items    = n_whole + n_quarters;
     auto item_tail = [&](unsigned it) { return my_turn + (it - n_whole) * kPerSimd; };                  // which of the workgroup's tail units
-    auto item_unit = [&](unsigned it) { return it < n_whole ? g + it * G : dealt + c + item_tail(it) * s.splits; };
+    auto item_unit = [&](unsigned it) { return s.unit_begin + (it < n_whole ? g + it * G : dealt + c + item_tail(it) * s.splits); };  // (absolute: the tile and the offset q follow from it)
     auto item_shift = [&](unsigned it) { return it < n_whole ? 0u : 16u * my_quarter; };
 
     auto tile_first = [&](unsigned u) {
@@ -398,7 +398,7 @@ template <typename T, int R, int S> __global__ __launch_bounds__(64 * S) __attri
     __syncthreads();
     // the tail units of the workgroup: a body's four quarter sums, in quarter order, then the one store a whole unit would have made
     for (unsigned k = static_cast<unsigned>(wave); k < wg_tail; k += S) {
-        const unsigned u         = dealt + c + k * s.splits;
+        const unsigned u         = s.unit_begin + dealt + c + k * s.splits;
         const unsigned q         = u / TB;
         const bool     symmetric = diag ? (q != 0 && !(even && q == Q)) : (s.keep != 0);
         const unsigned j         = tile_first(u) + lane;
@@ -690,7 +690,7 @@ template <typename T> hipError_t launch_pair_tile(const PairArgs<T>& args, const
     const unsigned block     = 64u * static_cast<unsigned>(g.vectors_per_lane * W);
     a.blocks                 = (a.i_count + block - 1) / block;
     a.splits                 = g.splits;
-    const unsigned units = a.diag ? (a.blocks / 2 + 1) * static_cast<unsigned>(g.vectors_per_lane * W) : (a.j_count + 63) / 64;
+    const unsigned units = a.diag ? (a.unit_count != 0 ? a.unit_count : (a.blocks / 2 + 1) * static_cast<unsigned>(g.vectors_per_lane * W)) : (a.j_count + 63) / 64;
     unsigned       lds_bytes;
     {   // how the units reach the waves (see the kernel): equal whole units + quarters of the rest when the LDS has room for the quarters' sums
         const unsigned slots = g.splits * static_cast<unsigned>(g.waves), each = units / slots;

@@ -31,6 +31,12 @@ NB_API int nb_set_pair_slices_override(int slices);
 /* Smallest slice (bodies per rank) for which a multi-GPU step goes pairwise across the ranks; 0 = automatic (2 048). */
 NB_API int nb_comm_set_pair_min_slice(int min_bodies_per_rank);
 
+/* A rank's diagonal (its own slice against itself) in a pairwise multi-GPU step: 1 (default) = two launches, the first half of the
+ * block offsets first and the rest as the rank's LAST force kernel, so that the last reaction sums travel under local work;
+ * 0 = one launch, first (the order up to round 4) -- for A/B timings.  Process-global like the plan overrides; with one process
+ * per GPU every rank must set the same (nb_comm_set_workspace checks it).  Summation order, hence the last bits, differ. */
+NB_API int nb_set_late_diagonal(int on);
+
 /* Tuning / projection hook (bench.py --emulate-gpus): exactly the kernels that rank `rank` of a `world_size`-rank pairwise step
  * launches, on the current device, with no communicator and no exchange (what the other ranks would send is whatever the
  * workspace holds: the positions written are meaningless, the kernel time is the point).  workspace == NULL: *workspace_bytes

@@ -348,8 +348,14 @@ def test_pair_shard_plan_without_gpu(pkg):
     rc, b8 = need(262144, 8)
     # 32 768 bodies per rank: R = 8 -> 32 blocks of 1 024, C = 4 for the diagonal and the rectangles (128 workgroups per launch: two
     # rectangles run at once) -- 8 for the split rectangle at distance 4 as its higher partner runs it (half of its blocks of
-    # bodies i) --, H = 4 partners, 15 diagonal slots
-    assert rc == 0 and b8 == ((4 + 3 * 4 + 8) + 15 + 2 * 32 + 4 + 4) * 3 * 32768 * 4
+    # bodies i) --, H = 4 partners, 15 diagonal slots.  Round 5: the diagonal is two launches (offsets q = 0 .. 8 first, 9 .. 16 last),
+    # each with its own C = 4 planes of i-side sums; nb_set_late_diagonal(0) is the single launch of before
+    assert rc == 0 and b8 == ((4 + 4 + 3 * 4 + 8) + 15 + 2 * 32 + 4 + 4) * 3 * 32768 * 4
+    assert lib.nb_set_late_diagonal(2) == 10001 and lib.nb_set_late_diagonal(0) == 0
+    try:
+        assert need(262144, 8) == (0, ((4 + 3 * 4 + 8) + 15 + 2 * 32 + 4 + 4) * 3 * 32768 * 4)
+    finally:
+        assert lib.nb_set_late_diagonal(1) == 0
     rc, b2 = need(262144, 2)
     assert rc == 0 and b2 > b8
     assert need(262144, 8, fn=lib.nb_emulate_pair_rank_f64, dt=0.016)[0] == 0

@@ -13,9 +13,8 @@ import sqlite3
 
 
 def short(name):
-    name = re.sub(r"\(.*", "", name)
-    name = name.replace("void nb::", "").replace("nb::", "")
-    return name[:60]
+    m = re.search(r"(pair_forces|pair_finish|pair_reduce|integrate_bodies_\w+|ncclDevKernel_\w+|__amd_rocclr_\w+)(<[^(]*>)?", name)
+    return (m.group(1) + (m.group(2) or "")) [:60] if m else name[:60]
 
 
 def main():
