@@ -44,7 +44,7 @@ import __graft_entry__ as entry  # noqa: E402
 
 from bench_support import (CONFIG3_BODIES, ChipWatch, FP32_ISSUE_CEILING_INTERACTIONS_PER_S, FP32_VECTOR_PEAK_TFLOPS, FP64_ISSUE_CEILING_INTERACTIONS_PER_S,  # noqa: E402
                            FP64_VECTOR_PEAK_TFLOPS, cpu_baseline, make_bodies, multi_gpu_diagnostics, other_configs, pair_evaluations, pair_kernel_split,
-                           rank_projection)
+                           plan_dict, pmc_summary, rank_projection)
 
 
 def parse_args():
@@ -510,34 +510,37 @@ def main():
         dominant_ms = forces_ms if forces_ms is not None else stream_ms_per_step
         algorithmic_flops = flops_per * float(n) * float(n) / world  # per launch of the dominant kernel(s) of one rank's step
         achieved_tflops = algorithmic_flops / (dominant_ms * 1e-3) / 1e12
-        # HBM traffic cannot be counted from inside this process: it comes from the separate rocprofv3 --pmc passes
-        # of this same command (tools/profile.sh -> tools/summarize_prof.py), committed under profiles/.
-        traffic, traffic_src = None, None
-        plan_now = {"bodies_per_lane": plan.bodies_per_lane, "lane_groups": plan.lanes_per_body, "lds_tile_bodies": plan.tile_bodies,
-                    "grid": plan.grid_blocks, "lds_bytes": plan.lds_bytes}
-        if pair is not None:
-            plan_now = {"layout": "pairwise", "bodies_per_lane": pair.bodies_per_lane, "waves_per_block": pair.waves_per_block, "workgroups_per_block": pair.splits,
-                        "blocks": pair.blocks, "block_bodies": pair.block_bodies, "reaction_slots": pair.reaction_slots, "grid": pair.grid_blocks,
-                        "lds_bytes": pair.lds_bytes, "workspace_bytes": pair.workspace_bytes}
-        if world == 1 and args.mode == "fast":
-            import glob
-
-            tag = f"n{n}_{'f64' if args.fp64 else 'f32'}" + ("_pairwise" if pairwise else "")
-            found = sorted(glob.glob(os.path.join(ROOT, "profiles", f"round*_{tag}_pmc_summary.json")))
-            if found:
-                with open(found[-1]) as fh:
-                    summary = json.load(fh)
-                if summary.get("kernel_plan") == plan_now:  # counters of another geometry say nothing about this run
-                    traffic = summary["derived"].get("hbm_bytes_per_launch")
-                    traffic_src = os.path.relpath(found[-1], ROOT)
-                else:
-                    traffic_src = f"{os.path.relpath(found[-1], ROOT)} was taken with another launch plan: re-run tools/profile.sh"
+        # HBM traffic and VALU busy cannot be counted from inside this process: they come from the separate rocprofv3 --pmc passes
+        # of this same command (tools/profile.sh -> tools/summarize_prof.py), committed under profiles/ -- used only where the
+        # summary was taken with THIS launch plan (counters of another geometry say nothing about this run).
+        plan_now = plan_dict(pkg, n, dtype, "pairwise" if pair is not None else "one-sided", world)
+        traffic = traffic_src = valu_busy = wasted = None
+        if world == 1:
+            pmc = pmc_summary(n, args.fp64, args.mode, "pairwise" if pairwise else "one-sided", plan_now)
+            if pmc is not None:
+                traffic, traffic_src, valu_busy = pmc.get("hbm_bytes_per_launch"), pmc["source"], pmc.get("valu_busy")
+            if traffic is not None:
+                # every kernel of the step: the pairwise layout's second kernel reads back what the first one stored
+                finish_pmc = pmc_summary(n, args.fp64, args.mode, "pairwise", plan_now, kernel="_finish") if pair is not None else None
+                step_bytes = traffic + ((finish_pmc or {}).get("hbm_bytes_per_launch") or 0.0)
+                wasted = {"ratio": round(step_bytes / ((128 if args.fp64 else 64) * n), 1), "hbm_bytes_per_step": step_bytes,
+                          "kernels_counted": ["pair_forces", "pair_finish"] if (finish_pmc or {}).get("hbm_bytes_per_launch") else ["the dominant kernel"],
+                          "what": "HBM bytes the step's kernels really move (PMC passes) / SURVEY 8(d)'s algorithmic 64 N (128 N fp64): the pairwise layout "
+                                  "writes its reaction slots once and reads them once; ~0.1-0.2 ms of the step, not its limiter"}
         executed = None
+        per = 36 if args.fp64 else 24
         if pair is not None:
             evals = pair_evaluations(pair)
-            per = 36 if args.fp64 else 24
             executed = {"pair_evaluations_per_launch": evals, "flops_per_pair_evaluation": per,
                         "tflops": per * evals / (dominant_ms * 1e-3) / 1e12, "frac": per * evals / (dominant_ms * 1e-3) / 1e12 / peak}
+        elif capi_rank is not None and pairwise and world > 1:
+            # pairwise ACROSS the ranks: what THIS rank (rank 0) evaluates per step -- its diagonal and its rectangles against ranks
+            # r+1 .. r+G/2 (nb_comm_pair_work_*, from the plan the step runs) -- over its own step time, all kernels and waits included
+            work = capi_rank.pair_work()
+            if work is not None:
+                evals, launches = work
+                executed = {"pair_evaluations_per_step_this_rank": evals, "force_launches_per_step": launches, "flops_per_pair_evaluation": per,
+                            "tflops": per * evals / (dominant_ms * 1e-3) / 1e12, "frac": per * evals / (dominant_ms * 1e-3) / 1e12 / peak}
         roofline = {
             "bound": "valu_fp32_fma" if not args.fp64 else "valu_fp64_fma",
             "kernel": "pair_forces" if pair is not None else ("one rank's step (all its kernels and waits)" if distributed and world > 1 else "the step's one kernel"),
@@ -551,8 +554,10 @@ def main():
             "frac_counts": "algorithmic flop (reference convention) / peak; executed.frac = flop issued / peak",
             "executed": executed,
             "step_frac": flops_per * value / world / 1e12 / peak,  # the same count over the WHOLE step as the driver times it (value)
-            "traffic": traffic,  # HBM bytes per launch, rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes (tools/profile.sh)
+            "traffic": traffic,  # HBM bytes per launch of the dominant kernel, rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes (tools/profile.sh)
             "traffic_source": traffic_src,
+            "wasted_traffic_ratio": wasted,
+            "valu_busy": valu_busy,  # SQ_ACTIVE_INST_VALU / SQ_BUSY_CYCLES of the same passes: the hardware's own utilisation figure
             "kernel_ms": dominant_ms,
             "pair_forces_ms": forces_ms,
             "pair_finish_ms": finish_ms,
@@ -666,8 +671,17 @@ def main():
             seen = [None] * world
             clock = chip_summary if rank == 0 else chip.summary()  # (this rank's card while the headline was timed)
             clock = None if clock is None else {k: clock[k] for k in ("sclk_mhz", "sclk_mhz_min", "socket_power_w", "samples")}
-            dist.all_gather_object(seen, dict(capi_rank.info(), pairwise=capi_rank.pairwise(), one_group=capi_rank.exchange_grouping(), workspace_bytes=work_bytes,
-                                              cuda_device=torch.cuda.current_device(), chip=clock) if capi_rank is not None else {"rank": rank, "path": "sharded.py", "chip": clock})
+            # what every rank's communicator says about itself, the RCCL it is bound to (version, file), the card it runs on (PCI address) and
+            # -- pairwise across the ranks -- the pair evaluations and force launches of its step, and its step time by HIP events
+            mine = {"rank": rank, "path": "sharded.py", "chip": clock}
+            if capi_rank is not None:
+                mine = dict(capi_rank.info(), pairwise=capi_rank.pairwise(), one_group=capi_rank.exchange_grouping(), workspace_bytes=work_bytes,
+                            cuda_device=torch.cuda.current_device(), chip=clock)
+                work = capi_rank.pair_work() if (capi_rank.pairwise() and world > 1) else None
+                mine["pair_work"] = None if work is None else {"pair_evaluations_per_step": work[0], "force_launches_per_step": work[1]}
+            mine["pci"] = pci_address(torch, local_rank)
+            mine["stream_ms_per_step"] = float(f"{stream_ms_per_step:.5g}")
+            dist.all_gather_object(seen, mine)
             extra["ranks_seen"] = seen
             if not args.no_diagnostics:
                 extra["diagnostics"] = multi_gpu_diagnostics(pkg, lib, dist, torch, args, capi_rank, system, sharded, launch, fence, step, finish, lend, stream_ptr,

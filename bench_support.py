@@ -174,6 +174,38 @@ class ChipWatch:
                 "power_cap_w": None if cap is None else cap * 1e-6, "samples": len(clocks), "peak_is_computed_at_mhz": self.PEAK_CLOCK_MHZ}
 
 
+def plan_dict(pkg, n, dtype, layout, world=1):
+    """The launch plan of a step as the line (and profiles/*_pmc_summary.json, tools/summarize_prof.py) spell it."""
+    if layout == "pairwise":
+        pair = pkg.pair_plan(n, dtype)
+        return {"layout": "pairwise", "bodies_per_lane": pair.bodies_per_lane, "waves_per_block": pair.waves_per_block, "workgroups_per_block": pair.splits,
+                "blocks": pair.blocks, "block_bodies": pair.block_bodies, "reaction_slots": pair.reaction_slots, "grid": pair.grid_blocks,
+                "lds_bytes": pair.lds_bytes, "workspace_bytes": pair.workspace_bytes}
+    plan = pkg.plan(n // world, n, dtype)
+    return {"bodies_per_lane": plan.bodies_per_lane, "lane_groups": plan.lanes_per_body, "lds_tile_bodies": plan.tile_bodies, "grid": plan.grid_blocks, "lds_bytes": plan.lds_bytes}
+
+
+def pmc_summary(n, fp64, mode, layout, plan_now=None, kernel=""):
+    """What the committed rocprofv3 --pmc passes say about this configuration's dominant kernel (tools/profile.sh ->
+    tools/summarize_prof.py -> profiles/round*_n{N}_{f32|f64}[_pairwise|_strict][_finish]_pmc_summary.json; counters cannot be read
+    from inside the process being timed): {"valu_busy", "hbm_bytes_per_launch", "source"} of the NEWEST such file, or None.  A file
+    taken with another launch plan says nothing about this run: then only {"source": "... another launch plan"}."""
+    import glob
+    import json
+
+    tag = f"n{n}_{'f64' if fp64 else 'f32'}" + ("_strict" if mode == "strict" else ("_pairwise" if layout == "pairwise" else "")) + kernel
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", f"round*_{tag}_pmc_summary.json")), key=lambda f: int(os.path.basename(f).split("_")[0][5:]))
+    if not found:
+        return None
+    with open(found[-1]) as fh:
+        summary = json.load(fh)
+    source = os.path.relpath(found[-1], ROOT)
+    if plan_now is not None and mode != "strict" and summary.get("kernel_plan") != plan_now:
+        return {"source": f"{source} was taken with another launch plan: re-run tools/profile.sh"}
+    d = summary.get("derived", {})
+    return {"valu_busy": None if d.get("valu_busy_fraction") is None else round(d["valu_busy_fraction"], 4), "hbm_bytes_per_launch": d.get("hbm_bytes_per_launch"), "source": source}
+
+
 def pair_evaluations(pair) -> float:
     """pair evaluations per step of the pairwise layout: NB x (NB/2 + 1) block pairs of (64 I)^2"""
     return float(pair.blocks) * (pair.blocks // 2 + 1) * pair.block_bodies * pair.block_bodies
@@ -193,12 +225,13 @@ def fractions(n, fp64, layout, ms, pair=None):
 
 
 CONFIG_WARMUP_S = 0.25  # other_configs: steps run (untimed) for at least this long before a config is timed
+GRAPH_SIZES = (16384, 65536)  # ... and these pairwise entries are also timed as hipGraph replays
 
 
 def other_configs(pkg, lib, headline):
     """BASELINE.json configs besides the headline one, plus STRICT (the parity-exact mode) and, for FAST, both layouts
     (pairwise = nb_integrate_ws_* with a workspace, one-sided = nb_integrate_*), each as
-    {workload, bodies, dtype, mode, layout, steps, warmup_steps, ms_per_step, frac, executed_frac}: untimed steps for at least
+    {workload, bodies, dtype, mode, layout, steps, warmup_steps, ms_per_step, frac_algorithmic, executed_frac, valu_busy}: untimed steps for at least
     CONFIG_WARMUP_S (steady clocks -- these entries are steady-state figures; the headline keeps the driver's W warm-up steps), then
     K steps between two HIP events on the launch stream (the reference's GPU protocol, compute_cuda.cpp:183-195); the fractions:
     see fractions()."""
@@ -254,11 +287,34 @@ def other_configs(pkg, lib, headline):
             e1.record(None)
             e1.synchronize()
             ms = e0.elapsed_ms(e1) / steps
+            graph_ms = None
+            if layout == "pairwise" and n in GRAPH_SIZES:
+                # the same steps as ONE hipGraph launch per 100 (nb_graph_create_ws_*: the two kernels of a step captured back to back):
+                # what a graph saves is the second launch and the gap of each step -- 8 + 3 us of a 56 us step at 16 384 bodies
+                # (profiles/round4_*); timed right after the eager steps, same clocks
+                per_replay = 100
+                system.update_many(dt, per_replay)
+                system.synchronize()
+                replays = max(2, steps // per_replay)
+                g0, g1 = pkg.Event(), pkg.Event()
+                g0.record(None)
+                for _ in range(replays):
+                    system.update_many(dt, per_replay)
+                g1.record(None)
+                g1.synchronize()
+                graph_ms = g0.elapsed_ms(g1) / (replays * per_replay)
             system.free()
             frac, executed = fractions(n, fp64, layout, ms, pkg.pair_plan(n, dtype) if layout == "pairwise" else None)
             # (kept short: the whole line should stay well under what a log tail holds; interactions/s = bodies^2 / ms_per_step)
+            # frac_algorithmic: SURVEY 8(d)'s count (20 / 30 flop x N^2) over the peak -- NOT a utilisation figure for the pairwise layout
+            # (each pair is evaluated once: it can pass 1); executed_frac: the flop really issued over the same peak; valu_busy: the
+            # hardware's own answer, from the committed PMC passes of this configuration where its plan matches (None: no such pass)
+            pmc = pmc_summary(n, fp64, mode_name, layout, plan_dict(pkg, n, dtype, layout) if cap is None else None)
             out.append({"workload": what, "bodies": n, "dtype": "f64" if fp64 else "f32", "mode": mode_name, "layout": layout, "steps": steps, "warmup_steps": warmed,
-                        "ms_per_step": float(f"{ms:.5g}"), "frac": frac, "executed_frac": executed})
+                        "ms_per_step": float(f"{ms:.5g}"), "frac_algorithmic": frac, "executed_frac": executed, "valu_busy": None if not pmc else pmc.get("valu_busy")})
+            if graph_ms is not None:
+                out[-1]["hipgraph_ms_per_step"] = float(f"{graph_ms:.5g}")
+                out[-1]["hipgraph_gain"] = round(ms / graph_ms - 1.0, 4)
             if cap is not None:
                 out[-1]["workspace_bytes"] = system_bytes
     return out
@@ -296,7 +352,44 @@ def rank_projection(pkg, lib, n, dtype, dt, damping, single_ms):
         work.free()
     for b in bufs:
         b.free()
+    # ... and the same rank's whole STEP with the real RCCL on the chip (round 5): a LOOPBACK rank (nb_comm_loopback_open) launches the
+    # kernels, RCCL groups, events and waits of rank G/2 of a G-rank step, every send going to the rank itself -- a step minus what the
+    # xGMI links add.  A child process (tools/exchange_contention.py) under a timeout: it brings up RCCL communicators, and nothing
+    # a third-party library does may cost this process its headline line.
+    if np.dtype(dtype) == np.float32:
+        out["loopback"] = loopback_projection(n, single_ms)
     return out
+
+
+def loopback_projection(n, single_ms, worlds=(2, 4, 8), timeout_s=150):
+    import json
+    import subprocess
+
+    tool = os.path.join(ROOT, "tools", "exchange_contention.py")
+    got = {"what": "ONE GPU, real RCCL: ms per step of a loopback rank (rank G/2 of a nominal G-rank communicator; its kernels, RCCL groups, events and waits -- "
+                   "the transfers go to the rank itself), next to the same kernels with no communicator; a multi-GPU step minus the xGMI transfer time, NOT a "
+                   "multi-GPU measurement", "ranks": {}}
+    env = dict(os.environ)
+    for name in ("NBODY_RCCL_LIB", "FAKE_RCCL_IPC", "NCCL_DEBUG"):
+        env.pop(name, None)
+    try:
+        done = subprocess.run([sys.executable, tool, "--torch", "--bodies", str(n), "--world", ",".join(str(g) for g in worlds), "--steps", "40", "--rounds", "3",
+                               "--phases", "step_pairwise_late1_group_per_round,kernels_alone_pairwise_late1"], capture_output=True, text=True, timeout=timeout_s, env=env)
+    except subprocess.TimeoutExpired:
+        got["error"] = f"the child did not finish within {timeout_s} s"
+        return got
+    for text in done.stdout.splitlines():
+        if not text.startswith("{"):
+            continue
+        row = json.loads(text)
+        step, alone = row.get("step_pairwise_late1_group_per_round"), row.get("kernels_alone_pairwise_late1")
+        if step:
+            got["ranks"][str(row["nominal_world"])] = {"step_ms": step, "kernels_alone_ms": alone, "exposed_exchange_ms": None if alone is None else round(step - alone, 4),
+                                                       "speedup_excl_link_time": round(single_ms / step, 2)}
+            got["rccl_version"], got["rccl_library"] = row.get("rccl_version"), row.get("rccl_library")
+    if done.returncode != 0 or not got["ranks"]:
+        got["error"] = f"exit status {done.returncode}: " + done.stderr.strip().splitlines()[-1][:300] if done.stderr.strip() else f"exit status {done.returncode}"
+    return got
 
 
 def pair_kernel_split(pkg, lib, step, stream, reps=10):
@@ -374,8 +467,11 @@ def multi_gpu_diagnostics(pkg, lib, dist, torch, args, capi_rank, system, sharde
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(f"{float(t.item()) / reps * 1e3:.5g}")
 
-    def stream_timed(fn, reps):
-        """this rank's stream time (HIP events), max over ranks: for work that involves no other rank"""
+    by_rank = {}
+
+    def stream_timed(fn, reps, label=None):
+        """this rank's stream time (HIP events), max over ranks: for work that involves no other rank (`label`: every rank's own
+        figure goes into out["by_rank"][label], so that "exchange cost = step - kernels" can be read per rank)"""
         fence()
         e0, e1 = pkg.Event(), pkg.Event()
         e0.record(stream_ptr)
@@ -383,8 +479,13 @@ def multi_gpu_diagnostics(pkg, lib, dist, torch, args, capi_rank, system, sharde
             fn()
         e1.record(stream_ptr)
         e1.synchronize()
-        t = torch.tensor([e0.elapsed_ms(e1) / reps], dtype=torch.float64)
+        own = e0.elapsed_ms(e1) / reps
+        t = torch.tensor([own], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        if label is not None:
+            every = [None] * world
+            dist.all_gather_object(every, float(f"{own:.5g}"))
+            by_rank[label] = every
         fence()
         return float(f"{float(t.item()):.5g}")
 
@@ -422,7 +523,7 @@ def multi_gpu_diagnostics(pkg, lib, dist, torch, args, capi_rank, system, sharde
         need = ctypes.c_size_t(work_bytes)
         r = capi_rank.read
         out["pairwise_kernels_alone_ms"] = stream_timed(lambda: pkg.check(emulate(bufs[1 - r].data_ptr(), bufs[r].data_ptr(), vel_t.data_ptr(), work_t.data_ptr(), ctypes.byref(need), n, world, rank, dt, damping,
-                                                                                 stream_ptr), "nb_emulate_pair_rank"), reps)
+                                                                                 stream_ptr), "nb_emulate_pair_rank"), reps, "pairwise_kernels_alone_ms")
     i0, ni = sharded.slice_of(rank, world, n)
     schedule = sharded.tile_schedule(rank, world, n, mode == pkg.NB_MODE_STRICT)
 
@@ -431,7 +532,20 @@ def multi_gpu_diagnostics(pkg, lib, dist, torch, args, capi_rank, system, sharde
         for k, (j0, nj, _) in enumerate(schedule):
             launch(bufs[1 - r], bufs[r], vel_t, acc_t, i0, ni, j0, nj, (pkg.NB_SHARD_ACC_IN if k else 0) | (pkg.NB_SHARD_FINALIZE if k == len(schedule) - 1 else 0))
 
-    out["one_sided_kernels_alone_ms"] = stream_timed(tile_kernels, reps)
+    out["one_sided_kernels_alone_ms"] = stream_timed(tile_kernels, reps, "one_sided_kernels_alone_ms")
+    out["by_rank"] = by_rank
+    # (3b) the order of round 4 -- the diagonal as ONE launch, first -- against this round's (second half of it last, under which the
+    # last reaction sums travel): a process-global plan setting, so every rank flips it and the communicator re-agrees its layout
+    if was_pairwise:
+        try:
+            pkg.check(lib.nb_set_late_diagonal(0), "nb_set_late_diagonal")
+            capi_rank.set_workspace(work_t.data_ptr(), work_bytes)
+            if capi_rank.pairwise():  # (the one-launch form wants FEWER planes: what was lent suffices)
+                steps["pairwise_diagonal_first_" + ("one_group" if was_one_group else "group_per_round")] = timed(step, reps)
+        finally:
+            pkg.check(lib.nb_set_late_diagonal(1), "nb_set_late_diagonal")
+            capi_rank.set_workspace(work_t.data_ptr(), work_bytes)
+        assert capi_rank.pairwise()
     # (4) the other layout: every rank takes its workspace back (the call is collective) -> the one-sided tile schedule
     if was_pairwise:
         capi_rank.set_workspace(None, 0)
@@ -474,7 +588,7 @@ def multi_gpu_diagnostics(pkg, lib, dist, torch, args, capi_rank, system, sharde
         ms = float(t.item()) / k * 1e3
         out["configs"] = [{"workload": "configs[3]" if nb == CONFIG3_BODIES else f"configs[3]'s shape at {nb} bodies (rehearsal)", "bodies": nb, "n_gpus": world, "dtype": "f32", "mode": "fast",
                            "layout": "pairwise across ranks" if job.pairwise() else "one-sided tiles", "steps": k, "ms_per_step": float(f"{ms:.5g}"),
-                           "interactions_per_s": float(nb) * nb / (ms * 1e-3), "frac": round(20 * float(nb) * nb / (ms * 1e-3) / world / (FP32_VECTOR_PEAK_TFLOPS * 1e12), 4),
+                           "interactions_per_s": float(nb) * nb / (ms * 1e-3), "frac_algorithmic": round(20 * float(nb) * nb / (ms * 1e-3) / world / (FP32_VECTOR_PEAK_TFLOPS * 1e12), 4),
                            "workspace_bytes_per_rank": b_work.numel() if b_work is not None else 0}]
         # hand the communicator back to the headline system
         capi_rank.set_workspace(work_t.data_ptr() if work_t is not None else None, work_bytes)

@@ -23,6 +23,7 @@ LIB_PATH = os.environ.get("NBODY_HIP_LIB", os.path.join(HERE, "libnbody_hip.so")
 
 NB_MODE_STRICT, NB_MODE_FAST = 0, 1
 NB_SHARD_ACC_IN, NB_SHARD_FINALIZE = 1, 2
+NB_ERR_INVALID_ARGUMENT, NB_ERR_UNSUPPORTED, NB_ERR_RCCL_BASE = 10001, 10002, 20000
 
 # enum class NBodyConfig, src/nbody/nbody_config.hpp:3
 NBODY_CONFIG_RANDOM, NBODY_CONFIG_SHELL, NBODY_CONFIG_EXPAND = 0, 1, 2
@@ -177,6 +178,9 @@ TUNING_SIGNATURES = {
     "nb_comm_selftest_f32": (_ci, [_vp, _sz, _vp, _P(CommSelftest)]),
     "nb_comm_self_transfer_f32": (_ci, [_vp, _vp, _vp, _sz, _ci, _ci, _vp, _vp, _vp]),
     "nb_comm_transport_info": (_ci, [_vp, _P(_ci), ctypes.c_char_p, _sz]),
+    "nb_comm_last_step_trace": (_ci, [_vp, ctypes.c_char_p, _sz]),
+    "nb_comm_pair_work_f32": (_ci, [_vp, _cu, _P(ctypes.c_ulonglong), _P(_ci)]),
+    "nb_comm_pair_work_f64": (_ci, [_vp, _cu, _P(ctypes.c_ulonglong), _P(_ci)]),
 }
 
 _lib = None
@@ -513,6 +517,17 @@ class ShardedRank:
         out = {"rank": r.value, "world": w.value, "device": d.value}
         out.update(comm_transport_info(self.comm))
         return out
+
+    def pair_work(self):
+        """nb_comm_pair_work_* (tuning header): (pair evaluations, force launches) of this rank per pairwise step; None when the
+        communicator steps one-sidedly"""
+        evals, launches = ctypes.c_ulonglong(0), _ci(0)
+        fn = lib().nb_comm_pair_work_f32 if self.dtype == np.float32 else lib().nb_comm_pair_work_f64
+        rc = fn(self.comm, self.n, ctypes.byref(evals), ctypes.byref(launches))
+        if rc == NB_ERR_UNSUPPORTED:
+            return None
+        check(rc, "nb_comm_pair_work")
+        return evals.value, launches.value
 
     def update(self, delta_time, damping) -> None:
         """pos[1-read][own slice], vel[own slice] <- one step from pos[read]; then the tiles of pos[1-read] start moving."""

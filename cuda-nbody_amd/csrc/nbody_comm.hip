@@ -5,8 +5,8 @@
 // array; every array is full-size and indexed by global body id.  The one exchange step of the path is the all-gather of
 // the new positions, issued as its G-1 position TILES over RCCL (= xGMI inside a node): in round s = 1..G-1 every rank
 // sends its slice to rank r-s and receives the slice of rank r+s -- ncclSend/ncclRecv pairs on the communicator's own
-// high-priority stream, an event per tile (all rounds of a step in ONE RCCL group by default, a group per round with
-// NBODY_EXCHANGE_ONE_GROUP=0: see exchange_tiles).  Accumulation is additive over j chunks, so a step starts with the chunk
+// high-priority stream, an event per tile (a group and an event per round by default since round 5, all rounds of a step in ONE
+// RCCL group with NBODY_EXCHANGE_ONE_GROUP=1 / nb_comm_set_exchange_grouping: see exchange_tiles).  Accumulation is additive over j chunks, so a step starts with the chunk
 // that is already local (j in the rank's own slice) and then takes the tiles in arrival order, the kernel of tile k waiting
 // only for tile k's event: the exchange runs under the force compute of the chunks already there.
 // STRICT keeps the CPU path's summation order (ascending j): tiles in rank order, each waiting for its own round,
@@ -121,7 +121,7 @@ struct Comm {
     size_t      workspace_bytes = 0;
     size_t      agreed_bytes    = 0;       // one process per rank: the SMALLEST amount any rank of the communicator was lent (set_workspace's exchange)
     size_t      agreed_budget   = 0;       // ... and the smallest device memory budget of any rank (0 until that exchange: this rank's own)
-    bool        one_group       = true;    // nb_comm_set_exchange_grouping: all G-1 position rounds of a step in one RCCL group
+    bool        one_group       = false;   // nb_comm_set_exchange_grouping: all G-1 position rounds of a step in one RCCL group (default: a group per round)
     unsigned long long* notes   = nullptr; // [world][kNoteWords] device memory of the communicator: what set_workspace's ranks tell each other
     hipStream_t aux       = nullptr;       // pairwise step: every other rectangle runs here, so that the tails and launch gaps of
     hipEvent_t  aux_begin = nullptr;       // one stream's kernels are filled by the other's (events: aux may start / aux is done)
@@ -129,6 +129,7 @@ struct Comm {
     std::vector<hipEvent_t> react_ready;   // [world/2 + 1] pairwise step: "the reaction sums for partner s are in the send buffer" (compute stream)
     std::vector<hipEvent_t> react_arrived; // [world/2 + 1] ... "round s of the reaction exchange is done" (exchange stream)
     std::vector<Comm*> group;              // all local ranks of this communicator (just {this} with one process per GPU)
+    std::string trace;                     // what the rank's last pairwise step enqueued, in host order (nb_comm_last_step_trace: tests read the order)
     bool        loopback = false;          // nb_comm_loopback_open (tuning header): rank / world are NOMINAL, the ncclComm has one rank and every peer is this rank itself
 };
 
@@ -137,9 +138,9 @@ inline int peer_of(const Comm* c, int logical) { return c->loopback ? 0 : logica
 
 constexpr int kNoteWords = 8;  // {workspace bytes, min slice, pair plan overrides R S C, device memory budget, late diagonal, spare}
 
-bool default_one_group() {  // NBODY_EXCHANGE_ONE_GROUP=0 flips the default of nb_comm_set_exchange_grouping
+bool default_one_group() {  // NBODY_EXCHANGE_ONE_GROUP=1 flips the default of nb_comm_set_exchange_grouping (a group per round since round 5)
     const char* v = std::getenv("NBODY_EXCHANGE_ONE_GROUP");
-    return v == nullptr || v[0] != '0';
+    return v != nullptr && v[0] == '1';
 }
 
 inline Comm* as_comm(nb_comm_t c) { return static_cast<Comm*>(c); }
@@ -235,12 +236,14 @@ int exchange_tiles(const std::vector<Comm*>& locals, void* const* positions, uns
         if (err != hipSuccess) return static_cast<int>(err);
         c->in_flight = positions[k];
     }
-    // All G-1 rounds of a step go out as ONE RCCL group (one RCCL kernel per step, every xGMI link busy at once, all tiles arriving
-    // together): a force kernel holds every CU for its whole run (two 512-thread workgroups per CU at 128 VGPRs), so an RCCL
-    // kernel that becomes ready in the middle of one waits for a workgroup slot -- a wait that G-1 separate rounds could pay G-1
-    // times per step.  nb_comm_set_exchange_grouping(comm, 0) issues a group per round instead (tile k's event then fires with
-    // round k): a per-communicator setting, so that one job can time both.  Same data, same bits either way (tested with the
-    // transport double); which one is faster has not been measured on several GPUs.
+    // A group -- one RCCL kernel, one event -- PER ROUND by default (round 5, measured with the real RCCL on one GPU, a loopback rank:
+    // profiles/round5_exchange_contention.jsonl, round5_exchange_timeline.txt): tile k's event fires with round k, so the kernels that
+    // need the first tiles start ~30 us earlier than when one kernel moves all G-1 tiles before any event fires (8 ranks, 262 144 bodies:
+    // 1.290 against 1.357 ms per step; never slower at 2 / 4 ranks or 1 Mi bodies).  An RCCL kernel that becomes ready while the force
+    // kernels hold every CU does wait for one of them to retire -- a pair_forces<float,8,8> workgroup owns its CU's register file -- but
+    // with a group per round those waits fall on tiles that are not needed yet.  nb_comm_set_exchange_grouping(comm, 1) issues all
+    // rounds of a step as ONE group instead: a per-communicator setting, so that one job can time both (bench.py's diagnostics do).
+    // Same data, same bits either way (tested with the transport double).
     const bool one_group = locals.front()->one_group;
     for (Comm* c : locals)
         if (c->one_group != one_group) return NB_ERR_INVALID_ARGUMENT;  // the local ranks of a group must agree (all ranks must)
@@ -404,6 +407,7 @@ int pair_rank_tiles(Comm* c, unsigned r, int G, const PairShard& plan, T* work, 
         if (plan.late_units != 0) {
             a.self_first = plan.diag.splits, a.unit_begin = plan.early_units, a.unit_count = plan.late_units;
             if (const auto err = nb::launch_pair_tile<T>(a, plan.diag_late, stream); err != hipSuccess) return static_cast<int>(err);
+            if (c != nullptr) c->trace += "forces diagonal-late\n";
             f.self_set[f.n_self++] = {plan.diag.splits, plan.diag_late.splits, 0u, ni};
         }
         if (aux != nullptr) {  // the finish kernel (on `stream`) needs the second stream's sums too
@@ -429,6 +433,7 @@ int pair_rank_tiles(Comm* c, unsigned r, int G, const PairShard& plan, T* work, 
     }
     a.self_first = 0, a.unit_begin = 0, a.unit_count = plan.late_units != 0 ? plan.early_units : 0u;
     if (const auto err = nb::launch_pair_tile<T>(a, plan.diag, stream); err != hipSuccess) return static_cast<int>(err);
+    if (c != nullptr) c->trace = plan.late_units != 0 ? "forces diagonal-early\n" : "forces diagonal\n";
     f.self_set[f.n_self++] = {0u, plan.diag.splits, 0u, ni};
     // the rectangles against the partners r+1 .. r+H, each as its positions arrive
     for (unsigned s = 1; s <= plan.H; ++s) {
@@ -456,6 +461,7 @@ int pair_rank_tiles(Comm* c, unsigned r, int G, const PairShard& plan, T* work, 
         if (const auto err = nb::launch_pair_reduce<T>(a.react, plan.plane, blocks_i, work + plan.send_at + (s - 1) * plane3, plan.plane, a.j_count, on); err != hipSuccess) return static_cast<int>(err);
         if (c != nullptr) {
             if (const auto err = hipEventRecord(c->react_ready[s], on); err != hipSuccess) return static_cast<int>(err);
+            c->trace += "forces rectangle " + std::to_string(s) + "\nfold " + std::to_string(s) + "\n";
         }
         // what arrives in round s comes from rank r-s, which covered: all of this slice -- or, splitting the rectangle as the
         // lower rank, only the first half of its blocks
@@ -467,6 +473,26 @@ int pair_rank_tiles(Comm* c, unsigned r, int G, const PairShard& plan, T* work, 
     a.diag = 1, a.keep = 1, a.react = work + plan.react_d_at, a.react_origin = own;
     a.i_begin = a.j_begin = own, a.i_count = a.j_count = ni;
     return late_diagonal_and_join();
+}
+
+// Pair evaluations rank r makes in one pairwise step (what pair_rank_tiles launches, counted the way the kernel loops: whole
+// 64-body tiles against whole blocks of bodies i, the half-kept offsets q = 0 and q = NB/2 included) and its force launches.
+inline void pair_rank_work(const PairShard& plan, unsigned r, int G, unsigned long long* evaluations, int* launches) {
+    const unsigned long long block = plan.block;
+    unsigned long long       sum   = static_cast<unsigned long long>(plan.blocks) * (plan.blocks / 2 + 1) * block * block;  // the diagonal's tournament
+    int                      count = plan.late_units != 0 ? 2 : 1;
+    for (unsigned s = 1; s <= plan.H; ++s) {
+        const unsigned p = (r + s) % static_cast<unsigned>(G);
+        unsigned       i_count = plan.ni, j_count = plan.ni;
+        if (plan.even && s == plan.H) {
+            if (r < p) j_count = plan.half;
+            else i_count = plan.ni - plan.half;
+        }
+        const unsigned long long blocks_i = (i_count + plan.block - 1) / plan.block, tiles_j = (j_count + 63) / 64;
+        sum += blocks_i * block * tiles_j * 64;
+        ++count;
+    }
+    *evaluations = sum, *launches = count;
 }
 
 // The reaction leg of a pairwise step: round s = send to rank r+s what was summed for its bodies, receive from r-s what it
@@ -497,6 +523,7 @@ template <typename T> int reaction_exchange(const std::vector<Comm*>& locals, co
         for (Comm* c : locals) {
             DeviceScope scope(c->device);
             if (const auto err = hipEventRecord(c->react_arrived[s], c->stream); err != hipSuccess) return static_cast<int>(err);
+            c->trace += "send reaction " + std::to_string(s) + "\n";
         }
     }
     return 0;
@@ -532,6 +559,7 @@ int pair_sharded_step(const std::vector<Comm*>& locals, const PairShard& plan, T
             if (const auto err = hipStreamWaitEvent(stream, c->react_arrived[s], 0); err != hipSuccess) return static_cast<int>(err);
         }
         if (const auto err = nb::launch_pair_finish<T>(finish[k], stream); err != hipSuccess) return static_cast<int>(err);
+        c->trace += "finish\n";
     }
     return 0;
 }
@@ -729,6 +757,15 @@ template <typename T> int comm_layout(nb_comm_t comm, unsigned num_bodies, int m
         return rc;
     }
     *pairwise = step_is_pairwise<T>(std::vector<Comm*>{c}, num_bodies, mode, nullptr) ? 1 : 0;
+    return 0;
+}
+template <typename T> int comm_pair_work(nb_comm_t comm, unsigned num_bodies, unsigned long long* evaluations, int* launches) {
+    Comm* c = as_comm(comm);
+    if (c == nullptr || evaluations == nullptr || launches == nullptr) return NB_ERR_INVALID_ARGUMENT;
+    *evaluations = 0, *launches = 0;
+    PairShard plan;
+    if (!step_is_pairwise<T>(std::vector<Comm*>{c}, num_bodies, NB_MODE_FAST, &plan)) return NB_ERR_UNSUPPORTED;  // (one-sided: N/G x N directed interactions, nothing to ask)
+    pair_rank_work(plan, static_cast<unsigned>(c->rank), c->world, evaluations, launches);
     return 0;
 }
 }  // namespace
@@ -1072,6 +1109,17 @@ int nb_comm_selftest_f32(nb_comm_t comm, size_t bytes, nb_stream_t stream, nb_co
     if (result == 0 && (report->send_recv_wrong_bytes != 0 || report->all_gather_wrong_bytes != 0)) result = NB_ERR_UNSUPPORTED;
     return result;
 }
+
+int nb_comm_last_step_trace(nb_comm_t comm, char* text, size_t bytes) {
+    Comm* c = as_comm(comm);
+    if (c == nullptr || text == nullptr || bytes == 0) return NB_ERR_INVALID_ARGUMENT;
+    std::strncpy(text, c->trace.c_str(), bytes - 1);
+    text[bytes - 1] = 0;
+    return 0;
+}
+
+int nb_comm_pair_work_f32(nb_comm_t comm, unsigned num_bodies, unsigned long long* pair_evaluations, int* force_launches) { return comm_pair_work<float>(comm, num_bodies, pair_evaluations, force_launches); }
+int nb_comm_pair_work_f64(nb_comm_t comm, unsigned num_bodies, unsigned long long* pair_evaluations, int* force_launches) { return comm_pair_work<double>(comm, num_bodies, pair_evaluations, force_launches); }
 
 int nb_comm_info(nb_comm_t comm, int* rank, int* world, int* device) {
     Comm* c = as_comm(comm);

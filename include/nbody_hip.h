@@ -184,7 +184,7 @@ NB_API int nb_integrate_shard_f64(double* new_positions, const double* old_posit
  *  as tipsy.cpp:111-119 does -- i.e. their velocities and their slice of every new position array; all arrays stay
  *  full-size.  The one exchange step is the all-gather of the new positions, issued as G-1 position TILES: in round s
  *  rank r sends its slice to r-s and receives the slice of r+s (RCCL send/recv pairs on the communicator's own
- *  high-priority stream, all rounds of a step in one RCCL group or a group per round -- nb_comm_set_exchange_grouping --, an
+ *  high-priority stream, a group per round or all rounds of a step in one RCCL group -- nb_comm_set_exchange_grouping --, an
  *  event per tile).  nb_sharded_step_* = the kernels of the own slice,
  *  then of each tile as it arrives (STRICT: ascending rank order, bit-identical to one GPU), integrate, and the start
  *  of the exchange of new_positions -- everything asynchronous; the caller ping-pongs the two position arrays exactly
@@ -220,11 +220,12 @@ NB_API int nb_comm_set_workspace(nb_comm_t comm, void* workspace, size_t workspa
  * 0: the one-sided tile schedule.  The same answer on every rank. */
 NB_API int nb_comm_layout_f32(nb_comm_t comm, unsigned num_bodies, int mode, int* pairwise);
 NB_API int nb_comm_layout_f64(nb_comm_t comm, unsigned num_bodies, int mode, int* pairwise);
-/* How the G-1 position rounds of a step are issued, per communicator (every rank must choose the same): one_group = 1 (default;
- * the environment variable NBODY_EXCHANGE_ONE_GROUP=0 flips the default): all rounds in ONE RCCL group -- one RCCL kernel per
- * step, every tile's event fires when the whole exchange is done; one_group = 0: a group and an event per round -- the kernel
- * of tile k can start while round k+1 is still moving.  Same data, same bits either way; which one is faster is unmeasured
- * (no multi-GPU box so far).  nb_comm_get_exchange_grouping reports the current setting. */
+/* How the G-1 position rounds of a step are issued, per communicator (every rank must choose the same): one_group = 0 (default
+ * since round 5; the environment variable NBODY_EXCHANGE_ONE_GROUP=1 flips the default): a group and an event per round -- the kernel
+ * of tile k can start while round k+1 is still moving; one_group = 1: all rounds in ONE RCCL group -- one RCCL kernel per step,
+ * every tile's event fires when the whole exchange is done.  Same data, same bits either way.  Measured with the real RCCL next to
+ * the force kernels on one GPU (profiles/round5_exchange_contention.jsonl): a group per round is never slower and 5 % faster for
+ * 262 144 bodies over 8 ranks.  nb_comm_get_exchange_grouping reports the current setting. */
 NB_API int nb_comm_set_exchange_grouping(nb_comm_t comm, int one_group);
 NB_API int nb_comm_get_exchange_grouping(nb_comm_t comm, int* one_group);
 NB_API int nb_sharded_step_f32(nb_comm_t comm, float* new_positions, const float* old_positions, float* velocities, float* acc,

@@ -86,6 +86,17 @@ NB_API int nb_comm_self_transfer_f32(nb_comm_t comm, const float* src, float* ds
                                      nb_event_t begin, nb_event_t end);
 NB_API int nb_comm_transport_info(nb_comm_t comm, int* rccl_version, char* library_path, size_t path_bytes);
 
+/* What this rank EXECUTES in one pairwise multi-GPU step (the communicator's layout must be pairwise for this system: NB_ERR_UNSUPPORTED
+ * otherwise): pair evaluations -- whole tiles against whole blocks, as the kernel loops, 24 flop each in fp32 / 36 in fp64 -- and
+ * force-kernel launches.  bench.py's N > 1 line states the flop a rank really issues next to the algorithmic count with it. */
+NB_API int nb_comm_pair_work_f32(nb_comm_t comm, unsigned num_bodies, unsigned long long* pair_evaluations, int* force_launches);
+NB_API int nb_comm_pair_work_f64(nb_comm_t comm, unsigned num_bodies, unsigned long long* pair_evaluations, int* force_launches);
+
+/* What this rank's LAST pairwise multi-GPU step enqueued, in host order, one item per line: "forces diagonal-early", "forces
+ * rectangle s", "fold s", "send reaction s", "forces diagonal-late", "finish" (empty before the first such step).  Tests read the
+ * ORDER from it: every reaction send is enqueued before the rank's last force kernel. */
+NB_API int nb_comm_last_step_trace(nb_comm_t comm, char* text, size_t bytes);
+
 /* An event recorded between the forces kernel and the finish kernel of every ONE-GPU pairwise step from now on (NULL = none):
  * bench.py times the two kernels of the headline step separately with it, after the timed region. */
 NB_API int nb_set_pair_probe_event(nb_event_t event);

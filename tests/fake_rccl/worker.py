@@ -7,6 +7,7 @@ library resolves RCCL, which happens once per process -- hence a process of its 
 
 `ws`: every rank is lent the workspace nb_comm_workspace_bytes_* asks for (FAST then takes the pairwise step across the ranks).
 Environment: WORKER_ONE_GROUP=0|1 -> nb_comm_set_exchange_grouping on every communicator (unset: the library's default);
+WORKER_LATE_DIAGONAL=0|1 -> nb_set_late_diagonal;
 WORKER_NO_WORKSPACE_RANK=k -> rank k lends nothing (nb_comm_set_workspace(comm, NULL, 0)): the layout must then be one-sided on
 EVERY rank.  The output holds `layout` (nb_comm_layout_* per rank) and `setup_counters` (what the transport had seen before the
 first step: nb_comm_set_workspace's exchange with one process -- here: thread -- per rank).
@@ -81,6 +82,8 @@ def main():
         pkg.check(lib.nb_set_softening_sq_f64(float(soft * soft)))
     if with_workspace:
         pkg.check(lib.nb_comm_set_pair_min_slice(64), "nb_comm_set_pair_min_slice")  # (the test systems are small)
+    if os.environ.get("WORKER_LATE_DIAGONAL") is not None:
+        pkg.check(lib.nb_set_late_diagonal(int(os.environ["WORKER_LATE_DIAGONAL"])), "nb_set_late_diagonal")
     ws_bytes_fn = lib.nb_comm_workspace_bytes_f32 if f32 else lib.nb_comm_workspace_bytes_f64
     layout_fn = lib.nb_comm_layout_f32 if f32 else lib.nb_comm_layout_f64
     workspaces = []
@@ -145,6 +148,10 @@ def main():
                                arr([r.bufs[3].ptr for r in ranks]), n, dt, one, 256, mode, arr([r.stream for r in ranks])), "nb_sharded_step_all")
             for r in ranks:
                 r.read = 1 - rd
+        if steps:  # what the last pairwise step of rank 0 enqueued, in host order (empty for the one-sided schedule)
+            text = ctypes.create_string_buffer(4096)
+            pkg.check(lib.nb_comm_last_step_trace(comms[0], text, len(text)), "nb_comm_last_step_trace")
+            out["trace_0"] = np.frombuffer(text.value, dtype=np.uint8)
         for k, r in enumerate(ranks):
             p, v = r.results(comms[k], pos0, vel0)
             out[f"pos_{k}"] = p

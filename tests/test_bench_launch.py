@@ -207,10 +207,23 @@ def test_default_line_carries_every_baseline_config():
     projection = line["multi_gpu_kernel_projection"]
     assert "PROJECTION" in projection["what"] and set(projection["ranks"]) == {"2", "4", "8"}
     assert projection["ranks"]["8"]["kernel_ms"] < projection["ranks"]["2"]["kernel_ms"] < line["ms_per_step"]
+    # round 5: the same rank's whole step with the REAL RCCL's kernels on the chip (a loopback rank, in a child process)
+    loop = projection["loopback"]
+    assert "error" not in loop and loop["rccl_version"] >= 20000 and "fake" not in loop["rccl_library"], loop
+    assert set(loop["ranks"]) == {"2", "4", "8"} and loop["ranks"]["8"]["step_ms"] < loop["ranks"]["4"]["step_ms"] < loop["ranks"]["2"]["step_ms"] < line["ms_per_step"]
+    assert all(abs(v["exposed_exchange_ms"]) < 0.25 * v["step_ms"] for v in loop["ranks"].values())
     for c in line["configs"]:
-        assert c["ms_per_step"] > 0 and 0 < c["frac"] < 1.3  # (pairwise: the algorithmic count may pass the one-sided peak)
+        assert "frac" not in c  # (round 5: no bare "frac" that reads as utilisation)
+        assert c["ms_per_step"] > 0 and 0 < c["frac_algorithmic"] < 1.3  # (pairwise: the algorithmic count may pass the one-sided peak)
         assert 0 < c["executed_frac"] < 1  # ... which is why the flop really issued stand next to it, and never pass 1
-        assert (c["executed_frac"] < c["frac"]) == (c["layout"] == "pairwise")
+        assert (c["executed_frac"] < c["frac_algorithmic"]) == (c["layout"] == "pairwise")
+        assert c["valu_busy"] is None or 0.1 < c["valu_busy"] <= 1.0  # the hardware's own figure, where a committed PMC pass matches the plan
+    by_size = {(c["bodies"], c["layout"]): c for c in line["configs"] if c["dtype"] == "f32" and c["mode"] == "fast"}
+    for n in (16384, 65536):  # the hipGraph form timed next to the eager steps
+        assert by_size[(n, "pairwise")]["hipgraph_ms_per_step"] > 0 and -0.5 < by_size[(n, "pairwise")]["hipgraph_gain"] < 1.0
+    # the headline's own counters and the bytes the step really moves against SURVEY 8(d)'s 64 N
+    if roof["traffic"] is not None:
+        assert 0.5 < roof["valu_busy"] <= 1.0 and roof["wasted_traffic_ratio"]["ratio"] > 10 and roof["wasted_traffic_ratio"]["kernels_counted"] == ["pair_forces", "pair_finish"]
     f64 = next(c for c in line["configs"] if (c["bodies"], c["dtype"], c["layout"]) == (262144, "f64", "pairwise"))
     assert f64["executed_frac"] < 0.8
 
@@ -246,12 +259,23 @@ def test_n_rank_line_rehearsed_on_one_gpu_through_the_capi(ranks):
     line = _metric_line(out.stdout)
     assert line["n_gpus"] == ranks and line["exchange_fallback"] is False and line["value"] > 0
     assert line["config"]["step_entry_point"] == "nb_sharded_step_*" and "REHEARSAL" in line["config"]["exchange"] and "PAIRWISE" in line["config"]["exchange"]
-    assert line["config"]["exchange_grouping"].startswith("one RCCL group for all")
+    assert line["config"]["exchange_grouping"].startswith("one RCCL group per position round")  # (round 5's default: measured, profiles/round5_exchange_contention.jsonl)
     seen = line["ranks_seen"]
-    assert [r["rank"] for r in seen] == list(range(ranks)) and all(r["world"] == ranks and r["pairwise"] and r["one_group"] and r["workspace_bytes"] > 0 for r in seen)
+    assert [r["rank"] for r in seen] == list(range(ranks)) and all(r["world"] == ranks and r["pairwise"] and not r["one_group"] and r["workspace_bytes"] > 0 for r in seen)
     assert all("chip" in r for r in seen)  # (every rank's own card: clock and power while the headline was timed; None where sysfs says nothing)
+    # the record alone says which RCCL carried the bytes (here: the double, version 0), which card a rank ran on, what
+    # the rank executed per step and how long its own stream took
+    assert all(r["rccl_version"] == 0 and "fake_rccl" in r["rccl_library"] for r in seen)
+    assert all(r["pci"] == seen[0]["pci"] and r["stream_ms_per_step"] > 0 for r in seen)  # (the rehearsal: one card)
+    assert all(r["pair_work"]["pair_evaluations_per_step"] > 0 and r["pair_work"]["force_launches_per_step"] == 2 + ranks // 2 for r in seen)
+    total = sum(r["pair_work"]["pair_evaluations_per_step"] for r in seen)
+    assert 0.5 * 16384 ** 2 <= total <= 0.75 * 16384 ** 2  # every pair once, plus the half-kept diagonal blocks
+    executed = line["roofline"]["executed"]
+    assert executed["pair_evaluations_per_step_this_rank"] == seen[0]["pair_work"]["pair_evaluations_per_step"] and 0 < executed["frac"] < 1
     diag = line["diagnostics"]
-    assert set(diag["step_ms"]) == {"pairwise_one_group", "pairwise_group_per_round", "one_sided_one_group", "one_sided_group_per_round"} and diag["headline_was"] == "pairwise_one_group"
+    assert set(diag["step_ms"]) == {"pairwise_one_group", "pairwise_group_per_round", "one_sided_one_group", "one_sided_group_per_round", "pairwise_diagonal_first_group_per_round"}
+    assert diag["headline_was"] == "pairwise_group_per_round"
+    assert len(diag["by_rank"]["pairwise_kernels_alone_ms"]) == ranks and all(v > 0 for v in diag["by_rank"]["pairwise_kernels_alone_ms"])
     assert all(v > 0 for v in diag["step_ms"].values())
     assert set(diag["position_exchange_alone_ms"]) == {"one_group", "group_per_round"} and diag["reaction_exchange_alone_ms"] > 0
     assert 0 < diag["pairwise_kernels_alone_ms"] and 0 < diag["one_sided_kernels_alone_ms"]

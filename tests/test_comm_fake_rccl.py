@@ -70,7 +70,7 @@ def test_init_all_four_ranks_on_one_gpu(tmp_path, oracle, dtype, tag, mode):
     got = _run(tmp_path, "all", pos0, vel0, world, steps, mode)
     assert list(got["rejected"]) == [10001, 10001, 10001]  # subset of the group / a rank twice / per-rank form on a multi-rank group
     sends, recvs, gathers, groups, copies = got["counters"]
-    assert sends == recvs == copies == (world - 1) * world * steps and groups == steps and gathers == 0  # (one group per step holds all G-1 rounds)
+    assert sends == recvs == copies == (world - 1) * world * steps and groups == (world - 1) * steps and gathers == 0  # (a group per round: the default since round 5)
     ref_p, ref_v = pos0.copy(), vel0.copy()
     oracle.update(ref_p, ref_v, dtype(np.float32(0.016)), steps=steps)
     pos = [got[f"pos_{k}"] for k in range(world)]
@@ -110,7 +110,7 @@ def test_init_rank_one_thread_per_rank(tmp_path, oracle, mode):
     pos0, vel0 = oracle.startup_state(n, np.float32)
     got = _run(tmp_path, "threads", pos0, vel0, world, steps, mode)
     sends, recvs, gathers, groups, copies = got["counters"]
-    assert sends == recvs == copies == (world - 1) * world * steps and groups == world * steps
+    assert sends == recvs == copies == (world - 1) * world * steps and groups == (world - 1) * world * steps  # (a thread per rank: every rank issues its own group per round)
     ref_p, ref_v = pos0.copy(), vel0.copy()
     oracle.update(ref_p, ref_v, np.float32(0.016), steps=steps)
     vel = np.concatenate([got[f"vel_{k}"] for k in range(world)])
@@ -211,7 +211,7 @@ def test_pairwise_step_across_ranks(tmp_path, oracle, world, dtype):
     got = _run(tmp_path, "all", pos0, vel0, world, steps, "fast", workspace=True)
     assert np.all(got["workspace_bytes"] > 0)
     sends, recvs, gathers, groups, copies = got["counters"]
-    assert sends == recvs == (world - 1 + world // 2) * world * steps and groups == (1 + world // 2) * steps
+    assert sends == recvs == (world - 1 + world // 2) * world * steps and groups == (world - 1 + world // 2) * steps
     ref_p, ref_v = pos0.copy(), vel0.copy()
     oracle.update(ref_p, ref_v, dtype(np.float32(0.016)), steps=steps)
     for k in range(1, world):
@@ -227,6 +227,33 @@ def test_pairwise_step_across_ranks(tmp_path, oracle, world, dtype):
     # STRICT ignores the workspace: still the CPU path's bits
     strict = _run(tmp_path, "all", pos0, vel0, world, steps, "strict", workspace=True)
     assert strict["pos_0"].tobytes() == ref_p.tobytes()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 4, 5, 8])
+def test_reaction_sends_are_enqueued_before_the_last_force_kernel(tmp_path, oracle, world):
+    """VERDICT r4 item 2.  The finish kernel of a rank waits for the reaction sums its partners send, and a partner used to produce
+    the last of them with its last kernel: that hop sat bare at the end of every step.  Round 5: a rank's diagonal -- work that
+    needs nothing from anybody -- goes out as two launches, the second one LAST, and every reaction round is enqueued before it
+    (nb_comm_last_step_trace, tuning header: the host order of rank 0's last step).  nb_set_late_diagonal(0) is round 4's order,
+    kept for A/B timings: another summation order (other last bits), the same physics."""
+    n, steps = world * 1024, 2
+    pos0, vel0 = oracle.startup_state(n, np.float32)
+    got = _run(tmp_path, "all", pos0, vel0, world, steps, "fast", workspace=True)
+    trace = bytes(got["trace_0"]).decode().split("\n")[:-1]
+    H = world // 2
+    folds = [f"fold {s}" for s in range(1, H + 1)]
+    sends = [f"send reaction {s}" for s in range(1, H + 1)]
+    assert trace[0] == "forces diagonal-early" and trace[-2:] == ["forces diagonal-late", "finish"], trace
+    assert [t for t in trace if t.startswith("fold")] == folds and [t for t in trace if t.startswith("send")] == sends
+    assert max(trace.index(t) for t in folds) < min(trace.index(t) for t in sends)  # a round is enqueued once its rectangle's fold is
+    assert max(trace.index(t) for t in sends) < trace.index("forces diagonal-late")
+    assert sum(t.startswith("forces") for t in trace) == 2 + H
+    before = _run(tmp_path, "all", pos0, vel0, world, steps, "fast", workspace=True, WORKER_LATE_DIAGONAL="0")
+    old = bytes(before["trace_0"]).decode().split("\n")[:-1]
+    assert old[0] == "forces diagonal" and "forces diagonal-late" not in old and old[-1] == "finish" and old[-2] == sends[-1]
+    assert before["pos_0"].tobytes() != got["pos_0"].tobytes()
+    np.testing.assert_allclose(before["pos_0"], got["pos_0"], rtol=2e-6, atol=2e-6)
 
 
 @pytest.mark.gpu
@@ -327,22 +354,25 @@ def test_config4_shape_eight_ranks_at_one_mi_bodies(tmp_path, oracle):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("workspace", [False, True])
-def test_position_exchange_one_group_per_round(tmp_path, oracle, workspace):
-    """nb_comm_set_exchange_grouping(comm, 0): a group per round (tile k's event fires with round k) instead of the default one
-    group per step -- a per-communicator setting, so that one multi-GPU job can time both: the same bits -- STRICT == the CPU
-    path, FAST (one-sided tiles and pairwise across ranks) == the default.  The environment variable only sets the default."""
+def test_position_exchange_grouping_is_a_setting_not_a_result(tmp_path, oracle, workspace):
+    """nb_comm_set_exchange_grouping(comm, 1): all G-1 position rounds of a step in ONE RCCL group (round 4's default) instead of a
+    group and an event per round (the default since round 5: measured, profiles/round5_exchange_contention.jsonl) -- a
+    per-communicator setting, so that one multi-GPU job can time both: the same bits -- STRICT == the CPU path, FAST (one-sided
+    tiles and pairwise across ranks) == the default.  The environment variable only sets the default."""
     n, steps, world = 4096, 4, 4
     pos0, vel0 = oracle.startup_state(n, np.float32)
     ref_p, ref_v = pos0.copy(), vel0.copy()
     oracle.update(ref_p, ref_v, np.float32(0.016), steps=steps)
-    strict = _run(tmp_path, "all", pos0, vel0, world, steps, "strict", workspace=workspace, WORKER_ONE_GROUP="0")
+    reaction = (world // 2) * steps if workspace else 0  # (the reaction rounds of the pairwise step: always a group each)
+    strict = _run(tmp_path, "all", pos0, vel0, world, steps, "strict", workspace=workspace, WORKER_ONE_GROUP="1")
     assert strict["pos_0"].tobytes() == ref_p.tobytes()
     sends, recvs, gathers, groups, copies = strict["counters"]
-    assert sends == recvs == (world - 1) * world * steps and groups == (world - 1) * steps  # a group per round
-    fast = _run(tmp_path, "all", pos0, vel0, world, steps, "fast", workspace=workspace, WORKER_ONE_GROUP="0")
+    assert sends == recvs == (world - 1) * world * steps and groups == steps  # one group per step
+    fast = _run(tmp_path, "all", pos0, vel0, world, steps, "fast", workspace=workspace, WORKER_ONE_GROUP="1")
     default = _run(tmp_path, "all", pos0, vel0, world, steps, "fast", workspace=workspace)
-    explicit = _run(tmp_path, "all", pos0, vel0, world, steps, "fast", workspace=workspace, WORKER_ONE_GROUP="1", NBODY_EXCHANGE_ONE_GROUP="0")  # the API outranks the variable
-    by_env = _run(tmp_path, "all", pos0, vel0, world, steps, "fast", workspace=workspace, NBODY_EXCHANGE_ONE_GROUP="0")  # ... which is the default only
+    assert default["counters"][3] == (world - 1) * steps + reaction and fast["counters"][3] == steps + reaction
+    explicit = _run(tmp_path, "all", pos0, vel0, world, steps, "fast", workspace=workspace, WORKER_ONE_GROUP="0", NBODY_EXCHANGE_ONE_GROUP="1")  # the API outranks the variable
+    by_env = _run(tmp_path, "all", pos0, vel0, world, steps, "fast", workspace=workspace, NBODY_EXCHANGE_ONE_GROUP="1")  # ... which is the default only
     assert explicit["counters"][3] == default["counters"][3] and by_env["counters"][3] == fast["counters"][3] != default["counters"][3]
     for k in range(world):
         assert fast[f"pos_{k}"].tobytes() == default["pos_0"].tobytes()

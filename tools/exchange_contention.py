@@ -11,10 +11,9 @@ pair_forces for the chip as they would on a node; only the xGMI transfer time is
     *_one_sided          no workspace lent (the one-sided tile schedule)
     *_exchange_alone     the position exchange / the reaction leg on an otherwise idle chip
 
-    python3 tools/exchange_contention.py [--bodies 262144,1048576] [--world 8] [--rank 4] [--steps 60] [--rounds 5] [--reserve 0,8,16]
+    python3 tools/exchange_contention.py [--bodies 262144,1048576] [--world 8] [--rank 4] [--steps 60] [--rounds 5]
 
---reserve k: nb_comm_set_reserved_cus(comm, k) where the library has it (the pairwise launches of a rank leave k CUs to the
-exchange).  One JSON line per system and setting.  Positions are meaningless after the first loopback step; only the time counts."""
+One JSON line per world size and system.  Positions are meaningless after the first loopback step; only the time counts."""
 import argparse
 import ctypes
 import json
@@ -29,10 +28,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--bodies", default="262144,1048576")
-    ap.add_argument("--world", type=int, default=8)
+    ap.add_argument("--world", default="8", help="nominal world size(s), e.g. 2,4,8 (a communicator each)")
+    ap.add_argument("--phases", default="", help="comma-separated label prefixes: time only these phases (default: all)")
     ap.add_argument("--rank", type=int, default=-1, help="-1: world / 2")
     ap.add_argument("--steps", type=int, default=60)
-    ap.add_argument("--reserve", default="0")
     ap.add_argument("--rounds", type=int, default=5, help="how many times the phases take turns (the median over the rounds is reported)")
     ap.add_argument("--torch", action="store_true", help="import torch first (binds torch's RCCL, as bench.py does)")
     args = ap.parse_args()
@@ -44,14 +43,11 @@ def main():
     pkg = entry.load_package()
     lib = pkg.lib()
     pkg.check(lib.nb_set_device(0), "nb_set_device")
-    G, r = args.world, (args.world // 2 if args.rank < 0 else args.rank)
     pkg.check(lib.nb_set_softening_sq_f32(np.float32(0.01)))
     dt, damping = np.float32(0.016), np.float32(1.0)
-    comm = ctypes.c_void_p()
-    pkg.check(lib.nb_comm_loopback_open(ctypes.byref(comm), pkg.comm_unique_id(), G, r), "nb_comm_loopback_open")
     stream = ctypes.c_void_p()
     pkg.check(lib.nb_stream_create(ctypes.byref(stream)), "nb_stream_create")
-    has_reserve = hasattr(lib, "nb_comm_set_reserved_cus")
+    wanted = [w for w in args.phases.split(",") if w]
 
     def timed(fn, reps, after=None):
         fn()
@@ -67,78 +63,77 @@ def main():
         pkg.check(lib.nb_device_synchronize())
         return round(e0.elapsed_ms(e1) / reps, 4)
 
-    for n in [int(x) for x in args.bodies.split(",")]:
-        pos0, vel0 = make_bodies(n, np.float32)
-        bufs = [pkg.DeviceBuffer(pos0.nbytes) for _ in range(4)]  # pos a, pos b, vel, acc
-        bufs[0].upload(pos0), bufs[1].upload(pos0), bufs[2].upload(vel0)
-        job = pkg.ShardedRank(None, G, r, [bufs[0].ptr.value, bufs[1].ptr.value], bufs[2].ptr.value, bufs[3].ptr.value, n, np.float32, pkg.NB_MODE_FAST, 256, stream, comm=comm)
-        need = 0
-        for late in (1, 0):  # (the two forms of the diagonal want different numbers of planes: lend the larger amount to both)
-            pkg.check(lib.nb_set_late_diagonal(late))
-            need = max(need, job.workspace_bytes())
-        pkg.check(lib.nb_set_late_diagonal(1))
-        work = pkg.DeviceBuffer(need) if need else None
-        ni = n // G
-        size = ctypes.c_size_t(need)
+    for G in [int(x) for x in args.world.split(",")]:
+        r = G // 2 if args.rank < 0 else args.rank
+        comm = ctypes.c_void_p()
+        pkg.check(lib.nb_comm_loopback_open(ctypes.byref(comm), pkg.comm_unique_id(), G, r), "nb_comm_loopback_open")
+        for n in [int(x) for x in args.bodies.split(",")]:
+            pos0, vel0 = make_bodies(n, np.float32)
+            bufs = [pkg.DeviceBuffer(pos0.nbytes) for _ in range(4)]  # pos a, pos b, vel, acc
+            bufs[0].upload(pos0), bufs[1].upload(pos0), bufs[2].upload(vel0)
+            job = pkg.ShardedRank(None, G, r, [bufs[0].ptr.value, bufs[1].ptr.value], bufs[2].ptr.value, bufs[3].ptr.value, n, np.float32, pkg.NB_MODE_FAST, 256, stream, comm=comm)
+            need = 0
+            for late in (1, 0):  # (the two forms of the diagonal want different numbers of planes: lend the larger amount to both)
+                pkg.check(lib.nb_set_late_diagonal(late))
+                need = max(need, job.workspace_bytes())
+            pkg.check(lib.nb_set_late_diagonal(1))
+            work = pkg.DeviceBuffer(need) if need else None
+            ni = n // G
+            size = ctypes.c_size_t(need)
 
-        def emulate():
-            pkg.check(lib.nb_emulate_pair_rank_f32(bufs[1].ptr, bufs[0].ptr, bufs[2].ptr, work.ptr, ctypes.byref(size), n, G, r, dt, damping, stream), "nb_emulate_pair_rank")
+            def emulate():
+                pkg.check(lib.nb_emulate_pair_rank_f32(bufs[1].ptr, bufs[0].ptr, bufs[2].ptr, work.ptr, ctypes.byref(size), n, G, r, dt, damping, stream), "nb_emulate_pair_rank")
 
-        def tiles():
-            for t in range(G):
-                peer = (r + t) % G
-                flags = (pkg.NB_SHARD_ACC_IN if t else 0) | (pkg.NB_SHARD_FINALIZE if t == G - 1 else 0)
-                pkg.check(lib.nb_integrate_shard_f32(bufs[1].ptr, bufs[0].ptr, bufs[2].ptr, bufs[3].ptr, r * ni, ni, peer * ni, ni, flags, dt, damping, 256, pkg.NB_MODE_FAST, stream), "nb_integrate_shard")
+            def tiles():
+                for t in range(G):
+                    peer = (r + t) % G
+                    flags = (pkg.NB_SHARD_ACC_IN if t else 0) | (pkg.NB_SHARD_FINALIZE if t == G - 1 else 0)
+                    pkg.check(lib.nb_integrate_shard_f32(bufs[1].ptr, bufs[0].ptr, bufs[2].ptr, bufs[3].ptr, r * ni, ni, peer * ni, ni, flags, dt, damping, 256, pkg.NB_MODE_FAST, stream), "nb_integrate_shard")
 
-        def configure(layout, one_group, late=1, reserve=0):
-            pkg.check(lib.nb_set_late_diagonal(late))
-            if has_reserve:
-                pkg.check(lib.nb_comm_set_reserved_cus(comm, reserve), "nb_comm_set_reserved_cus")
-            job.set_workspace(work.ptr if layout == "pairwise" else None, need if layout == "pairwise" else 0)
-            assert job.pairwise() == (layout == "pairwise")
-            job.set_exchange_grouping(one_group)
+            def configure(layout, one_group, late=1):
+                pkg.check(lib.nb_set_late_diagonal(late))
+                job.set_workspace(work.ptr if layout == "pairwise" else None, need if layout == "pairwise" else 0)
+                assert job.pairwise() == (layout == "pairwise")
+                job.set_exchange_grouping(one_group)
 
-        step = lambda: job.update(dt, damping)  # noqa: E731
-        # phase: label -> (configure arguments, what one repetition does, what ends the timed stretch)
-        phases = {}
-        for reserve in [int(x) for x in args.reserve.split(",")]:
-            if reserve and not has_reserve:
-                continue
-            tag = f"_reserve{reserve}" if reserve else ""
+            step = lambda: job.update(dt, damping)  # noqa: E731
+            # phase: label -> (configure arguments, what one repetition does, what ends the timed stretch)
+            phases = {}
             if work is not None:
                 for late in (1, 0):
                     for og in (True, False):
-                        phases[f"step_pairwise_late{late}_{'one_group' if og else 'group_per_round'}{tag}"] = (("pairwise", og, late, reserve), step, job.finish)
-                    phases[f"kernels_alone_pairwise_late{late}{tag}"] = (("pairwise", True, late, reserve), emulate, None)
-            if not reserve:
-                for og in (True, False):
-                    phases[f"step_one_sided_{'one_group' if og else 'group_per_round'}"] = (("one_sided", og), step, job.finish)
-                phases["kernels_alone_one_sided"] = (("one_sided", True), tiles, None)
-                for og in (True, False):
-                    phases[f"position_exchange_alone_{'one_group' if og else 'group_per_round'}"] = (("one_sided", og), lambda: job.exchange_once(0), None)
-                if work is not None:
-                    phases["reaction_exchange_alone"] = (("pairwise", True), job.reaction_exchange_once, None)
-        # the phases take turns, `--rounds` times over: the clock the power management grants drifts over a run, so back-to-back
-        # stretches of ONE phase each would compare clocks, not schedules
-        samples = {label: [] for label in phases}
-        for _ in range(args.rounds):
-            for label, (config, fn, after) in phases.items():
-                configure(*config)
-                samples[label].append(timed(fn, args.steps, after))
-        row = {"bodies": n, "nominal_world": G, "nominal_rank": r, "steps_per_stretch": args.steps, "rounds": args.rounds, "position_tile_bytes": ni * 16,
-               "reaction_array_bytes": ni * 12, "workspace_bytes": need, **pkg.comm_transport_info(comm),
-               "what": "ms per repetition: median over the rounds (phases interleaved); *_min: the fastest stretch"}
-        for label, got in samples.items():
-            got = sorted(got)
-            row[label] = got[len(got) // 2]
-            row[label + "_min"] = got[0]
-        print(json.dumps(row), flush=True)
-        configure("one_sided", True)
-        pkg.check(lib.nb_device_synchronize())
-        for b in bufs + ([work] if work is not None else []):
-            b.free()
+                        phases[f"step_pairwise_late{late}_{'one_group' if og else 'group_per_round'}"] = (("pairwise", og, late), step, job.finish)
+                    phases[f"kernels_alone_pairwise_late{late}"] = (("pairwise", True, late), emulate, None)
+            for og in (True, False):
+                phases[f"step_one_sided_{'one_group' if og else 'group_per_round'}"] = (("one_sided", og), step, job.finish)
+            phases["kernels_alone_one_sided"] = (("one_sided", True), tiles, None)
+            for og in (True, False):
+                phases[f"position_exchange_alone_{'one_group' if og else 'group_per_round'}"] = (("one_sided", og), lambda: job.exchange_once(0), None)
+            if work is not None:
+                phases["reaction_exchange_alone"] = (("pairwise", True), job.reaction_exchange_once, None)
+            # the phases take turns, `--rounds` times over: the clock the power management grants drifts over a run, so back-to-back
+            # stretches of ONE phase each would compare clocks, not schedules
+            if wanted:
+                phases = {label: what for label, what in phases.items() if any(label.startswith(w) for w in wanted)}
+            samples = {label: [] for label in phases}
+            for _ in range(args.rounds):
+                for label, (config, fn, after) in phases.items():
+                    configure(*config)
+                    samples[label].append(timed(fn, args.steps, after))
+            row = {"bodies": n, "nominal_world": G, "nominal_rank": r, "steps_per_stretch": args.steps, "rounds": args.rounds, "position_tile_bytes": ni * 16,
+                   "reaction_array_bytes": ni * 12, "workspace_bytes": need, **pkg.comm_transport_info(comm),
+                   "what": "ms per repetition: median over the rounds (phases interleaved); *_min: the fastest stretch"}
+            for label, got in samples.items():
+                got = sorted(got)
+                row[label] = got[len(got) // 2]
+                row[label + "_min"] = got[0]
+            print(json.dumps(row), flush=True)
+            configure("one_sided", True)
+            pkg.check(lib.nb_device_synchronize())
+            for b in bufs + ([work] if work is not None else []):
+                b.free()
+        pkg.check(lib.nb_comm_destroy(comm))
     pkg.check(lib.nb_stream_destroy(stream))
-    pkg.check(lib.nb_comm_destroy(comm))
 
 
 if __name__ == "__main__":
