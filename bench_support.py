@@ -361,7 +361,7 @@ def rank_projection(pkg, lib, n, dtype, dt, damping, single_ms):
     return out
 
 
-def loopback_projection(n, single_ms, worlds=(2, 4, 8), timeout_s=150):
+def loopback_projection(n, single_ms, worlds=(2, 4, 8), timeout_s=180):
     import json
     import subprocess
 
@@ -372,23 +372,26 @@ def loopback_projection(n, single_ms, worlds=(2, 4, 8), timeout_s=150):
     env = dict(os.environ)
     for name in ("NBODY_RCCL_LIB", "FAKE_RCCL_IPC", "NCCL_DEBUG"):
         env.pop(name, None)
-    try:
-        done = subprocess.run([sys.executable, tool, "--torch", "--bodies", str(n), "--world", ",".join(str(g) for g in worlds), "--steps", "40", "--rounds", "3",
-                               "--phases", "step_pairwise_late1_group_per_round,kernels_alone_pairwise_late1"], capture_output=True, text=True, timeout=timeout_s, env=env)
-    except subprocess.TimeoutExpired:
-        got["error"] = f"the child did not finish within {timeout_s} s"
-        return got
-    for text in done.stdout.splitlines():
-        if not text.startswith("{"):
-            continue
-        row = json.loads(text)
-        step, alone = row.get("step_pairwise_late1_group_per_round"), row.get("kernels_alone_pairwise_late1")
-        if step:
-            got["ranks"][str(row["nominal_world"])] = {"step_ms": step, "kernels_alone_ms": alone, "exposed_exchange_ms": None if alone is None else round(step - alone, 4),
-                                                       "speedup_excl_link_time": round(single_ms / step, 2)}
-            got["rccl_version"], got["rccl_library"] = row.get("rccl_version"), row.get("rccl_library")
-    if done.returncode != 0 or not got["ranks"]:
-        got["error"] = f"exit status {done.returncode}: " + done.stderr.strip().splitlines()[-1][:300] if done.stderr.strip() else f"exit status {done.returncode}"
+    # one child per world size: a process that has brought up and destroyed one communicator after another has been seen to time the
+    # LATER worlds' kernels-alone figure at twice its value (the two streams of nb_emulate_pair_rank_* no longer overlapping --
+    # the runtime maps streams onto a few hardware queues as they come and go), gpurun call r5g
+    for world in worlds:
+        try:
+            done = subprocess.run([sys.executable, tool, "--torch", "--bodies", str(n), "--world", str(world), "--steps", "40", "--rounds", "3",
+                                   "--phases", "step_pairwise_late1_group_per_round,kernels_alone_pairwise_late1"], capture_output=True, text=True, timeout=timeout_s / len(worlds), env=env)
+        except subprocess.TimeoutExpired:
+            got["error"] = f"the child for {world} ranks did not finish within {timeout_s / len(worlds):.0f} s"
+            break
+        rows = [json.loads(text) for text in done.stdout.splitlines() if text.startswith("{")]
+        for row in rows:
+            step, alone = row.get("step_pairwise_late1_group_per_round"), row.get("kernels_alone_pairwise_late1")
+            if step:
+                got["ranks"][str(row["nominal_world"])] = {"step_ms": step, "kernels_alone_ms": alone, "exposed_exchange_ms": None if alone is None else round(step - alone, 4),
+                                                           "speedup_excl_link_time": round(single_ms / step, 2)}
+                got["rccl_version"], got["rccl_library"] = row.get("rccl_version"), row.get("rccl_library")
+        if done.returncode != 0 or not rows:
+            got["error"] = f"{world} ranks: exit status {done.returncode}" + (": " + done.stderr.strip().splitlines()[-1][:300] if done.stderr.strip() else "")
+            break
     return got
 
 

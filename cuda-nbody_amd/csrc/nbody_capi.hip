@@ -127,7 +127,7 @@ struct StepGraph {
 };
 
 // Fewer bodies than this and the pairwise layout loses to the one-sided kernels (measured: profiles/round3_pair_crossover_*.jsonl
-// and the finer sweep in DESIGN.md section 5: fp32 8 192 bodies 29.4 against 27.1 us, 10 240 bodies 44.8 against 51.5 us;
+// and the finer sweep in docs/history.md section 5: fp32 8 192 bodies 29.4 against 27.1 us, 10 240 bodies 44.8 against 51.5 us;
 // fp64 4 096 bodies 24.3 / 18.9 us, 6 144 bodies 38.5 / 40.8 us; round 4, with the wave-split tiles of 512 bodies: exactly 6 144 bodies
 // -- 384 workgroups -- 43.7 against 33.9 us, 6 145 bodies 43.3 / 43.8, 7 000 bodies 44.9 / 48.4, 8 193 bodies 50.3 / 76.4)
 template <typename T> constexpr unsigned kPairMinBodies = sizeof(T) == 4 ? 8193u : 6145u;

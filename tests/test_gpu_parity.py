@@ -86,7 +86,7 @@ def rel_err(a, b):
 
 @pytest.mark.parametrize("n", [8, 256, 1024, 4096])
 def test_fast_fp32_vs_golden(gpu, n):
-    """FAST against the CPU path's trajectory.  Measured max / p99 / median per horizon: DESIGN.md section 5 (table from
+    """FAST against the CPU path's trajectory.  Measured max / p99 / median per horizon: docs/history.md section 5, "FAST accuracy" (table from
     tools/fast_error_table.py, profiles/round2_fast_vs_cpu_path_errors.json).  The system is chaotic: by 100 steps single
     bodies that went through a close encounter are off by 1e-3..1e-2 (as two roundings of the CPU code itself are), so
     the 100-step bar is on the median and the 99th percentile, not the max."""
@@ -103,7 +103,7 @@ def test_fast_fp32_vs_golden(gpu, n):
     assert errs[1].max() <= 2e-6, errs[1].max()
     assert errs[10].max() <= 2e-5, errs[10].max()
     if 100 in errs:
-        # the measured envelope: N = 1024: max 1.8e-3, p99 8.5e-4, median 2.4e-5; N = 256: 4.7e-5 / 2.6e-5 / 1.7e-7
+        # the measured envelope (docs/history.md section 5): N = 1024: max 1.8e-3, p99 8.5e-4, median 2.4e-5; N = 256: 4.7e-5 / 2.6e-5 / 1.7e-7
         assert np.median(errs[100]) <= 5e-5, np.median(errs[100])  # the north_star figure is 1e-4: met on the median
         assert np.percentile(errs[100], 99) <= 2e-3, np.percentile(errs[100], 99)
         assert errs[100].max() <= 1e-2, errs[100].max()  # bodies that went through a close encounter (chaos, see below)

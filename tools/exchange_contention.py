@@ -28,7 +28,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--bodies", default="262144,1048576")
-    ap.add_argument("--world", default="8", help="nominal world size(s), e.g. 2,4,8 (a communicator each)")
+    ap.add_argument("--world", default="8", help="nominal world size(s), e.g. 2,4,8 (a communicator each).  PREFER ONE PER PROCESS: after one communicator has been "
+                                                  "destroyed and the next made, the kernels-alone phase has been seen at twice its time (its two streams no longer overlapping)")
     ap.add_argument("--phases", default="", help="comma-separated label prefixes: time only these phases (default: all)")
     ap.add_argument("--rank", type=int, default=-1, help="-1: world / 2")
     ap.add_argument("--steps", type=int, default=60)
