@@ -179,6 +179,7 @@ TUNING_SIGNATURES = {
     "nb_comm_self_transfer_f32": (_ci, [_vp, _vp, _vp, _sz, _ci, _ci, _vp, _vp, _vp]),
     "nb_comm_transport_info": (_ci, [_vp, _P(_ci), ctypes.c_char_p, _sz]),
     "nb_comm_last_step_trace": (_ci, [_vp, ctypes.c_char_p, _sz]),
+    "nb_comm_side_stream_collisions": (_ci, [_vp, _P(_ci)]),
     "nb_comm_pair_work_f32": (_ci, [_vp, _cu, _P(ctypes.c_ulonglong), _P(_ci)]),
     "nb_comm_pair_work_f64": (_ci, [_vp, _cu, _P(ctypes.c_ulonglong), _P(_ci)]),
 }
@@ -516,6 +517,9 @@ class ShardedRank:
         check(lib().nb_comm_info(self.comm, ctypes.byref(r), ctypes.byref(w), ctypes.byref(d)), "nb_comm_info")
         out = {"rank": r.value, "world": w.value, "device": d.value}
         out.update(comm_transport_info(self.comm))
+        hits = _ci(-1)
+        check(lib().nb_comm_side_stream_collisions(self.comm, ctypes.byref(hits)), "nb_comm_side_stream_collisions")
+        out["side_stream_collisions"] = hits.value  # (-1: never probed -- no pairwise step with two partners yet)
         return out
 
     def pair_work(self):

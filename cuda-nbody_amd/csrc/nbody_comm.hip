@@ -126,6 +126,10 @@ struct Comm {
     hipStream_t aux       = nullptr;       // pairwise step: every other rectangle runs here, so that the tails and launch gaps of
     hipEvent_t  aux_begin = nullptr;       // one stream's kernels are filled by the other's (events: aux may start / aux is done)
     hipEvent_t  aux_done  = nullptr;
+    hipStream_t aux_settled_beside = nullptr;  // the caller's stream `aux` was last probed against (settle_side_stream); aux_probed: whether it ever was
+    bool        aux_probed = false;
+    int         aux_collisions = 0;        // how many candidates shared a hardware queue with the caller's stream (nb_comm_transport_info reports it)
+    std::vector<hipStream_t> aux_retired;  // ... kept until the communicator goes
     std::vector<hipEvent_t> react_ready;   // [world/2 + 1] pairwise step: "the reaction sums for partner s are in the send buffer" (compute stream)
     std::vector<hipEvent_t> react_arrived; // [world/2 + 1] ... "round s of the reaction exchange is done" (exchange stream)
     std::vector<Comm*> group;              // all local ranks of this communicator (just {this} with one process per GPU)
@@ -162,6 +166,81 @@ class DeviceScope {  // switch device for a few calls, restore on exit (single-p
     int saved_ = 0;
 };
 
+// ---- the second compute stream of a pairwise step (every other rectangle runs there, next to the caller's stream) ----------------
+// The HIP runtime maps the streams of one priority onto a small pool of hardware queues (four by default, GPU_MAX_HW_QUEUES) and
+// lets a fifth stream SHARE a queue; two streams on one queue run their kernels strictly one after the other.  RCCL brings
+// streams of its own, so a stream made after a communicator is up can land on the caller's queue -- measured (round 5, gpurun
+// calls r5k / r5l): one rank's kernels of an 8-rank step 2.31 ms instead of 1.25, every kernel starting exactly where the other
+// stream's ended.  Another priority is no way out: the pools are per priority, but a queue of lower OR higher priority does not
+// run side by side with the caller's (the same step 1.77 ms either way), and a CU-masked stream -- a queue of its own -- is a
+// blocking stream that would synchronise with a caller computing on the null stream.  So the stream is made at the caller's
+// priority and PROBED against the caller's stream the first time the two meet: two ~40 us spin kernels, one on each, started
+// together; had they run one after the other, another stream is made (the collided ones are kept until the communicator
+// goes, so that the pool moves on) -- up to eight times.
+__global__ void queue_probe_spin(unsigned long long ticks, unsigned* sink) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz, whatever the shader clock
+    unsigned                 x  = threadIdx.x;
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) x = x * 1664525u + 1013904223u;
+    if (x == 0x9e3779b9u) *sink = x;
+}
+
+// do kernels on `a` and `b` overlap?  (both streams are synchronised first: a one-off cost, the first time a pair of streams meets)
+bool streams_run_side_by_side(hipStream_t a, hipStream_t b) {
+    static unsigned* sink[64] = {};
+    int              dev      = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;
+    if (sink[dev] == nullptr && hipMalloc(reinterpret_cast<void**>(&sink[dev]), sizeof(unsigned)) != hipSuccess) {
+        (void)hipGetLastError();
+        return true;  // (cannot tell: keep what there is)
+    }
+    hipEvent_t begin = nullptr, end_a = nullptr, end_b = nullptr;
+    bool       side_by_side = true;
+    if (hipEventCreate(&begin) == hipSuccess && hipEventCreate(&end_a) == hipSuccess && hipEventCreate(&end_b) == hipSuccess &&
+        hipStreamSynchronize(a) == hipSuccess && hipStreamSynchronize(b) == hipSuccess) {
+        constexpr unsigned long long kTicks = 4000;  // 40 us
+        float best = 1e30f;
+        for (int attempt = 0; attempt < 3; ++attempt) {  // (the shortest of three: a preempted attempt must not read as a shared queue)
+            (void)hipEventRecord(begin, a);
+            (void)hipStreamWaitEvent(b, begin, 0);
+            hipLaunchKernelGGL(queue_probe_spin, dim3(1), dim3(64), 0, a, kTicks, sink[dev]);
+            hipLaunchKernelGGL(queue_probe_spin, dim3(1), dim3(64), 0, b, kTicks, sink[dev]);
+            (void)hipEventRecord(end_a, a);
+            (void)hipEventRecord(end_b, b);
+            float ms_a = 0, ms_b = 0;
+            if (hipEventSynchronize(end_a) != hipSuccess || hipEventSynchronize(end_b) != hipSuccess || hipEventElapsedTime(&ms_a, begin, end_a) != hipSuccess ||
+                hipEventElapsedTime(&ms_b, begin, end_b) != hipSuccess) {
+                best = 0;
+                break;
+            }
+            best = std::min(best, std::max(ms_a, ms_b));
+        }
+        side_by_side = best < 0.070f;  // two 40 us kernels one after the other take 80 us and more
+    }
+    (void)hipGetLastError();
+    for (hipEvent_t e : {begin, end_a, end_b})
+        if (e != nullptr) (void)hipEventDestroy(e);
+    return side_by_side;
+}
+
+// `side` runs next to `beside` from now on: make sure it can (see above).  `retired`: streams that collided, destroyed with their owner.
+// NBODY_AUX_PROBE=0 switches the probe off (for A/B timings of the collision itself).
+hipError_t settle_side_stream(hipStream_t* side, hipStream_t beside, std::vector<hipStream_t>* retired, int* collisions) {
+    static const bool probing = [] {
+        const char* v = std::getenv("NBODY_AUX_PROBE");
+        return v == nullptr || v[0] != '0';
+    }();
+    if (*side == nullptr) {
+        if (const auto err = hipStreamCreateWithFlags(side, hipStreamNonBlocking); err != hipSuccess) return err;
+    }
+    for (int attempt = 0; probing && attempt < 8 && !streams_run_side_by_side(beside, *side); ++attempt) {
+        if (collisions != nullptr) ++*collisions;
+        retired->push_back(*side);
+        *side = nullptr;
+        if (const auto err = hipStreamCreateWithFlags(side, hipStreamNonBlocking); err != hipSuccess) return err;
+    }
+    return hipSuccess;
+}
+
 int make_resources(Comm* c) {
     DeviceScope scope(c->device);
     int         lo = 0, hi = 0;
@@ -170,7 +249,7 @@ int make_resources(Comm* c) {
     if (err != hipSuccess) return static_cast<int>(err);
     err = hipEventCreateWithFlags(&c->ready, hipEventDisableTiming);
     if (err != hipSuccess) return static_cast<int>(err);
-    err = hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking);
+    err = hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking);  // (probed against the caller's stream at its first pairwise step: settle_side_stream)
     if (err == hipSuccess) err = hipEventCreateWithFlags(&c->aux_begin, hipEventDisableTiming);
     if (err == hipSuccess) err = hipEventCreateWithFlags(&c->aux_done, hipEventDisableTiming);
     if (err != hipSuccess) return static_cast<int>(err);
@@ -201,6 +280,7 @@ void free_resources(Comm* c) {
     if (c->aux_begin) (void)hipEventDestroy(c->aux_begin);
     if (c->aux_done) (void)hipEventDestroy(c->aux_done);
     if (c->aux) (void)hipStreamDestroy(c->aux);
+    for (hipStream_t s : c->aux_retired) (void)hipStreamDestroy(s);
     if (c->stream) (void)hipStreamDestroy(c->stream);
 }
 
@@ -538,6 +618,10 @@ int pair_sharded_step(const std::vector<Comm*>& locals, const PairShard& plan, T
         Comm*       c = locals[k];
         DeviceScope scope(c->device);
         const bool  waiting = c->in_flight == static_cast<const void*>(old_pos[k]);
+        if (plan.H >= 2 && (!c->aux_probed || c->aux_settled_beside != reinterpret_cast<hipStream_t>(streams[k]))) {  // (the second stream is used from two partners on)
+            if (const auto err = settle_side_stream(&c->aux, reinterpret_cast<hipStream_t>(streams[k]), &c->aux_retired, &c->aux_collisions); err != hipSuccess) return static_cast<int>(err);
+            c->aux_probed = true, c->aux_settled_beside = reinterpret_cast<hipStream_t>(streams[k]);
+        }
         const int   rc = pair_rank_tiles<T>(c, static_cast<unsigned>(c->rank), G, plan, static_cast<T*>(c->workspace), new_pos[k], old_pos[k], vel[k], num_bodies, dt, damping, eps2,
                                             reinterpret_cast<hipStream_t>(streams[k]), waiting, finish[k], c->aux, c->aux_begin, c->aux_done, kBeforeSends);
         if (rc != 0) return rc;
@@ -704,17 +788,22 @@ template <typename T> int emulate_pair_rank(T* new_pos, const T* old_pos, T* vel
     hipStream_t       s  = reinterpret_cast<hipStream_t>(stream);
     // the second stream of the step, as a communicator would own it (one per device, created on first use, never destroyed)
     static std::mutex  guard;
-    static hipStream_t aux[64]   = {};
+    static hipStream_t aux[64]   = {}, beside[64] = {};
+    static bool        probed[64] = {};
     static hipEvent_t  begin[64] = {}, done[64] = {};
+    static std::vector<hipStream_t> retired;
     int                dev       = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return NB_ERR_INVALID_ARGUMENT;
     {
         std::lock_guard<std::mutex> lock(guard);
-        if (aux[dev] == nullptr && std::getenv("NBODY_PAIR_ONE_STREAM") == nullptr) {
+        if (std::getenv("NBODY_PAIR_ONE_STREAM") == nullptr) {
             NB_KEEP_RAND_STREAM;
-            if (hipStreamCreateWithFlags(&aux[dev], hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&begin[dev], hipEventDisableTiming) != hipSuccess ||
-                hipEventCreateWithFlags(&done[dev], hipEventDisableTiming) != hipSuccess)
+            if (begin[dev] == nullptr && (hipEventCreateWithFlags(&begin[dev], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&done[dev], hipEventDisableTiming) != hipSuccess))
                 return NB_ERR_UNSUPPORTED;
+            if (aux[dev] == nullptr || (plan.H >= 2 && (!probed[dev] || beside[dev] != s))) {  // (as a communicator does: a second stream that really runs beside this one)
+                if (settle_side_stream(&aux[dev], s, &retired, nullptr) != hipSuccess) return NB_ERR_UNSUPPORTED;
+                probed[dev] = plan.H >= 2, beside[dev] = s;
+            }
         }
     }
     const int rc = pair_rank_tiles<T>(nullptr, static_cast<unsigned>(rank), world, plan, static_cast<T*>(workspace), new_pos, old_pos, vel, num_bodies, dt, damping, eps2, s, false, f, aux[dev], begin[dev], done[dev]);
@@ -1108,6 +1197,13 @@ int nb_comm_selftest_f32(nb_comm_t comm, size_t bytes, nb_stream_t stream, nb_co
     }
     if (result == 0 && (report->send_recv_wrong_bytes != 0 || report->all_gather_wrong_bytes != 0)) result = NB_ERR_UNSUPPORTED;
     return result;
+}
+
+int nb_comm_side_stream_collisions(nb_comm_t comm, int* collisions) {
+    Comm* c = as_comm(comm);
+    if (c == nullptr || collisions == nullptr) return NB_ERR_INVALID_ARGUMENT;
+    *collisions = c->aux_probed ? c->aux_collisions : -1;
+    return 0;
 }
 
 int nb_comm_last_step_trace(nb_comm_t comm, char* text, size_t bytes) {

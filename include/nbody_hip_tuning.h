@@ -92,6 +92,12 @@ NB_API int nb_comm_transport_info(nb_comm_t comm, int* rccl_version, char* libra
 NB_API int nb_comm_pair_work_f32(nb_comm_t comm, unsigned num_bodies, unsigned long long* pair_evaluations, int* force_launches);
 NB_API int nb_comm_pair_work_f64(nb_comm_t comm, unsigned num_bodies, unsigned long long* pair_evaluations, int* force_launches);
 
+/* The second compute stream of a pairwise multi-GPU step must run BESIDE the caller's stream; the HIP runtime lets streams share a
+ * hardware queue once a process has more than a few, and two streams on one queue run one after the other.  A communicator
+ * probes its side stream against the caller's the first time the two meet and replaces it while they collide (csrc/nbody_comm.hip,
+ * settle_side_stream; NBODY_AUX_PROBE=0 switches that off).  *collisions: how many candidates were replaced; -1: not probed yet. */
+NB_API int nb_comm_side_stream_collisions(nb_comm_t comm, int* collisions);
+
 /* What this rank's LAST pairwise multi-GPU step enqueued, in host order, one item per line: "forces diagonal-early", "forces
  * rectangle s", "fold s", "send reaction s", "forces diagonal-late", "finish" (empty before the first such step).  Tests read the
  * ORDER from it: every reaction send is enqueued before the rank's last force kernel. */

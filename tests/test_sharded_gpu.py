@@ -243,3 +243,28 @@ def test_real_rccl_self_loop_through_the_hand_resolved_entry_points(torch_first)
     for c in calls:
         assert c["rc"] == 0 and c["send_recv_status"] == 0 and c["all_gather_status"] == 0 and c["refused_call"] == ""
         assert c["send_recv_wrong_bytes"] == 0 and c["all_gather_wrong_bytes"] == 0 and 0 < c["send_recv_ms"] < 50 and 0 < c["all_gather_ms"] < 50
+
+
+@pytest.mark.gpu
+def test_second_compute_stream_runs_beside_the_first_in_a_crowded_process():
+    """Round 5 (profiles/round5_hw_queue_collision.txt): the HIP runtime lets streams SHARE a hardware queue once a process has more
+    than a few -- RCCL brings its own -- and two streams on one queue run their kernels one after the other: the two-stream overlap
+    of a pairwise multi-GPU step (every other rectangle on a second stream) silently becomes a serial schedule, 2.31 ms instead of
+    1.25 for one rank of eight.  The library probes its second stream against the caller's the first time the two meet and
+    replaces it while they collide.  The scenario in which the collision was found: a loopback rank (real RCCL) steps first, then
+    nb_emulate_pair_rank_f32 makes ITS second stream in the by-then crowded process -- the same kernels must take the same time
+    with and without the communicator.  (NBODY_AUX_PROBE=0 reproduces the collision; not asserted, the runtime's mapping is its own.)"""
+    import json
+    import subprocess
+    import sys
+
+    env = dict(os.environ)
+    for name in ("NBODY_RCCL_LIB", "NCCL_DEBUG", "FAKE_RCCL_IPC", "NBODY_AUX_PROBE"):
+        env.pop(name, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "exchange_contention.py"), "--bodies", "262144", "--world", "8", "--steps", "20", "--rounds", "2",
+                          "--phases", "step_pairwise_late1_group_per_round,kernels_alone_pairwise_late1"], capture_output=True, text=True, timeout=240, env=env)
+    rows = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    assert out.returncode == 0 and len(rows) == 1, (out.stdout[-1500:], out.stderr[-1500:])
+    step, alone = rows[0]["step_pairwise_late1_group_per_round"], rows[0]["kernels_alone_pairwise_late1"]
+    assert rows[0]["side_stream_collisions"] >= 0  # (the communicator's own second stream was probed)
+    assert 0.85 * step < alone < 1.08 * step, (step, alone)  # a shared queue reads ~1.8x

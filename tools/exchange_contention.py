@@ -124,6 +124,7 @@ def main():
             row = {"bodies": n, "nominal_world": G, "nominal_rank": r, "steps_per_stretch": args.steps, "rounds": args.rounds, "position_tile_bytes": ni * 16,
                    "reaction_array_bytes": ni * 12, "workspace_bytes": need, **pkg.comm_transport_info(comm),
                    "what": "ms per repetition: median over the rounds (phases interleaved); *_min: the fastest stretch"}
+            row["side_stream_collisions"] = job.info()["side_stream_collisions"]  # candidates for the second compute stream that shared a hardware queue with the first
             for label, got in samples.items():
                 got = sorted(got)
                 row[label] = got[len(got) // 2]
