@@ -217,7 +217,7 @@ def test_default_line_carries_every_baseline_config():
         assert c["ms_per_step"] > 0 and 0 < c["frac_algorithmic"] < 1.3  # (pairwise: the algorithmic count may pass the one-sided peak)
         assert 0 < c["executed_frac"] < 1  # ... which is why the flop really issued stand next to it, and never pass 1
         assert (c["executed_frac"] < c["frac_algorithmic"]) == (c["layout"] == "pairwise")
-        assert c["valu_busy"] is None or 0.1 < c["valu_busy"] <= 1.0  # the hardware's own figure, where a committed PMC pass matches the plan
+        assert c["valu_busy"] is None or 0.1 < c["valu_busy"] <= 1.02  # the hardware's own figure (a ratio of two sampled counters: the fp64 kernel reads 1.007), where a committed PMC pass matches the plan
     by_size = {(c["bodies"], c["layout"]): c for c in line["configs"] if c["dtype"] == "f32" and c["mode"] == "fast"}
     for n in (16384, 65536):  # the hipGraph form timed next to the eager steps
         assert by_size[(n, "pairwise")]["hipgraph_ms_per_step"] > 0 and -0.5 < by_size[(n, "pairwise")]["hipgraph_gain"] < 1.0
