@@ -50,18 +50,28 @@ def main():
     pkg.check(lib.nb_stream_create(ctypes.byref(stream)), "nb_stream_create")
     wanted = [w for w in args.phases.split(",") if w]
 
-    def timed(fn, reps, after=None):
+    host_ms = {}
+
+    def timed(fn, reps, after=None, label=None):
+        """ms per repetition on the stream (events); host_ms[label]: what the HOST needs to enqueue one repetition (the loop's wall
+        clock before anything is waited for) -- a step whose enqueue takes longer than its kernels is bound by the host"""
+        import time
+
         fn()
         (after or (lambda: None))()
         pkg.check(lib.nb_device_synchronize())
         e0, e1 = pkg.Event(), pkg.Event()
         e0.record(stream)
+        t0 = time.perf_counter()
         for _ in range(reps):
             fn()
+        t1 = time.perf_counter()
         (after or (lambda: None))()
         e1.record(stream)
         e1.synchronize()
         pkg.check(lib.nb_device_synchronize())
+        if label is not None:
+            host_ms.setdefault(label, []).append((t1 - t0) / reps * 1e3)
         return round(e0.elapsed_ms(e1) / reps, 4)
 
     for G in [int(x) for x in args.world.split(",")]:
@@ -120,7 +130,7 @@ def main():
             for _ in range(args.rounds):
                 for label, (config, fn, after) in phases.items():
                     configure(*config)
-                    samples[label].append(timed(fn, args.steps, after))
+                    samples[label].append(timed(fn, args.steps, after, label))
             row = {"bodies": n, "nominal_world": G, "nominal_rank": r, "steps_per_stretch": args.steps, "rounds": args.rounds, "position_tile_bytes": ni * 16,
                    "reaction_array_bytes": ni * 12, "workspace_bytes": need, **pkg.comm_transport_info(comm),
                    "what": "ms per repetition: median over the rounds (phases interleaved); *_min: the fastest stretch"}
@@ -129,7 +139,10 @@ def main():
                 got = sorted(got)
                 row[label] = got[len(got) // 2]
                 row[label + "_min"] = got[0]
+                if label.startswith("step_"):  # (the enqueue loop may run into a full queue: the MINIMUM over the stretches is the host's own time)
+                    row[label.replace("step_", "host_enqueue_ms_", 1)] = round(min(host_ms[label]), 4)
             print(json.dumps(row), flush=True)
+            host_ms.clear()
             configure("one_sided", True)
             pkg.check(lib.nb_device_synchronize())
             for b in bufs + ([work] if work is not None else []):
