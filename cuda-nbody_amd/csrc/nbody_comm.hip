@@ -186,12 +186,16 @@ __global__ void queue_probe_spin(unsigned long long ticks, unsigned* sink) {
 
 // do kernels on `a` and `b` overlap?  (both streams are synchronised first: a one-off cost, the first time a pair of streams meets)
 bool streams_run_side_by_side(hipStream_t a, hipStream_t b) {
-    static unsigned* sink[64] = {};
-    int              dev      = 0;
+    static unsigned*  sink[64] = {};
+    static std::mutex guard;  // (a thread per rank: several ranks of one device may meet here)
+    int               dev      = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;
-    if (sink[dev] == nullptr && hipMalloc(reinterpret_cast<void**>(&sink[dev]), sizeof(unsigned)) != hipSuccess) {
-        (void)hipGetLastError();
-        return true;  // (cannot tell: keep what there is)
+    {
+        std::lock_guard<std::mutex> lock(guard);
+        if (sink[dev] == nullptr && hipMalloc(reinterpret_cast<void**>(&sink[dev]), sizeof(unsigned)) != hipSuccess) {
+            (void)hipGetLastError();
+            return true;  // (cannot tell: keep what there is)
+        }
     }
     hipEvent_t begin = nullptr, end_a = nullptr, end_b = nullptr;
     bool       side_by_side = true;
