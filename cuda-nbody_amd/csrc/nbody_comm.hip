@@ -304,7 +304,7 @@ bool same_group(const std::vector<Comm*>& locals) {
 }
 
 // The G-1 rounds for every local rank of a communicator.  `bytes_per_body` = 4 * sizeof(T).
-int exchange_tiles(const std::vector<Comm*>& locals, void* const* positions, unsigned num_bodies, size_t bytes_per_body, int nccl_type, const hipStream_t* after) {
+int exchange_tiles(const std::vector<Comm*>& locals, void* const* positions, unsigned num_bodies, size_t bytes_per_body, int nccl_type, const hipStream_t* after, int waited_for = 0) {
     Rccl* lib = rccl();
     if (lib == nullptr) return NB_ERR_UNSUPPORTED;
     NB_KEEP_RAND_STREAM;  // RCCL calls below; a world of one never gets here
@@ -328,42 +328,39 @@ int exchange_tiles(const std::vector<Comm*>& locals, void* const* positions, uns
     // with a group per round those waits fall on tiles that are not needed yet.  nb_comm_set_exchange_grouping(comm, 1) issues all
     // rounds of a step as ONE group instead: a per-communicator setting, so that one job can time both (bench.py's diagnostics do).
     // Same data, same bits either way (tested with the transport double).
+    // `waited_for` (the pairwise step passes G/2): only the tiles of the first `waited_for` rounds are waited for by a kernel of
+    // the next step -- a rank's rectangles run against ranks r+1 .. r+G/2 --, the others complete the position array for the caller:
+    // those travel as ONE more group (a group costs the host ~60 us and the chip a kernel launch: 8 ranks 11 -> 9 RCCL launches per
+    // step, the host's enqueue time per step 0.71 -> 0.59 ms).
     const bool one_group = locals.front()->one_group;
     for (Comm* c : locals)
         if (c->one_group != one_group) return NB_ERR_INVALID_ARGUMENT;  // the local ranks of a group must agree (all ranks must)
-    int rc = one_group ? lib->GroupStart() : 0;
-    for (int s = 1; s < G && rc == 0; ++s) {
-        if (!one_group) rc = lib->GroupStart();
-        for (size_t k = 0; k < locals.size() && rc == 0; ++k) {
-            Comm*      c    = locals[k];
-            const int  dst  = (c->rank - s + G) % G, src = (c->rank + s) % G;
-            char*      base = static_cast<char*>(positions[k]);
-            rc              = lib->Send(base + static_cast<size_t>(c->rank) * slice_bodies * bytes_per_body, slice_values, nccl_type, peer_of(c, dst), c->nccl, c->stream);
-            if (rc == 0) rc = lib->Recv(base + static_cast<size_t>(src) * slice_bodies * bytes_per_body, slice_values, nccl_type, peer_of(c, src), c->nccl, c->stream);
+    int first = 1;
+    while (first < G) {
+        const int last = one_group ? G - 1 : ((waited_for > 0 && first > waited_for) ? G - 1 : first);  // rounds first .. last form one group
+        int       rc   = lib->GroupStart();
+        for (int s = first; s <= last && rc == 0; ++s) {
+            for (size_t k = 0; k < locals.size() && rc == 0; ++k) {
+                Comm*      c    = locals[k];
+                const int  dst  = (c->rank - s + G) % G, src = (c->rank + s) % G;
+                char*      base = static_cast<char*>(positions[k]);
+                rc              = lib->Send(base + static_cast<size_t>(c->rank) * slice_bodies * bytes_per_body, slice_values, nccl_type, peer_of(c, dst), c->nccl, c->stream);
+                if (rc == 0) rc = lib->Recv(base + static_cast<size_t>(src) * slice_bodies * bytes_per_body, slice_values, nccl_type, peer_of(c, src), c->nccl, c->stream);
+            }
         }
-        if (one_group) continue;
         const int end = lib->GroupEnd();
         if (rc == 0) rc = end;
         if (rc != 0) return nccl_status(rc);
         for (Comm* c : locals) {
             DeviceScope scope(c->device);
-            const auto  err = hipEventRecord(c->arrived[static_cast<size_t>((c->rank + s) % G)], c->stream);
-            if (err != hipSuccess) return static_cast<int>(err);
-        }
-    }
-    if (one_group) {
-        const int end = lib->GroupEnd();
-        if (rc == 0) rc = end;
-        if (rc != 0) return nccl_status(rc);
-        for (Comm* c : locals) {
-            DeviceScope scope(c->device);
-            for (int s = 1; s < G; ++s) {
+            for (int s = first; s <= last; ++s) {
                 const auto err = hipEventRecord(c->arrived[static_cast<size_t>((c->rank + s) % G)], c->stream);
                 if (err != hipSuccess) return static_cast<int>(err);
             }
         }
+        first = last + 1;
     }
-    return rc != 0 ? nccl_status(rc) : 0;
+    return 0;
 }
 
 template <typename T> struct Api;
@@ -763,7 +760,7 @@ int sharded_step(nb_comm_t const* comms, int n_local, T* const* new_pos, const T
     std::vector<void*>       arrays(static_cast<size_t>(n_local));
     std::vector<hipStream_t> after(static_cast<size_t>(n_local));
     for (int k = 0; k < n_local; ++k) arrays[static_cast<size_t>(k)] = new_pos[k], after[static_cast<size_t>(k)] = reinterpret_cast<hipStream_t>(streams[k]);
-    return exchange_tiles(locals, arrays.data(), num_bodies, 4 * sizeof(T), Api<T>::nccl_type, after.data());
+    return exchange_tiles(locals, arrays.data(), num_bodies, 4 * sizeof(T), Api<T>::nccl_type, after.data(), done_pairwise ? G / 2 : 0);
 }
 
 template <typename T> int comm_workspace_bytes(nb_comm_t comm, unsigned num_bodies, int mode, size_t* bytes) {

@@ -211,7 +211,10 @@ def test_pairwise_step_across_ranks(tmp_path, oracle, world, dtype):
     got = _run(tmp_path, "all", pos0, vel0, world, steps, "fast", workspace=True)
     assert np.all(got["workspace_bytes"] > 0)
     sends, recvs, gathers, groups, copies = got["counters"]
-    assert sends == recvs == (world - 1 + world // 2) * world * steps and groups == (world - 1 + world // 2) * steps
+    # a group per round for the world // 2 tiles the next step's kernels wait for, ONE group for the tiles nobody waits for (round 5),
+    # a group per reaction round
+    H = world // 2
+    assert sends == recvs == (world - 1 + H) * world * steps and groups == (H + (1 if world - 1 > H else 0) + H) * steps
     ref_p, ref_v = pos0.copy(), vel0.copy()
     oracle.update(ref_p, ref_v, dtype(np.float32(0.016)), steps=steps)
     for k in range(1, world):
