@@ -474,8 +474,12 @@ def main():
         step()
     finish()
     ev1.record(stream_ptr)
-    fence()
+    # The closing bracket: this rank's device work done (synchronize), its clock stopped, THEN the barrier.  The figure reported is the
+    # MAX over the ranks of these times -- the moment the last rank finished -- so the host barrier that closes the bracket (gloo: a
+    # few hundred microseconds, as much as a step at 8 GPUs) is not part of anybody's K steps.
+    torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    fence()
     chip.stop()
     ev1.synchronize()
     if headline_watchdog is not None:

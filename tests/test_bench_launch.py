@@ -282,3 +282,28 @@ def test_n_rank_line_rehearsed_on_one_gpu_through_the_capi(ranks):
     (big,) = line["configs"]
     assert big["bodies"] == 65536 and big["n_gpus"] == ranks and big["layout"] == "pairwise across ranks" and big["ms_per_step"] > 0 and big["workspace_bytes_per_rank"] > 0
     assert "diagnostics_incomplete" not in line and "diagnostics_error" not in line
+
+
+def test_line_takes_counters_only_from_a_profile_of_the_same_launch_plan(pkg):
+    """bench_support.pmc_summary / plan_dict (host logic): `valu_busy`, `traffic` and `wasted_traffic_ratio` in the bench line come from
+    the committed rocprofv3 --pmc passes -- the NEWEST round's file for the configuration, and only if it was taken with the launch
+    plan that runs now; a configuration without a pass says None, never a neighbour's figure."""
+    import numpy as np
+
+    sys.path.insert(0, ROOT)
+    from bench_support import plan_dict, pmc_summary
+
+    plan = plan_dict(pkg, 262144, np.float32, "pairwise")
+    assert plan["layout"] == "pairwise" and plan["bodies_per_lane"] == 16 and plan["grid"] == 256 and plan["workspace_bytes"] == 402653184
+    got = pmc_summary(262144, False, "fast", "pairwise", plan)
+    assert got["source"].startswith("profiles/round5_n262144_f32_pairwise_pmc_summary.json") and 0.9 < got["valu_busy"] < 1.0 and got["hbm_bytes_per_launch"] > 8e8
+    finish = pmc_summary(262144, False, "fast", "pairwise", plan, kernel="_finish")
+    assert "finish" in finish["source"] and finish["hbm_bytes_per_launch"] > 4e8 and finish["valu_busy"] < 0.5  # the HBM-bound kernel of the path
+    other = dict(plan, workgroups_per_block=2)
+    stale = pmc_summary(262144, False, "fast", "pairwise", other)
+    assert set(stale) == {"source"} and "another launch plan" in stale["source"]
+    assert pmc_summary(123456, False, "fast", "pairwise", None) is None  # no pass for this size
+    strict = pmc_summary(262144, False, "strict", "strict", None)
+    assert "strict" in strict["source"] and strict["valu_busy"] > 0.9
+    one_sided = plan_dict(pkg, 262144, np.float32, "one-sided")
+    assert one_sided == {"bodies_per_lane": 4, "lane_groups": 8, "lds_tile_bodies": 2048, "grid": 1024, "lds_bytes": one_sided["lds_bytes"]}
