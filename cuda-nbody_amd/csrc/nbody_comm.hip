@@ -15,6 +15,13 @@
 // FAST with a workspace lent to every rank (round 3): each pair of bodies is evaluated once across the ranks too -- see
 // pair_sharded_step below; the position exchange stays as described, a second leg carries reaction sums to their owners.
 //
+// What round 5 measured with the REAL RCCL on one GPU (profiles/round5_*; the hooks are in the tuning header: a self-loop with every
+// byte checked, a LOOPBACK rank that steps as rank r of a nominal G-rank communicator) and what it changed here: a group per round
+// is the default (exchange_tiles); the tiles no kernel waits for travel as one more group; a rank's diagonal is two launches, the
+// second one LAST, with every reaction round enqueued before it (pair_rank_tiles); the second compute stream is probed against the
+// caller's for a shared hardware queue (settle_side_stream).  Layout of this file: the RCCL binding, a rank's resources, the
+// position exchange, the pairwise plan and step, the one-sided step, then the extern "C" entry points -- the tuning header's at the end.
+//
 // Process models, one code path: one process per GPU (nb_comm_init_rank; a group of 1 local rank) or one process
 // driving several GPUs (nb_comm_init_all; every RCCL round is then one ncclGroup over the local ranks); a thread per GPU works too.
 // RCCL is dlopen'ed on first use (librccl.so.1): a single-GPU run never pays for loading it, and inside a torch process
