@@ -376,9 +376,14 @@ def main():
                         work_bytes = work_t.numel() if work_t is not None else 0
                     capi_rank.set_workspace(work_t.data_ptr() if work_t is not None else None, work_bytes)
                     pairwise = capi_rank.pairwise()
-                    # bring the communicator up (channels, first-call set-up) outside any timed step, whatever --warmup says;
-                    # every rank holds identical positions at this point, so exchanging them changes nothing
+                    # bring the communicator up (channels, first-call set-up, the transport's registration of every buffer it will
+                    # ever be handed) outside any timed step, whatever --warmup says: BOTH position arrays -- every rank holds
+                    # identical positions in both at this point, so exchanging them changes nothing -- and, pairwise, the send and
+                    # receive arrays of the reaction leg (whatever they hold: every step overwrites them before it reads them)
                     capi_rank.exchange_once(0)
+                    capi_rank.exchange_once(1)
+                    if pairwise and world > 1:
+                        capi_rank.reaction_exchange_once()
                     torch.cuda.synchronize()
                 except pkg.NBodyHipError as exc:
                     problem = exc
