@@ -406,6 +406,7 @@ struct PairShard {
     bool         applies = false;
     nb::PairGeom diag{}, diag_late{}, rect{}, rect_upper{};  // rect_upper: the split rectangle as the HIGHER partner runs it (half of its blocks of bodies i: twice the workgroups per block)
     unsigned     ni = 0, block = 0, blocks = 0, plane = 0, half = 0, H = 0, diag_slots = 0;
+    unsigned     send_order[nb::kMaxRecv] = {};  // the reaction rounds s = 1 .. H in the order their rectangles' folds are expected to complete (send_order[k] = s)
     unsigned     early_units = 0, late_units = 0;  // the diagonal's units per block as two launches: block offsets q < q_split first, the rest LAST (late_units == 0: one launch)
     bool         even = false;
     size_t       self_at = 0, react_d_at = 0, react_r_at = 0, send_at = 0, recv_at = 0, elements = 0;  // offsets in T
@@ -457,6 +458,21 @@ template <typename T> PairShard plan_pair_shard(unsigned num_bodies, int G, int 
     p.rect = {R, S, splits((p.ni + 63) / 64)};
     p.rect_upper = p.rect;
     if (p.even && p.blocks >= 2 && (p.ni + 63) / 64 >= p.rect.splits * 2 * static_cast<unsigned>(S) * 2) p.rect_upper.splits = p.rect.splits * 2;
+    {   // The reaction rounds leave in the order their sums become ready, not in the order of the partners: the exchange stream is a
+        // FIFO, and a round that waits for a fold late on the second stream would hold up one whose fold finished long before (8
+        // ranks: round 4's sums are ready 170 us before round 3's -- the half rectangle runs on the step's own stream before the late
+        // diagonal).  Expected completion = the work queued on the rectangle's stream up to and including it, in units of a full
+        // rectangle (the step's own stream starts with the early diagonal: a quarter, or a half when the diagonal is one launch; odd
+        // partners run on the second stream from two partners on).  A function of G alone: the same order on every rank.
+        double at_own = p.late_units != 0 ? 0.25 : 0.5, at_second = 0.0, done[nb::kMaxRecv + 1] = {};
+        for (unsigned s = 1; s <= p.H; ++s) {
+            const double cost = (p.even && s == p.H) ? 0.5 : 1.0;
+            double&      at   = (p.H >= 2 && (s & 1u) != 0) ? at_second : at_own;
+            at += cost, done[s] = at;
+        }
+        for (unsigned k = 0; k < p.H; ++k) p.send_order[k] = k + 1;
+        std::stable_sort(p.send_order, p.send_order + p.H, [&](unsigned a, unsigned b) { return done[a] < done[b]; });
+    }
     const size_t plane3 = 3 * static_cast<size_t>(p.plane);
     p.self_at    = 0;
     p.react_d_at = p.self_at + (p.diag.splits + p.diag_late.splits + static_cast<size_t>(p.H - 1) * p.rect.splits + p.rect_upper.splits) * plane3;  // (the last rectangle is the one that may be split)
@@ -592,7 +608,8 @@ template <typename T> int reaction_exchange(const std::vector<Comm*>& locals, co
     const int    G      = locals.front()->world;
     const size_t plane3 = 3 * static_cast<size_t>(plan.plane);
     NB_KEEP_RAND_STREAM;
-    for (unsigned s = 1; s <= plan.H; ++s) {
+    for (unsigned k = 0; k < plan.H; ++k) {
+        const unsigned s = plan.send_order[k];
         for (Comm* c : locals) {
             DeviceScope scope(c->device);
             if (const auto err = hipStreamWaitEvent(c->stream, c->react_ready[s], 0); err != hipSuccess) return static_cast<int>(err);
