@@ -1,6 +1,8 @@
 /*
  * nbody_hip_tuning.h -- the lab bench of libnbody_hip.so: plan overrides for tuning sweeps, the kernel-time projection of one
- * rank of a multi-GPU step, a probe event between the two kernels of a pairwise step, counters for tests.
+ * rank of a multi-GPU step, a probe event between the two kernels of a pairwise step, counters for tests; round 5: the REAL RCCL on
+ * a one-GPU box (a self-loop with every byte checked, a loopback rank that steps as rank r of a nominal G-rank communicator) and
+ * what a communicator can say about its last step (host-order trace, executed work, hardware-queue collisions of its second stream).
  *
  * NOT part of the drop-in boundary (that is nbody_hip.h: what a maintainer of the reference binds).  Everything declared here
  * is PROCESS-GLOBAL state and NOT THREAD-SAFE against steps running concurrently: an override set while another thread is
