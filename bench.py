@@ -384,6 +384,9 @@ def main():
                     capi_rank.exchange_once(1)
                     if pairwise and world > 1:
                         capi_rank.reaction_exchange_once()
+                        # ... and the one-off probe of the rank's second compute stream against this one (a shared hardware queue
+                        # would serialise the two) happens here, not inside the first step
+                        pkg.check(lib.nb_comm_settle_side_stream(capi_rank.comm, stream_ptr), "nb_comm_settle_side_stream")
                     torch.cuda.synchronize()
                 except pkg.NBodyHipError as exc:
                     problem = exc

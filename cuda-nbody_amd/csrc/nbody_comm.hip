@@ -1224,6 +1224,18 @@ int nb_comm_selftest_f32(nb_comm_t comm, size_t bytes, nb_stream_t stream, nb_co
     return result;
 }
 
+int nb_comm_settle_side_stream(nb_comm_t comm, nb_stream_t beside) {
+    NB_KEEP_RAND_STREAM;
+    Comm* c = as_comm(comm);
+    if (c == nullptr) return NB_ERR_INVALID_ARGUMENT;
+    DeviceScope scope(c->device);
+    hipStream_t with = reinterpret_cast<hipStream_t>(beside);
+    if (c->aux_probed && c->aux_settled_beside == with) return 0;
+    if (const auto err = settle_side_stream(&c->aux, with, &c->aux_retired, &c->aux_collisions); err != hipSuccess) return static_cast<int>(err);
+    c->aux_probed = true, c->aux_settled_beside = with;
+    return 0;
+}
+
 int nb_comm_side_stream_collisions(nb_comm_t comm, int* collisions) {
     Comm* c = as_comm(comm);
     if (c == nullptr || collisions == nullptr) return NB_ERR_INVALID_ARGUMENT;

@@ -99,6 +99,9 @@ NB_API int nb_comm_pair_work_f64(nb_comm_t comm, unsigned num_bodies, unsigned l
  * probes its side stream against the caller's the first time the two meet and replaces it while they collide (csrc/nbody_comm.hip,
  * settle_side_stream; NBODY_AUX_PROBE=0 switches that off).  *collisions: how many candidates were replaced; -1: not probed yet. */
 NB_API int nb_comm_side_stream_collisions(nb_comm_t comm, int* collisions);
+/* ... and the same probe NOW, against the stream the caller is going to step on (else it runs inside the first pairwise step with two or
+ * more partners: two stream synchronisations and ~0.2 ms, once). */
+NB_API int nb_comm_settle_side_stream(nb_comm_t comm, nb_stream_t beside);
 
 /* What this rank's LAST pairwise multi-GPU step enqueued, in host order, one item per line: "forces diagonal-early", "forces
  * rectangle s", "fold s", "send reaction s", "forces diagonal-late", "finish" (empty before the first such step).  Tests read the
