@@ -1,7 +1,8 @@
 #!/bin/bash
 # tools/gpu_evidence.sh [OUT] -- the evidence run of a round, sent to the GPU box as ONE gpurun call:
 #     gpurun --timeout 1100 -- 'bash tools/gpu_evidence.sh gpurun_out/r4'
-# (1) the GPU test suite, (2) smoke, (3) the default bench line and the one-sided one, (4) rocprofv3 kernel trace + the separate
+# (1) the GPU test suite, (2) smoke, (3) the default bench line and the one-sided one, (3b, round 5) the real-RCCL self-loop and the loopback
+# contention measurement, (4) rocprofv3 kernel trace + the separate
 # PMC passes (tools/profile.sh) of every BASELINE size through the bench command itself.  Afterwards, here:
 #     python tools/summarize_prof.py gpurun_out/r4/f32 profiles/round4_n262144_f32_pairwise pair_forces      (and so on per size;
 #     one_sided -> profiles/roundN_n262144_f32 integrate_bodies, strict -> ..._strict integrate_bodies_strict)
@@ -14,6 +15,9 @@ timeout -k 10 120 python __graft_entry__.py smoke > $OUT/smoke.txt 2>&1 || { tai
 timeout -k 10 300 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err || { tail -5 $OUT/bench.err; exit 1; }
 echo "bench ok: $(cut -c1-200 $OUT/bench.json)"
 timeout -k 10 300 python3 bench.py --layout one-sided --no-configs --no-cpu-baseline > $OUT/bench_one_sided.json 2> $OUT/bench_one_sided.err || exit 1
+# round 5: the real RCCL on this one GPU -- the self-loop (every byte checked) and the loopback rank next to the shipping kernels
+for how in "" "--torch"; do timeout -k 10 150 python3 tools/rccl_selfloop.py $how 2>/dev/null | grep "^{" >> $OUT/rccl_selfloop.jsonl || { echo "rccl_selfloop $how FAILED"; exit 1; }; done
+for w in 8 4 2; do timeout -k 10 300 python3 tools/exchange_contention.py --bodies 262144 --world $w 2>/dev/null | grep "^{" >> $OUT/exchange_contention.jsonl || { echo "exchange_contention $w FAILED"; exit 1; }; done
 run_prof() { PROF_OUT=$OUT/$1 timeout -k 10 600 bash tools/profile.sh "${@:2}" > $OUT/$1.log 2>&1 && echo "$1 ok" || { echo "$1 FAILED"; tail -5 $OUT/$1.log; return 1; }; }
 run_prof f32 --steps 20 --warmup 3 &&
 run_prof n65536 --steps 200 --warmup 10 --bodies 65536 &&
