@@ -58,6 +58,29 @@ def test_host_side_argument_errors_need_no_gpu(pkg):
     assert b"gfx950" in lib.nb_version()
 
 
+def test_round5_hooks_reject_bad_arguments_on_the_host(pkg):
+    """The tuning header's round-5 entry points (the real-RCCL self-test, the loopback rank, what a communicator says about its last
+    step) check their arguments before they touch HIP or RCCL: no GPU needed, nothing loaded."""
+    import ctypes
+
+    lib = pkg.lib()
+    comm, word, report = ctypes.c_void_p(), ctypes.c_int(0), pkg.CommSelftest()
+    evals = ctypes.c_ulonglong(0)
+    text = ctypes.create_string_buffer(64)
+    assert lib.nb_comm_selftest_open(None, None) == 10001 and lib.nb_comm_selftest_open(ctypes.byref(comm), None) == 10001
+    assert lib.nb_comm_loopback_open(ctypes.byref(comm), text, 1, 0) == 10001   # a nominal world of one is no world
+    assert lib.nb_comm_loopback_open(ctypes.byref(comm), None, 8, 4) == 10001   # no id
+    assert lib.nb_comm_loopback_open(ctypes.byref(comm), text, 8, 8) == 10001   # no such rank
+    assert comm.value is None
+    assert lib.nb_comm_selftest_f32(None, 1024, None, ctypes.byref(report)) == 10001
+    assert lib.nb_comm_self_transfer_f32(None, None, None, 0, 0, 1, None, None, None) == 10001
+    assert lib.nb_comm_transport_info(None, ctypes.byref(word), text, len(text)) == 10001
+    assert lib.nb_comm_pair_work_f32(None, 262144, ctypes.byref(evals), ctypes.byref(word)) == 10001
+    assert lib.nb_comm_last_step_trace(None, text, len(text)) == 10001
+    assert lib.nb_comm_side_stream_collisions(None, ctypes.byref(word)) == 10001 and lib.nb_comm_settle_side_stream(None, None) == 10001
+    assert lib.nb_set_late_diagonal(-1) == 10001 and lib.nb_set_alloc_limit(0) == 0
+
+
 def test_strict_translation_unit_has_no_fused_multiply_add():
     """The strict kernels must keep separate mul/add (bit-parity with the CPU path): the only v_fma in that
     object are inside the IEEE divide/sqrt expansions, never a contracted a*b+c of ours.  Checked structurally:
