@@ -35,6 +35,7 @@ def main():
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--rounds", type=int, default=5, help="how many times the phases take turns (the median over the rounds is reported)")
     ap.add_argument("--torch", action="store_true", help="import torch first (binds torch's RCCL, as bench.py does)")
+    ap.add_argument("--fp64", action="store_true", help="double precision: ncclFloat64 tiles of 32 B per body, reaction arrays of 24 B per body")
     args = ap.parse_args()
     if args.torch:
         import torch  # noqa: F401
@@ -44,8 +45,15 @@ def main():
     pkg = entry.load_package()
     lib = pkg.lib()
     pkg.check(lib.nb_set_device(0), "nb_set_device")
-    pkg.check(lib.nb_set_softening_sq_f32(np.float32(0.01)))
-    dt, damping = np.float32(0.016), np.float32(1.0)
+    dtype = np.float64 if args.fp64 else np.float32
+    if args.fp64:
+        pkg.check(lib.nb_set_softening_sq_f64(0.01))
+        dt, damping = 0.016, 1.0
+        emulate_fn, shard_fn = lib.nb_emulate_pair_rank_f64, lib.nb_integrate_shard_f64
+    else:
+        pkg.check(lib.nb_set_softening_sq_f32(np.float32(0.01)))
+        dt, damping = np.float32(0.016), np.float32(1.0)
+        emulate_fn, shard_fn = lib.nb_emulate_pair_rank_f32, lib.nb_integrate_shard_f32
     stream = ctypes.c_void_p()
     pkg.check(lib.nb_stream_create(ctypes.byref(stream)), "nb_stream_create")
     wanted = [w for w in args.phases.split(",") if w]
@@ -79,10 +87,10 @@ def main():
         comm = ctypes.c_void_p()
         pkg.check(lib.nb_comm_loopback_open(ctypes.byref(comm), pkg.comm_unique_id(), G, r), "nb_comm_loopback_open")
         for n in [int(x) for x in args.bodies.split(",")]:
-            pos0, vel0 = make_bodies(n, np.float32)
+            pos0, vel0 = make_bodies(n, dtype)
             bufs = [pkg.DeviceBuffer(pos0.nbytes) for _ in range(4)]  # pos a, pos b, vel, acc
             bufs[0].upload(pos0), bufs[1].upload(pos0), bufs[2].upload(vel0)
-            job = pkg.ShardedRank(None, G, r, [bufs[0].ptr.value, bufs[1].ptr.value], bufs[2].ptr.value, bufs[3].ptr.value, n, np.float32, pkg.NB_MODE_FAST, 256, stream, comm=comm)
+            job = pkg.ShardedRank(None, G, r, [bufs[0].ptr.value, bufs[1].ptr.value], bufs[2].ptr.value, bufs[3].ptr.value, n, dtype, pkg.NB_MODE_FAST, 256, stream, comm=comm)
             need = 0
             for late in (1, 0):  # (the two forms of the diagonal want different numbers of planes: lend the larger amount to both)
                 pkg.check(lib.nb_set_late_diagonal(late))
@@ -93,13 +101,13 @@ def main():
             size = ctypes.c_size_t(need)
 
             def emulate():
-                pkg.check(lib.nb_emulate_pair_rank_f32(bufs[1].ptr, bufs[0].ptr, bufs[2].ptr, work.ptr, ctypes.byref(size), n, G, r, dt, damping, stream), "nb_emulate_pair_rank")
+                pkg.check(emulate_fn(bufs[1].ptr, bufs[0].ptr, bufs[2].ptr, work.ptr, ctypes.byref(size), n, G, r, dt, damping, stream), "nb_emulate_pair_rank")
 
             def tiles():
                 for t in range(G):
                     peer = (r + t) % G
                     flags = (pkg.NB_SHARD_ACC_IN if t else 0) | (pkg.NB_SHARD_FINALIZE if t == G - 1 else 0)
-                    pkg.check(lib.nb_integrate_shard_f32(bufs[1].ptr, bufs[0].ptr, bufs[2].ptr, bufs[3].ptr, r * ni, ni, peer * ni, ni, flags, dt, damping, 256, pkg.NB_MODE_FAST, stream), "nb_integrate_shard")
+                    pkg.check(shard_fn(bufs[1].ptr, bufs[0].ptr, bufs[2].ptr, bufs[3].ptr, r * ni, ni, peer * ni, ni, flags, dt, damping, 256, pkg.NB_MODE_FAST, stream), "nb_integrate_shard")
 
             def configure(layout, one_group, late=1):
                 pkg.check(lib.nb_set_late_diagonal(late))
@@ -131,8 +139,8 @@ def main():
                 for label, (config, fn, after) in phases.items():
                     configure(*config)
                     samples[label].append(timed(fn, args.steps, after, label))
-            row = {"bodies": n, "nominal_world": G, "nominal_rank": r, "steps_per_stretch": args.steps, "rounds": args.rounds, "position_tile_bytes": ni * 16,
-                   "reaction_array_bytes": ni * 12, "workspace_bytes": need, **pkg.comm_transport_info(comm),
+            row = {"dtype": "f64" if args.fp64 else "f32", "bodies": n, "nominal_world": G, "nominal_rank": r, "steps_per_stretch": args.steps, "rounds": args.rounds, "position_tile_bytes": ni * 4 * np.dtype(dtype).itemsize,
+                   "reaction_array_bytes": ni * 3 * np.dtype(dtype).itemsize, "workspace_bytes": need, **pkg.comm_transport_info(comm),
                    "what": "ms per repetition: median over the rounds (phases interleaved); *_min: the fastest stretch"}
             row["side_stream_collisions"] = job.info()["side_stream_collisions"]  # candidates for the second compute stream that shared a hardware queue with the first
             for label, got in samples.items():
