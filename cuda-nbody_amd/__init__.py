@@ -181,6 +181,7 @@ TUNING_SIGNATURES = {
     "nb_comm_last_step_trace": (_ci, [_vp, ctypes.c_char_p, _sz]),
     "nb_comm_side_stream_collisions": (_ci, [_vp, _P(_ci)]),
     "nb_comm_settle_side_stream": (_ci, [_vp, _vp]),
+    "nb_comm_replace_side_stream": (_ci, [_vp]),
     "nb_comm_pair_work_f32": (_ci, [_vp, _cu, _P(ctypes.c_ulonglong), _P(_ci)]),
     "nb_comm_pair_work_f64": (_ci, [_vp, _cu, _P(ctypes.c_ulonglong), _P(_ci)]),
 }

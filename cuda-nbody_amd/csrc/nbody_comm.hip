@@ -1236,6 +1236,20 @@ int nb_comm_settle_side_stream(nb_comm_t comm, nb_stream_t beside) {
     return 0;
 }
 
+int nb_comm_replace_side_stream(nb_comm_t comm) {  // (experiments: how much does the placement of the second stream matter?)
+    NB_KEEP_RAND_STREAM;
+    Comm* c = as_comm(comm);
+    if (c == nullptr) return NB_ERR_INVALID_ARGUMENT;
+    DeviceScope scope(c->device);
+    if (c->aux != nullptr) {
+        (void)hipStreamSynchronize(c->aux);
+        c->aux_retired.push_back(c->aux);
+        c->aux = nullptr;
+    }
+    c->aux_probed = false;
+    return static_cast<int>(hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
+}
+
 int nb_comm_side_stream_collisions(nb_comm_t comm, int* collisions) {
     Comm* c = as_comm(comm);
     if (c == nullptr || collisions == nullptr) return NB_ERR_INVALID_ARGUMENT;

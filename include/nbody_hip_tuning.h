@@ -102,6 +102,8 @@ NB_API int nb_comm_side_stream_collisions(nb_comm_t comm, int* collisions);
 /* ... and the same probe NOW, against the stream the caller is going to step on (else it runs inside the first pairwise step with two or
  * more partners: two stream synchronisations and ~0.2 ms, once). */
 NB_API int nb_comm_settle_side_stream(nb_comm_t comm, nb_stream_t beside);
+/* Retire the second compute stream and make another (experiments on how much its placement matters: tools/side_stream_placement.py). */
+NB_API int nb_comm_replace_side_stream(nb_comm_t comm);
 
 /* What this rank's LAST pairwise multi-GPU step enqueued, in host order, one item per line: "forces diagonal-early", "forces
  * rectangle s", "fold s", "send reaction s", "forces diagonal-late", "finish" (empty before the first such step).  Tests read the
