@@ -338,6 +338,7 @@ def main():
         pkg.check(shard_fn(new_pos.data_ptr(), old_pos.data_ptr(), vel.data_ptr(), acc.data_ptr(), i0, ni, j0, nj, flags,
                            dt, damping, 256, mode, stream_ptr), "nb_integrate_shard")
 
+    own_stream = None  # (several ranks through the C-ABI: the well-placed stream the steps run on)
     capi_rank = None  # --exchange rccl: this rank of the product's sharded system (nb_comm_init_rank + nb_sharded_step_*)
     system = None     # every other exchange: cuda-nbody_amd/sharded.py over torch.distributed
     sharded = entry.load_package_module("sharded") if distributed else None
@@ -364,6 +365,16 @@ def main():
             else:
                 try:
                     capi_rank = pkg.ShardedRank(ids[0], world, rank, [b.data_ptr() for b in bufs], vel_t.data_ptr(), acc_t.data_ptr(), n, dtype, mode, 256, stream_ptr)
+                except pkg.NBodyHipError as exc:
+                    problem = exc
+            if capi_rank is not None and world > 1 and problem is None:
+                # Never step on the null stream (torch's current stream) next to RCCL: a rank that computes there -- or on a stream
+                # that shares its hardware queue, one created stream in three -- steps ~40 % slower (measured with the real RCCL,
+                # profiles/round5_hw_queue_collision.txt).  The communicator hands out a stream that is probed to be clear of it.
+                try:
+                    torch.cuda.synchronize()  # (what torch did to the tensors so far ran on ITS stream)
+                    own_stream = capi_rank.make_step_stream()
+                    stream_ptr = own_stream
                 except pkg.NBodyHipError as exc:
                     problem = exc
             if everyone(problem is None):
@@ -396,6 +407,7 @@ def main():
                 if capi_rank is not None:
                     capi_rank.destroy()
                 capi_rank, exchange_fallback, pairwise = None, True, False
+                stream_ptr = ctypes.c_void_p(stream.cuda_stream)  # (sharded.py orders its kernels against torch's collectives on torch's own stream)
                 args.exchange = "torch"
                 rccl_group = torch_rccl_group()
 
@@ -712,6 +724,8 @@ def main():
     if capi_rank is not None:
         torch.cuda.synchronize()
         capi_rank.destroy()
+        if own_stream is not None:
+            lib.nb_stream_destroy(own_stream)
     if distributed:
         dist.destroy_process_group()
 

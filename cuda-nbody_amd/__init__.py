@@ -137,6 +137,7 @@ SIGNATURES = {
     "nb_comm_init_all": (_ci, [_P(_vp), _ci, _P(_ci)]),
     "nb_comm_destroy": (_ci, [_vp]),
     "nb_comm_info": (_ci, [_vp, _P(_ci), _P(_ci), _P(_ci)]),
+    "nb_comm_stream_create": (_ci, [_vp, _P(_vp)]),
     "nb_comm_set_workspace": (_ci, [_vp, _vp, _sz]),
     "nb_comm_layout_f32": (_ci, [_vp, _cu, _ci, _P(_ci)]),
     "nb_comm_layout_f64": (_ci, [_vp, _cu, _ci, _P(_ci)]),
@@ -182,6 +183,7 @@ TUNING_SIGNATURES = {
     "nb_comm_side_stream_collisions": (_ci, [_vp, _P(_ci)]),
     "nb_comm_settle_side_stream": (_ci, [_vp, _vp]),
     "nb_comm_replace_side_stream": (_ci, [_vp]),
+    "nb_comm_caller_stream_placement": (_ci, [_vp, _P(_ci)]),
     "nb_comm_pair_work_f32": (_ci, [_vp, _cu, _P(ctypes.c_ulonglong), _P(_ci)]),
     "nb_comm_pair_work_f64": (_ci, [_vp, _cu, _P(ctypes.c_ulonglong), _P(_ci)]),
 }
@@ -522,6 +524,9 @@ class ShardedRank:
         hits = _ci(-1)
         check(lib().nb_comm_side_stream_collisions(self.comm, ctypes.byref(hits)), "nb_comm_side_stream_collisions")
         out["side_stream_collisions"] = hits.value  # (-1: never probed -- no pairwise step with two partners yet)
+        bad = _ci(-1)
+        check(lib().nb_comm_caller_stream_placement(self.comm, ctypes.byref(bad)), "nb_comm_caller_stream_placement")
+        out["caller_stream_badly_placed"] = bad.value  # 1: stepping on the null stream or on its hardware queue (~40 % slower with RCCL active)
         return out
 
     def pair_work(self):
@@ -534,6 +539,14 @@ class ShardedRank:
             return None
         check(rc, "nb_comm_pair_work")
         return evals.value, launches.value
+
+    def make_step_stream(self):
+        """nb_comm_stream_create: a well-placed non-blocking stream to step on, which becomes this rank's stream (the caller destroys
+        it with nb_stream_destroy); returns it as a ctypes.c_void_p"""
+        made = _vp()
+        check(lib().nb_comm_stream_create(self.comm, ctypes.byref(made)), "nb_comm_stream_create")
+        self.stream = made
+        return made
 
     def update(self, delta_time, damping) -> None:
         """pos[1-read][own slice], vel[own slice] <- one step from pos[read]; then the tiles of pos[1-read] start moving."""

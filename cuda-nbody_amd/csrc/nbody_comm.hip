@@ -39,6 +39,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cstdint>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -137,6 +138,8 @@ struct Comm {
     bool        aux_probed = false;
     int         aux_collisions = 0;        // how many candidates shared a hardware queue with the caller's stream (nb_comm_transport_info reports it)
     std::vector<hipStream_t> aux_retired;  // ... kept until the communicator goes
+    hipStream_t caller_last = nullptr;     // the caller's stream last looked at, whether it was, and the verdict (note_caller_stream)
+    bool        caller_checked = false, caller_bad = false;
     std::vector<hipEvent_t> react_ready;   // [world/2 + 1] pairwise step: "the reaction sums for partner s are in the send buffer" (compute stream)
     std::vector<hipEvent_t> react_arrived; // [world/2 + 1] ... "round s of the reaction exchange is done" (exchange stream)
     std::vector<Comm*> group;              // all local ranks of this communicator (just {this} with one process per GPU)
@@ -191,6 +194,25 @@ __global__ void queue_probe_spin(unsigned long long ticks, unsigned* sink) {
     if (x == 0x9e3779b9u) *sink = x;
 }
 
+// one candidate for the second compute stream.  NBODY_AUX_CUMASK=1 (experiment): a stream with a CU mask of all ones -- the runtime
+// gives CU-masked streams a hardware queue of their own instead of one from the shared pool
+hipError_t create_side_stream(hipStream_t* stream) {
+    static const bool masked = [] {
+        const char* v = std::getenv("NBODY_AUX_CUMASK");
+        return v != nullptr && v[0] == '1';
+    }();
+    if (masked) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) {
+            std::vector<uint32_t> mask(static_cast<size_t>((cus + 31) / 32), 0xffffffffu);
+            if (cus % 32) mask.back() = (1u << (cus % 32)) - 1u;
+            if (hipExtStreamCreateWithCUMask(stream, static_cast<uint32_t>(mask.size()), mask.data()) == hipSuccess) return hipSuccess;
+            (void)hipGetLastError();
+        }
+    }
+    return hipStreamCreateWithFlags(stream, hipStreamNonBlocking);
+}
+
 // do kernels on `a` and `b` overlap?  (both streams are synchronised first: a one-off cost, the first time a pair of streams meets)
 bool streams_run_side_by_side(hipStream_t a, hipStream_t b) {
     static unsigned*  sink[64] = {};
@@ -241,15 +263,31 @@ hipError_t settle_side_stream(hipStream_t* side, hipStream_t beside, std::vector
         return v == nullptr || v[0] != '0';
     }();
     if (*side == nullptr) {
-        if (const auto err = hipStreamCreateWithFlags(side, hipStreamNonBlocking); err != hipSuccess) return err;
+        if (const auto err = create_side_stream(side); err != hipSuccess) return err;
     }
-    for (int attempt = 0; probing && attempt < 8 && !streams_run_side_by_side(beside, *side); ++attempt) {
+    // (the null stream too: RCCL puts work of its own there, and a stream on the null stream's hardware queue waits behind it)
+    auto fits = [&](hipStream_t candidate) { return streams_run_side_by_side(beside, candidate) && (beside == nullptr || streams_run_side_by_side(nullptr, candidate)); };
+    for (int attempt = 0; probing && attempt < 8 && !fits(*side); ++attempt) {
         if (collisions != nullptr) ++*collisions;
         retired->push_back(*side);
         *side = nullptr;
-        if (const auto err = hipStreamCreateWithFlags(side, hipStreamNonBlocking); err != hipSuccess) return err;
+        if (const auto err = create_side_stream(side); err != hipSuccess) return err;
     }
     return hipSuccess;
+}
+
+// The stream a rank's kernels run on is the caller's; WHICH stream that is matters more than it should.  Measured with the real RCCL
+// next to the kernels that ship (round 5, profiles/round5_hw_queue_collision.txt): a rank that computes on the NULL stream -- or on
+// a stream that shares the null stream's hardware queue: one created stream in three or four -- steps in 1.80 ms instead of 1.29
+// (8 ranks, 262 144 bodies).  RCCL puts work of its own on the null stream, and whatever shares that queue waits behind it.
+// Computing on a stream of the communicator's own, ordered after / before the caller's with events, was built and measured: no
+// help (1.75 ms) -- the events themselves sit on the bad queue.  So the library only LOOKS (one spin-kernel probe per caller's
+// stream) and says so (nb_comm_caller_stream_placement; bench.py's ranks_seen), and nb_comm_stream_create hands out a stream that
+// is well placed: what bench.py and BodySystemHIPSharded step on.
+void note_caller_stream(Comm* c, hipStream_t caller) {
+    if (c->world < 2 || (c->caller_checked && c->caller_last == caller)) return;
+    c->caller_bad     = caller == nullptr || !streams_run_side_by_side(nullptr, caller);
+    c->caller_checked = true, c->caller_last = caller;
 }
 
 int make_resources(Comm* c) {
@@ -260,7 +298,7 @@ int make_resources(Comm* c) {
     if (err != hipSuccess) return static_cast<int>(err);
     err = hipEventCreateWithFlags(&c->ready, hipEventDisableTiming);
     if (err != hipSuccess) return static_cast<int>(err);
-    err = hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking);  // (probed against the caller's stream at its first pairwise step: settle_side_stream)
+    err = create_side_stream(&c->aux);  // (probed against the caller's stream at its first pairwise step: settle_side_stream)
     if (err == hipSuccess) err = hipEventCreateWithFlags(&c->aux_begin, hipEventDisableTiming);
     if (err == hipSuccess) err = hipEventCreateWithFlags(&c->aux_done, hipEventDisableTiming);
     if (err != hipSuccess) return static_cast<int>(err);
@@ -729,6 +767,11 @@ int sharded_step(nb_comm_t const* comms, int n_local, T* const* new_pos, const T
     const int G = locals.front()->world;
     if (num_bodies == 0 || num_bodies % static_cast<unsigned>(G)) return NB_ERR_INVALID_ARGUMENT;  // pad with zero-mass bodies (as tipsy.cpp:111-119 does)
     const unsigned ni = num_bodies / static_cast<unsigned>(G);
+    for (int k = 0; k < n_local && G > 1; ++k) {  // (a look at the stream the caller computes on, once per stream: see note_caller_stream)
+        Comm*       c = locals[static_cast<size_t>(k)];
+        DeviceScope scope(c->device);
+        note_caller_stream(c, reinterpret_cast<hipStream_t>(streams[k]));
+    }
     bool           done_pairwise = false;
     {   // every rank of the COMMUNICATOR lent a large enough workspace (decided identically on every rank): pairs once, across the ranks too
         PairShard plan;
@@ -1230,6 +1273,7 @@ int nb_comm_settle_side_stream(nb_comm_t comm, nb_stream_t beside) {
     if (c == nullptr) return NB_ERR_INVALID_ARGUMENT;
     DeviceScope scope(c->device);
     hipStream_t with = reinterpret_cast<hipStream_t>(beside);
+    note_caller_stream(c, with);
     if (c->aux_probed && c->aux_settled_beside == with) return 0;
     if (const auto err = settle_side_stream(&c->aux, with, &c->aux_retired, &c->aux_collisions); err != hipSuccess) return static_cast<int>(err);
     c->aux_probed = true, c->aux_settled_beside = with;
@@ -1247,7 +1291,14 @@ int nb_comm_replace_side_stream(nb_comm_t comm) {  // (experiments: how much doe
         c->aux = nullptr;
     }
     c->aux_probed = false;
-    return static_cast<int>(hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
+    return static_cast<int>(create_side_stream(&c->aux));
+}
+
+int nb_comm_caller_stream_placement(nb_comm_t comm, int* badly_placed) {
+    Comm* c = as_comm(comm);
+    if (c == nullptr || badly_placed == nullptr) return NB_ERR_INVALID_ARGUMENT;
+    *badly_placed = !c->caller_checked ? -1 : (c->caller_bad ? 1 : 0);
+    return 0;
 }
 
 int nb_comm_side_stream_collisions(nb_comm_t comm, int* collisions) {
@@ -1267,6 +1318,21 @@ int nb_comm_last_step_trace(nb_comm_t comm, char* text, size_t bytes) {
 
 int nb_comm_pair_work_f32(nb_comm_t comm, unsigned num_bodies, unsigned long long* pair_evaluations, int* force_launches) { return comm_pair_work<float>(comm, num_bodies, pair_evaluations, force_launches); }
 int nb_comm_pair_work_f64(nb_comm_t comm, unsigned num_bodies, unsigned long long* pair_evaluations, int* force_launches) { return comm_pair_work<double>(comm, num_bodies, pair_evaluations, force_launches); }
+
+int nb_comm_stream_create(nb_comm_t comm, nb_stream_t* stream) {
+    NB_KEEP_RAND_STREAM;
+    Comm* c = as_comm(comm);
+    if (c == nullptr || stream == nullptr) return NB_ERR_INVALID_ARGUMENT;
+    *stream = nullptr;
+    DeviceScope scope(c->device);
+    hipStream_t made = nullptr;
+    // (a non-blocking stream that does not share the null stream's hardware queue: candidates that do are kept until the communicator
+    // goes, so that the pool moves on; with one rank there is no RCCL and nothing to avoid)
+    const auto err = c->world > 1 ? settle_side_stream(&made, nullptr, &c->aux_retired, nullptr) : hipStreamCreateWithFlags(&made, hipStreamNonBlocking);
+    if (err != hipSuccess) return static_cast<int>(err);
+    *stream = made;
+    return 0;
+}
 
 int nb_comm_info(nb_comm_t comm, int* rank, int* world, int* device) {
     Comm* c = as_comm(comm);

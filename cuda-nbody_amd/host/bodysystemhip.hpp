@@ -4,6 +4,8 @@
 
 #include "nbody_types.hpp"
 
+#include "../../include/nbody_hip.h"  // nb_stream_t (an opaque handle: no HIP header on this side)
+
 #include <concepts>
 #include <span>
 #include <vector>
@@ -38,6 +40,10 @@ template <std::floating_point T> class BodySystemHIP {
     auto virtual set_velocity(std::span<const T> data) -> void = 0;
 
     auto nb_bodies() const noexcept { return nb_bodies_; }
+
+    // The stream update() enqueues on (events that time the steps are recorded there).  The default stream for every variant of the
+    // reference (everything there runs on stream 0); the sharded system steps on streams of its own -- see bodysystemhip_sharded.hpp.
+    auto virtual stream() const noexcept -> nb_stream_t { return nullptr; }
 
     virtual ~BodySystemHIP() = default;
 

@@ -57,12 +57,24 @@ template <std::floating_point T> auto BodySystemHIPSharded<T>::allocate(std::spa
         CurrentDevice scope(shard.device);
         shard.pos[0] = DeviceArray<T>(values), shard.pos[1] = DeviceArray<T>(values);
         shard.vel = DeviceArray<T>(values), shard.acc = DeviceArray<T>(values);
+        hip_check(nb_comm_stream_create(comms_[g], &shard.stream), "nb_comm_stream_create");
     }
 }
 
 template <std::floating_point T> BodySystemHIPSharded<T>::~BodySystemHIPSharded() {
+    for (auto& shard : shards_) {
+        if (shard.stream == nullptr) continue;
+        (void)nb_set_device(shard.device);
+        (void)nb_stream_synchronize(shard.stream);
+    }
     for (auto comm : comms_)
         if (comm != nullptr) (void)nb_comm_destroy(comm);
+    for (auto& shard : shards_) {
+        if (shard.stream == nullptr) continue;
+        (void)nb_set_device(shard.device);
+        (void)nb_stream_destroy(shard.stream);
+    }
+    if (!shards_.empty()) (void)nb_set_device(shards_.front().device);
 }
 
 template <std::floating_point T> auto BodySystemHIPSharded<T>::set_position(std::span<const T> data) -> void {
@@ -80,6 +92,7 @@ template <std::floating_point T> auto BodySystemHIPSharded<T>::set_velocity(std:
     this->current_read_ = 0, this->current_write_ = 1;
     for (auto& shard : shards_) {
         CurrentDevice scope(shard.device);
+        hip_check(nb_stream_synchronize(shard.stream), "nb_stream_synchronize");  // (a step may still be updating it)
         shard.vel.upload(data);  // every device gets the whole array; it only ever touches its own slice
     }
 }
@@ -88,7 +101,8 @@ template <std::floating_point T> auto BodySystemHIPSharded<T>::set_velocity(std:
 template <std::floating_point T> auto BodySystemHIPSharded<T>::get_position() const -> std::span<const T> {
     const auto&   shard = shards_.front();
     CurrentDevice scope(shard.device);
-    hip_check(nb_exchange_wait_all(comms_.front(), nullptr), "nb_exchange_wait_all");
+    hip_check(nb_exchange_wait_all(comms_.front(), shard.stream), "nb_exchange_wait_all");
+    hip_check(nb_stream_synchronize(shard.stream), "nb_stream_synchronize");  // (the copy below runs on the default stream, which orders nothing against this one)
     shard.pos[this->current_read_].download(host_pos_);
     return host_pos_;
 }
@@ -98,6 +112,7 @@ template <std::floating_point T> auto BodySystemHIPSharded<T>::get_velocity() co
     const auto slice = static_cast<std::size_t>(this->nb_bodies_) / shards_.size() * 4;
     for (std::size_t g = 0; g < shards_.size(); ++g) {
         CurrentDevice scope(shards_[g].device);
+        hip_check(nb_stream_synchronize(shards_[g].stream), "nb_stream_synchronize");
         hip_check(nb_d2h(host_vel_.data() + g * slice, shards_[g].vel.data() + g * slice, slice * sizeof(T), nullptr), "nb_d2h");
     }
     return host_vel_;
@@ -141,10 +156,11 @@ template <std::floating_point T> auto BodySystemHIPSharded<T>::update(T deltaTim
     const auto               n = shards_.size();
     std::vector<T*>          to(n), vel(n), acc(n);
     std::vector<const T*>    from(n);
-    std::vector<nb_stream_t> streams(n, nullptr);  // each device's default stream
+    std::vector<nb_stream_t> streams(n);  // each shard's own stream (never the default stream: see the header)
     for (std::size_t g = 0; g < n; ++g) {
         to[g] = shards_[g].pos[this->current_write_].data(), from[g] = shards_[g].pos[this->current_read_].data();
         vel[g] = shards_[g].vel.data(), acc[g] = shards_[g].acc.data();
+        streams[g] = shards_[g].stream;
     }
     int status;
     if constexpr (std::same_as<T, float>) {

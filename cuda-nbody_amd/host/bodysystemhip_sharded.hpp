@@ -6,6 +6,10 @@
 // slice of each new position array -- and holds full-size position arrays; every update() is one
 // nb_sharded_step_all_* call (include/nbody_hip.h): per device the kernels of the own slice and of each position tile as
 // it arrives over RCCL / xGMI, then the tile exchange of the new positions.  STRICT mode is bit-identical to one GPU.
+// Each shard steps on a stream of its own, made by nb_comm_stream_create -- never on the default stream: with RCCL active a rank that
+// computes on the null stream (or on a stream sharing its hardware queue) steps ~40 % slower, and so does one whose null stream
+// merely waits for it after every step (measured, profiles/round5_hw_queue_collision.txt).  The host-side reads and writes
+// synchronise the shard's stream themselves; ComputeHIP records its timing events on stream() = the first shard's.
 // Like BodySystemHIPDefault, each shard owns the scratch memory the library asks for (nb_comm_workspace_bytes_*): FAST then
 // evaluates every pair of bodies once, across the devices too (reaction sums travel to their owners); --no-workspace: off.
 #pragma once
@@ -27,6 +31,7 @@ template <std::floating_point T> class BodySystemHIPSharded final : public BodyS
     auto set_position(std::span<const T> data) -> void override;
     auto set_velocity(std::span<const T> data) -> void override;
     auto update(T deltaTime) -> void override;
+    auto stream() const noexcept -> nb_stream_t override { return shards_.empty() ? nullptr : shards_.front().stream; }
 
     auto nb_devices() const noexcept { return shards_.size(); }
 
@@ -37,6 +42,7 @@ template <std::floating_point T> class BodySystemHIPSharded final : public BodyS
         DeviceArray<T> vel;
         DeviceArray<T> acc;
         DeviceArray<unsigned char> workspace;
+        nb_stream_t    stream = nullptr;  // the shard steps here: nb_comm_stream_create (non-blocking, clear of the null stream's hardware queue)
     };
     auto allocate(std::span<const int> devices) -> void;
     auto ensure_workspaces() -> void;  // (re)lends every shard what the current mode asks for

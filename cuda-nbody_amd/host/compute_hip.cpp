@@ -110,7 +110,7 @@ ComputeHIP::ComputeHIP(bool enable_host_mem, int block_size, bool fp64_enabled, 
         allocate.template operator()<BodySystemHIPDefault<float>, BodySystemHIPDefault<double>>();
     }
 
-    start_event_.record();
+    start_event_.record(fp64_enabled_ ? nbody_fp64_->stream() : nbody_fp32_->stream());
 }
 
 template <typename F> auto ComputeHIP::with_active(F&& f) -> decltype(auto) {
@@ -147,11 +147,11 @@ auto ComputeHIP::run_benchmark(int nb_iterations, float dt) -> Milliseconds {
         nbody.update(dt);
         if (use_graph_ && nb_iterations >= 2 && nb_iterations % 2 == 0) {
             nbody.prepare_many(dt, static_cast<unsigned>(nb_iterations));  // capture + instantiate outside the timed region
-            start_event_.record();
+            start_event_.record(nbody.stream());
             nbody.update_many(dt, static_cast<unsigned>(nb_iterations));
             return get_milliseconds_passed();
         }
-        start_event_.record();
+        start_event_.record(nbody.stream());
         for (int i = 0; i < nb_iterations; ++i) nbody.update(dt);
         return get_milliseconds_passed();
     });
@@ -171,7 +171,7 @@ auto ComputeHIP::set_values(std::span<const double> positions, std::span<const d
 }
 
 auto ComputeHIP::update(float dt) -> void {
-    host_mem_sync_event_.record();  // what a renderer of mapped host memory would wait on (compute_cuda.cpp:237-246,284)
+    host_mem_sync_event_.record(with_active([](auto& nbody) { return nbody.stream(); }));  // what a renderer of mapped host memory would wait on (compute_cuda.cpp:237-246,284)
     with_active([&](auto& nbody) { nbody.update(dt); });
 }
 
@@ -186,10 +186,11 @@ auto ComputeHIP::update_params(const NBodyParams& params) -> void {
 
 // record stop, wait, elapsed, restart   (:263-272)
 auto ComputeHIP::get_milliseconds_passed() -> Milliseconds {
-    stop_event_.record();
+    const auto on = with_active([](auto& nbody) { return nbody.stream(); });  // (where the steps ran: the default stream unless the system is sharded)
+    stop_event_.record(on);
     stop_event_.synchronize();
     const auto ms = HipEvent::elapsed_ms(start_event_, stop_event_);
-    start_event_.record();
+    start_event_.record(on);
     return Milliseconds{ms};
 }
 

@@ -83,7 +83,7 @@ class HipEvent {
     ~HipEvent() {
         if (event_ != nullptr) (void)nb_event_destroy(event_);
     }
-    auto record() -> void { hip_check(nb_event_record(event_, nullptr), "nb_event_record"); }
+    auto record(nb_stream_t stream = nullptr) -> void { hip_check(nb_event_record(event_, stream), "nb_event_record"); }  // (on the stream the timed work runs on)
     auto synchronize() -> void { hip_check(nb_event_synchronize(event_), "nb_event_synchronize"); }
     auto handle() const noexcept { return event_; }
     static auto elapsed_ms(const HipEvent& start, const HipEvent& stop) -> float {

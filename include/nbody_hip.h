@@ -198,6 +198,11 @@ NB_API int nb_comm_init_rank(nb_comm_t* comm, const void* id, int world_size, in
 NB_API int nb_comm_init_all(nb_comm_t* comms /* [num_devices] */, int num_devices, const int* devices /* NULL = 0..n-1 */);
 NB_API int nb_comm_destroy(nb_comm_t comm);
 NB_API int nb_comm_info(nb_comm_t comm, int* rank, int* world_size, int* device);
+/* A stream to step this rank on (destroy it with nb_stream_destroy): non-blocking, and well PLACED.  The HIP runtime maps streams onto
+ * a few hardware queues; RCCL puts work of its own on the null stream, and a rank that computes on the null stream or on a stream
+ * that shares its queue -- about one created stream in three -- steps ~40 % slower (measured with the real RCCL next to the force
+ * kernels, profiles/round5_hw_queue_collision.txt).  This one is probed to be clear of that queue.  Any stream works; this one is fast. */
+NB_API int nb_comm_stream_create(nb_comm_t comm, nb_stream_t* stream);
 /* Lend a rank scratch memory (caller-owned, as everywhere; nb_comm_workspace_bytes_* says how much for this communicator,
  * 0 = none needed).  FAST mode then evaluates every PAIR of bodies once, across the ranks too: a communicator of one rank
  * steps through nb_integrate_ws_*; with G ranks, rank r evaluates its own slice against itself and against the slices of

@@ -102,6 +102,10 @@ NB_API int nb_comm_side_stream_collisions(nb_comm_t comm, int* collisions);
 /* ... and the same probe NOW, against the stream the caller is going to step on (else it runs inside the first pairwise step with two or
  * more partners: two stream synchronisations and ~0.2 ms, once). */
 NB_API int nb_comm_settle_side_stream(nb_comm_t comm, nb_stream_t beside);
+/* *badly_placed: 1 = the stream the caller stepped on last is the null stream or shares its hardware queue -- with RCCL active such a
+ * rank steps ~40 % slower (profiles/round5_hw_queue_collision.txt): step on a stream from nb_comm_stream_create instead; 0 = fine;
+ * -1 = no step with more than one rank yet. */
+NB_API int nb_comm_caller_stream_placement(nb_comm_t comm, int* badly_placed);
 /* Retire the second compute stream and make another (experiments on how much its placement matters: tools/side_stream_placement.py). */
 NB_API int nb_comm_replace_side_stream(nb_comm_t comm);
 

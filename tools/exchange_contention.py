@@ -54,8 +54,7 @@ def main():
         pkg.check(lib.nb_set_softening_sq_f32(np.float32(0.01)))
         dt, damping = np.float32(0.016), np.float32(1.0)
         emulate_fn, shard_fn = lib.nb_emulate_pair_rank_f32, lib.nb_integrate_shard_f32
-    stream = ctypes.c_void_p()
-    pkg.check(lib.nb_stream_create(ctypes.byref(stream)), "nb_stream_create")
+    stream = ctypes.c_void_p()  # (made per communicator below: nb_comm_stream_create -- a created stream in three is badly placed)
     wanted = [w for w in args.phases.split(",") if w]
 
     host_ms = {}
@@ -86,6 +85,9 @@ def main():
         r = G // 2 if args.rank < 0 else args.rank
         comm = ctypes.c_void_p()
         pkg.check(lib.nb_comm_loopback_open(ctypes.byref(comm), pkg.comm_unique_id(), G, r), "nb_comm_loopback_open")
+        if stream:
+            pkg.check(lib.nb_stream_destroy(stream))
+        pkg.check(lib.nb_comm_stream_create(comm, ctypes.byref(stream)), "nb_comm_stream_create")
         for n in [int(x) for x in args.bodies.split(",")]:
             pos0, vel0 = make_bodies(n, dtype)
             bufs = [pkg.DeviceBuffer(pos0.nbytes) for _ in range(4)]  # pos a, pos b, vel, acc

@@ -19,6 +19,9 @@ def main():
     ap.add_argument("--candidates", type=int, default=10)
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--torch", action="store_true")
+    ap.add_argument("--null-follows", action="store_true", help="after every step the NULL stream waits for an event of the stream stepped on (what a caller does who "
+                                                                  "times or copies on the null stream): does a marker on the null stream's queue slow the step?")
+    ap.add_argument("--placed", action="store_true", help="one more caller: a stream from nb_comm_stream_create")
     args = ap.parse_args()
     if args.torch:
         import torch  # noqa: F401
@@ -38,7 +41,25 @@ def main():
     pos0, vel0 = make_bodies(n, np.float32)
     bufs = [pkg.DeviceBuffer(pos0.nbytes) for _ in range(4)]
     bufs[0].upload(pos0), bufs[1].upload(pos0), bufs[2].upload(vel0)
-    for name, stream in (("created stream", created), ("null stream", None)):
+    others = []
+    for _ in range(3):  # (more callers' streams: the CALLER's stream has a placement too)
+        s = ctypes.c_void_p()
+        pkg.check(lib.nb_stream_create(ctypes.byref(s)))
+        others.append(s)
+    callers = [("created stream", created)] + [(f"created stream {k + 2}", s) for k, s in enumerate(others)] + [("null stream", None)]
+    if args.placed:
+        placed = ctypes.c_void_p()
+        pkg.check(lib.nb_comm_stream_create(comm, ctypes.byref(placed)), "nb_comm_stream_create")
+        callers.append(("nb_comm_stream_create", placed))
+    follow = pkg.Event()
+
+    def one_step(job, stream):
+        job.update(dt, damping)
+        if args.null_follows and stream is not None:
+            follow.record(stream)
+            pkg.check(lib.nb_stream_wait_event(None, follow.h), "nb_stream_wait_event")
+
+    for name, stream in callers:
         job = pkg.ShardedRank(None, G, r, [bufs[0].ptr.value, bufs[1].ptr.value], bufs[2].ptr.value, bufs[3].ptr.value, n, np.float32, pkg.NB_MODE_FAST, 256, stream, comm=comm)
         need = job.workspace_bytes()
         work = pkg.DeviceBuffer(need)
@@ -48,18 +69,18 @@ def main():
                 pkg.check(lib.nb_comm_replace_side_stream(comm), "nb_comm_replace_side_stream")
             times = []
             for _ in range(3):
-                job.update(dt, damping)
+                one_step(job, stream)
                 job.finish()
                 pkg.check(lib.nb_device_synchronize())
                 e0, e1 = pkg.Event(), pkg.Event()
                 e0.record(stream)
                 for _ in range(args.steps):
-                    job.update(dt, damping)
+                    one_step(job, stream)
                 job.finish()
                 e1.record(stream)
                 e1.synchronize()
                 times.append(round(e0.elapsed_ms(e1) / args.steps, 4))
-            print(json.dumps({"caller_computes_on": name, "candidate": k, "ms_per_step": sorted(times)[1], "all": times, "collisions_replaced_by_the_probe": job.info()["side_stream_collisions"]}), flush=True)
+            print(json.dumps({"caller_computes_on": name, "candidate": k, "ms_per_step": sorted(times)[1], "all": times, "collisions_replaced_by_the_probe": job.info()["side_stream_collisions"], "caller_stream_badly_placed": job.info()["caller_stream_badly_placed"]}), flush=True)
         job.set_workspace(None, 0)
         pkg.check(lib.nb_device_synchronize())
         work.free()
