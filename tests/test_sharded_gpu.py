@@ -268,3 +268,31 @@ def test_second_compute_stream_runs_beside_the_first_in_a_crowded_process():
     step, alone = rows[0]["step_pairwise_late1_group_per_round"], rows[0]["kernels_alone_pairwise_late1"]
     assert rows[0]["side_stream_collisions"] >= 0  # (the communicator's own second stream was probed)
     assert 0.85 * step < alone < 1.08 * step, (step, alone)  # a shared queue reads ~1.8x
+
+
+@pytest.mark.gpu
+def test_a_rank_must_not_step_on_the_null_stream_next_to_rccl():
+    """Round 5 (profiles/round5_hw_queue_collision.txt): RCCL puts work of its own on the NULL stream, and a rank that computes there
+    -- or on a stream that shares the null stream's hardware queue: about one created stream in three -- steps ~40 % slower
+    (1.80 against 1.29 ms for one rank of eight).  The library says so (nb_comm_caller_stream_placement) and hands out a stream
+    that is probed to be clear of that queue (nb_comm_stream_create): what bench.py and BodySystemHIPSharded step on.  A loopback
+    rank (real RCCL) on the null stream, on four created streams and on the library's: the flag, and the time that goes with it."""
+    import json
+    import subprocess
+    import sys
+
+    env = dict(os.environ)
+    for name in ("NBODY_RCCL_LIB", "NCCL_DEBUG", "FAKE_RCCL_IPC", "NBODY_AUX_PROBE"):
+        env.pop(name, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "side_stream_placement.py"), "--candidates", "1", "--steps", "30", "--placed"],
+                         capture_output=True, text=True, timeout=300, env=env)
+    rows = {r["caller_computes_on"]: r for r in (json.loads(l) for l in out.stdout.splitlines() if l.startswith("{"))}
+    assert out.returncode == 0 and "null stream" in rows and "nb_comm_stream_create" in rows, (out.stdout[-1500:], out.stderr[-1500:])
+    placed, null = rows["nb_comm_stream_create"], rows["null stream"]
+    assert placed["caller_stream_badly_placed"] == 0 and null["caller_stream_badly_placed"] == 1
+    assert placed["ms_per_step"] < 0.9 * null["ms_per_step"], (placed, null)
+    for name, row in rows.items():  # every stream the library calls well placed steps like the one it made itself
+        if row["caller_stream_badly_placed"] == 0:
+            assert row["ms_per_step"] < 1.08 * placed["ms_per_step"], (name, row, placed)
+        else:
+            assert row["ms_per_step"] > 1.15 * placed["ms_per_step"], (name, row, placed)
