@@ -267,6 +267,9 @@ def test_n_rank_line_rehearsed_on_one_gpu_through_the_capi(ranks):
     # the rank executed per step and how long its own stream took
     assert all(r["rccl_version"] == 0 and "fake_rccl" in r["rccl_library"] for r in seen)
     assert all(r["pci"] == seen[0]["pci"] and r["stream_ms_per_step"] > 0 for r in seen)  # (the rehearsal: one card)
+    # ... and on what kind of stream it stepped: one from nb_comm_stream_create, never the null stream (-1 / 0 / 1; with several processes
+    # on ONE card the spin-kernel probe behind the flag is noise, so only its presence is held here -- the flag itself: test_sharded_gpu.py)
+    assert all(r["caller_stream_badly_placed"] in (-1, 0, 1) and r["side_stream_collisions"] >= -1 for r in seen)
     assert all(r["pair_work"]["pair_evaluations_per_step"] > 0 and r["pair_work"]["force_launches_per_step"] == 2 + ranks // 2 for r in seen)
     total = sum(r["pair_work"]["pair_evaluations_per_step"] for r in seen)
     assert 0.5 * 16384 ** 2 <= total <= 0.75 * 16384 ** 2  # every pair once, plus the half-kept diagonal blocks
