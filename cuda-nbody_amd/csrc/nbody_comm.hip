@@ -39,7 +39,6 @@
 
 #include <algorithm>
 #include <atomic>
-#include <cstdint>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -182,11 +181,11 @@ class DeviceScope {  // switch device for a few calls, restore on exit (single-p
 // streams of its own, so a stream made after a communicator is up can land on the caller's queue -- measured (round 5, gpurun
 // calls r5k / r5l): one rank's kernels of an 8-rank step 2.31 ms instead of 1.25, every kernel starting exactly where the other
 // stream's ended.  Another priority is no way out: the pools are per priority, but a queue of lower OR higher priority does not
-// run side by side with the caller's (the same step 1.77 ms either way), and a CU-masked stream -- a queue of its own -- is a
-// blocking stream that would synchronise with a caller computing on the null stream.  So the stream is made at the caller's
-// priority and PROBED against the caller's stream the first time the two meet: two ~40 us spin kernels, one on each, started
-// together; had they run one after the other, another stream is made (the collided ones are kept until the communicator
-// goes, so that the pool moves on) -- up to eight times.
+// run side by side with the caller's (the same step 1.77 ms either way); a CU-masked stream is one more hardware queue each.  So
+// the stream is made at the caller's priority and PROBED the first time the two meet -- against the caller's stream, and against
+// the NULL stream (RCCL works there: a second stream on the null stream's queue costs 25 %, a caller on it 40 %: see
+// note_caller_stream below): two ~40 us spin kernels, one on each, started together; had they run one after the other, another
+// stream is made (the collided ones are kept until the communicator goes, so that the pool moves on) -- up to eight times.
 __global__ void queue_probe_spin(unsigned long long ticks, unsigned* sink) {
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz, whatever the shader clock
     unsigned                 x  = threadIdx.x;
@@ -194,24 +193,10 @@ __global__ void queue_probe_spin(unsigned long long ticks, unsigned* sink) {
     if (x == 0x9e3779b9u) *sink = x;
 }
 
-// one candidate for the second compute stream.  NBODY_AUX_CUMASK=1 (experiment): a stream with a CU mask of all ones -- the runtime
-// gives CU-masked streams a hardware queue of their own instead of one from the shared pool
-hipError_t create_side_stream(hipStream_t* stream) {
-    static const bool masked = [] {
-        const char* v = std::getenv("NBODY_AUX_CUMASK");
-        return v != nullptr && v[0] == '1';
-    }();
-    if (masked) {
-        int dev = 0, cus = 0;
-        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) {
-            std::vector<uint32_t> mask(static_cast<size_t>((cus + 31) / 32), 0xffffffffu);
-            if (cus % 32) mask.back() = (1u << (cus % 32)) - 1u;
-            if (hipExtStreamCreateWithCUMask(stream, static_cast<uint32_t>(mask.size()), mask.data()) == hipSuccess) return hipSuccess;
-            (void)hipGetLastError();
-        }
-    }
-    return hipStreamCreateWithFlags(stream, hipStreamNonBlocking);
-}
+// one candidate for a compute stream of the library's own: non-blocking, at the caller's (normal) priority.  (A CU-masked stream -- a
+// hardware queue of its own -- was measured too: the same placement lottery, and every one of them is one more hardware queue, the
+// chip oversubscribed from the twelfth on; profiles/round5_hw_queue_collision.txt.)
+hipError_t create_side_stream(hipStream_t* stream) { return hipStreamCreateWithFlags(stream, hipStreamNonBlocking); }
 
 // do kernels on `a` and `b` overlap?  (both streams are synchronised first: a one-off cost, the first time a pair of streams meets)
 bool streams_run_side_by_side(hipStream_t a, hipStream_t b) {
