@@ -296,8 +296,20 @@ def main():
             except (AttributeError, TypeError):
                 return dist.new_group(backend="nccl")
 
+        def step_on_a_placed_stream():
+            """torch.distributed's RCCL next to our kernels: not on the null stream (torch's current stream), where RCCL works -- a rank
+            computing there steps ~40 % slower (profiles/round5_hw_queue_collision.txt).  A stream probed to be clear of the null stream's
+            hardware queue becomes torch's current stream (sharded.py orders its kernels against the collectives on the current stream)."""
+            placed = ctypes.c_void_p()
+            pkg.check(lib.nb_stream_create_placed(ctypes.byref(placed)), "nb_stream_create_placed")
+            torch.cuda.synchronize()
+            torch.cuda.set_stream(torch.cuda.ExternalStream(placed.value, device=dev))
+            return placed
+
         if args.exchange in ("torch", "allgather"):
             rccl_group = torch_rccl_group()
+            if world > 1:
+                step_on_a_placed_stream()  # (torch's current stream from here on: what `stream` / `stream_ptr` below pick up)
     info = pkg.device_info(local_rank)
 
     params = pkg.NBodyParams()
@@ -407,7 +419,7 @@ def main():
                 if capi_rank is not None:
                     capi_rank.destroy()
                 capi_rank, exchange_fallback, pairwise = None, True, False
-                stream_ptr = ctypes.c_void_p(stream.cuda_stream)  # (sharded.py orders its kernels against torch's collectives on torch's own stream)
+                stream_ptr = step_on_a_placed_stream()  # (sharded.py orders its kernels against torch's collectives on torch's CURRENT stream: this one now)
                 args.exchange = "torch"
                 rccl_group = torch_rccl_group()
 

@@ -138,6 +138,7 @@ SIGNATURES = {
     "nb_comm_destroy": (_ci, [_vp]),
     "nb_comm_info": (_ci, [_vp, _P(_ci), _P(_ci), _P(_ci)]),
     "nb_comm_stream_create": (_ci, [_vp, _P(_vp)]),
+    "nb_stream_create_placed": (_ci, [_P(_vp)]),
     "nb_comm_set_workspace": (_ci, [_vp, _vp, _sz]),
     "nb_comm_layout_f32": (_ci, [_vp, _cu, _ci, _P(_ci)]),
     "nb_comm_layout_f64": (_ci, [_vp, _cu, _ci, _P(_ci)]),

@@ -1304,6 +1304,19 @@ int nb_comm_last_step_trace(nb_comm_t comm, char* text, size_t bytes) {
 int nb_comm_pair_work_f32(nb_comm_t comm, unsigned num_bodies, unsigned long long* pair_evaluations, int* force_launches) { return comm_pair_work<float>(comm, num_bodies, pair_evaluations, force_launches); }
 int nb_comm_pair_work_f64(nb_comm_t comm, unsigned num_bodies, unsigned long long* pair_evaluations, int* force_launches) { return comm_pair_work<double>(comm, num_bodies, pair_evaluations, force_launches); }
 
+int nb_stream_create_placed(nb_stream_t* stream) {  // (nb_comm_stream_create without a communicator: for hosts that bring their own RCCL, e.g. torch.distributed)
+    NB_KEEP_RAND_STREAM;
+    if (stream == nullptr) return NB_ERR_INVALID_ARGUMENT;
+    *stream = nullptr;
+    static std::mutex               guard;
+    static std::vector<hipStream_t> retired;  // candidates on the null stream's queue: kept, so that the pool moves on
+    std::lock_guard<std::mutex>     lock(guard);
+    hipStream_t                     made = nullptr;
+    if (const auto err = settle_side_stream(&made, nullptr, &retired, nullptr); err != hipSuccess) return static_cast<int>(err);
+    *stream = made;
+    return 0;
+}
+
 int nb_comm_stream_create(nb_comm_t comm, nb_stream_t* stream) {
     NB_KEEP_RAND_STREAM;
     Comm* c = as_comm(comm);

@@ -203,6 +203,8 @@ NB_API int nb_comm_info(nb_comm_t comm, int* rank, int* world_size, int* device)
  * that shares its queue -- about one created stream in three -- steps ~40 % slower (measured with the real RCCL next to the force
  * kernels, profiles/round5_hw_queue_collision.txt).  This one is probed to be clear of that queue.  Any stream works; this one is fast. */
 NB_API int nb_comm_stream_create(nb_comm_t comm, nb_stream_t* stream);
+/* ... the same without a communicator, on the current device: for a host that runs an RCCL of its own next to these kernels. */
+NB_API int nb_stream_create_placed(nb_stream_t* stream);
 /* Lend a rank scratch memory (caller-owned, as everywhere; nb_comm_workspace_bytes_* says how much for this communicator,
  * 0 = none needed).  FAST mode then evaluates every PAIR of bodies once, across the ranks too: a communicator of one rank
  * steps through nb_integrate_ws_*; with G ranks, rank r evaluates its own slice against itself and against the slices of
