@@ -201,7 +201,9 @@ NB_API int nb_comm_info(nb_comm_t comm, int* rank, int* world_size, int* device)
 /* A stream to step this rank on (destroy it with nb_stream_destroy): non-blocking, and well PLACED.  The HIP runtime maps streams onto
  * a few hardware queues; RCCL puts work of its own on the null stream, and a rank that computes on the null stream or on a stream
  * that shares its queue -- about one created stream in three -- steps ~40 % slower (measured with the real RCCL next to the force
- * kernels, profiles/round5_hw_queue_collision.txt).  This one is probed to be clear of that queue.  Any stream works; this one is fast. */
+ * kernels, profiles/round5_hw_queue_collision.txt).  This one is probed to be clear of that queue.  Any stream works; this one is fast.
+ * (The library looks at the stream a rank steps on ONCE per stream -- two 40 us spin kernels and a synchronisation of that stream and of
+ * the null stream inside the first nb_sharded_step_* that sees it -- to be able to say so: nb_comm_caller_stream_placement, tuning header.) */
 NB_API int nb_comm_stream_create(nb_comm_t comm, nb_stream_t* stream);
 /* ... the same without a communicator, on the current device: for a host that runs an RCCL of its own next to these kernels. */
 NB_API int nb_stream_create_placed(nb_stream_t* stream);
