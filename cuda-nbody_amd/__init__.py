@@ -507,8 +507,8 @@ class ShardedRank:
         return bool(flag.value)
 
     def set_exchange_grouping(self, one_group: bool) -> None:
-        """nb_comm_set_exchange_grouping: all G-1 position rounds of a step in one RCCL group (True, the default) or a group and
-        an event per round (False); every rank must choose the same."""
+        """nb_comm_set_exchange_grouping: all G-1 position rounds of a step in one RCCL group (True) or a group and
+        an event per round (False, the default since round 5); every rank must choose the same."""
         check(lib().nb_comm_set_exchange_grouping(self.comm, 1 if one_group else 0), "nb_comm_set_exchange_grouping")
 
     def exchange_grouping(self) -> bool:
