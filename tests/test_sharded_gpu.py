@@ -296,3 +296,32 @@ def test_a_rank_must_not_step_on_the_null_stream_next_to_rccl():
             assert row["ms_per_step"] < 1.08 * placed["ms_per_step"], (name, row, placed)
         else:
             assert row["ms_per_step"] > 1.15 * placed["ms_per_step"], (name, row, placed)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,torch_first", [(5, False), (3, True)])
+def test_real_rccl_carries_a_real_step_and_one_gpu_agrees(world, torch_first):
+    """The multi-GPU step's NUMBERS through the real transport, on one GPU (tools/rccl_loopback_parity.py).  A loopback rank's data is
+    garbage in general -- what "arrives" is its own -- except for a system that is periodic in the slices (G copies of one slice, the
+    copies of a body on top of each other: zero force between them) and an ODD G (no rectangle split between two partners): by symmetry
+    every rank of a real run then holds the slice this rank holds, the tile "from rank r+s" IS the own slice and the reaction sums
+    "from rank r-s" ARE the ones this rank computed for r+s.  So the loopback step is the true step of rank r with its bytes really
+    travelling through ncclSend / ncclRecv -- position tiles, the group of tiles nobody waits for, reaction rounds in ready order, the
+    late diagonal, every event -- and its slice must equal one GPU's: STRICT bit for bit, FAST (one-sided tiles and pairwise across
+    the ranks) to summation-order accuracy.  Both RCCL builds of the image."""
+    import json
+    import subprocess
+    import sys
+
+    env = dict(os.environ)
+    for name in ("NBODY_RCCL_LIB", "NCCL_DEBUG", "FAKE_RCCL_IPC"):
+        env.pop(name, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rccl_loopback_parity.py"), "--world", str(world), "--slice", "4096", "--steps", "3", *(["--torch"] if torch_first else [])],
+                         capture_output=True, text=True, timeout=240, env=env)
+    rows = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    assert out.returncode == 0 and len(rows) == 1, (out.stdout[-1500:], out.stderr[-1500:])
+    got = rows[0]
+    assert got["ok"] and got["rccl_version"] >= 20000 and "fake" not in got["rccl_library"]
+    assert got["strict_bitwise"] and got["strict_every_tile_arrived"]
+    for name in ("fast_one_sided", "fast_pairwise"):
+        assert got[name + "_every_tile_arrived"] and got[name + "_finite"] and got[name + "_max_err_rel_to_size"] < 5e-6
