@@ -17,6 +17,7 @@ echo "bench ok: $(cut -c1-200 $OUT/bench.json)"
 timeout -k 10 300 python3 bench.py --layout one-sided --no-configs --no-cpu-baseline > $OUT/bench_one_sided.json 2> $OUT/bench_one_sided.err || exit 1
 # round 5: the real RCCL on this one GPU -- the self-loop (every byte checked) and the loopback rank next to the shipping kernels
 for how in "" "--torch"; do timeout -k 10 150 python3 tools/rccl_selfloop.py $how 2>/dev/null | grep "^{" >> $OUT/rccl_selfloop.jsonl || { echo "rccl_selfloop $how FAILED"; exit 1; }; done
+for a in "--world 5 --slice 4096 --steps 3" "--world 7 --slice 32768 --steps 2 --torch"; do timeout -k 10 250 python3 tools/rccl_loopback_parity.py $a 2>/dev/null | grep "^{" >> $OUT/rccl_loopback_parity.jsonl || { echo "rccl_loopback_parity $a FAILED"; exit 1; }; done
 for w in 8 4 2; do timeout -k 10 300 python3 tools/exchange_contention.py --bodies 262144 --world $w 2>/dev/null | grep "^{" >> $OUT/exchange_contention.jsonl || { echo "exchange_contention $w FAILED"; exit 1; }; done
 run_prof() { PROF_OUT=$OUT/$1 timeout -k 10 600 bash tools/profile.sh "${@:2}" > $OUT/$1.log 2>&1 && echo "$1 ok" || { echo "$1 FAILED"; tail -5 $OUT/$1.log; return 1; }; }
 run_prof f32 --steps 20 --warmup 3 &&
