@@ -473,7 +473,9 @@ template <typename T> PairShard plan_pair_shard(unsigned num_bodies, int G, int 
     // per launch keep their reaction slots apart; each launch has its own i-side sums.  nb_comm_set_late_diagonal(comm, 0): one launch.
     {
         const unsigned tiles = static_cast<unsigned>(R) * W, offsets = p.blocks / 2 + 1;
-        const unsigned first = late_diagonal && offsets >= 2 ? (offsets + 1) / 2 : offsets;
+        // ... for slices up to 65 536 bodies: the hop is ~40 us whatever the size, the second launch costs a rank ~0.3 % of its kernel
+        // time -- measured (profiles/round5_exchange_contention.jsonl): 32 768-body slices -1.1 %, 65 536 -0.5 %, 131 072 +0.2 ... +0.7 %
+        const unsigned first = late_diagonal && offsets >= 2 && p.ni <= 65536u ? (offsets + 1) / 2 : offsets;
         p.early_units = first * tiles, p.late_units = (offsets - first) * tiles;
     }
     p.diag      = {R, S, splits(p.early_units)};

@@ -33,7 +33,8 @@ NB_API int nb_set_pair_slices_override(int slices);
 /* Smallest slice (bodies per rank) for which a multi-GPU step goes pairwise across the ranks; 0 = automatic (2 048). */
 NB_API int nb_comm_set_pair_min_slice(int min_bodies_per_rank);
 
-/* A rank's diagonal (its own slice against itself) in a pairwise multi-GPU step: 1 (default) = two launches, the first half of the
+/* A rank's diagonal (its own slice against itself) in a pairwise multi-GPU step: 1 (default) = two launches (for slices up to 65 536
+ * bodies: beyond, the hop it hides is under 0.3 % of a step and the second launch costs as much), the first half of the
  * block offsets first and the rest as the rank's LAST force kernel, so that the last reaction sums travel under local work;
  * 0 = one launch, first (the order up to round 4) -- for A/B timings.  Process-global like the plan overrides; with one process
  * per GPU every rank must set the same (nb_comm_set_workspace checks it).  Summation order, hence the last bits, differ. */
