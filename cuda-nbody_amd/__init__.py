@@ -177,6 +177,7 @@ TUNING_SIGNATURES = {
     "nb_lds_optin_count": (_ci, [_P(_ci)]),
     "nb_comm_selftest_open": (_ci, [_P(_vp), _vp]),
     "nb_comm_loopback_open": (_ci, [_P(_vp), _vp, _ci, _ci]),
+    "nb_comm_inprocess_open_all": (_ci, [_P(_vp), _ci, _vp]),
     "nb_comm_selftest_f32": (_ci, [_vp, _sz, _vp, _P(CommSelftest)]),
     "nb_comm_self_transfer_f32": (_ci, [_vp, _vp, _vp, _sz, _ci, _ci, _vp, _vp, _vp]),
     "nb_comm_transport_info": (_ci, [_vp, _P(_ci), ctypes.c_char_p, _sz]),

@@ -41,6 +41,7 @@
 #include <atomic>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -143,6 +144,9 @@ struct Comm {
     std::vector<hipEvent_t> react_arrived; // [world/2 + 1] ... "round s of the reaction exchange is done" (exchange stream)
     std::vector<Comm*> group;              // all local ranks of this communicator (just {this} with one process per GPU)
     std::string trace;                     // what the rank's last pairwise step enqueued, in host order (nb_comm_last_step_trace: tests read the order)
+    bool        inprocess = false;         // nb_comm_inprocess_open_all (tuning header): all G ranks live in this process on ONE device and share one real
+    bool        owns_stream = true;        // one-rank ncclComm and one exchange stream; a send of rank a is routed to the receive of rank b by the ORDER of the
+    std::shared_ptr<void> shared_nccl;     // self-transfers (RCCL matches sends and receives of one peer first in, first out)
     bool        loopback = false;          // nb_comm_loopback_open (tuning header): rank / world are NOMINAL, the ncclComm has one rank and every peer is this rank itself
 };
 
@@ -315,7 +319,7 @@ void free_resources(Comm* c) {
     if (c->aux_done) (void)hipEventDestroy(c->aux_done);
     if (c->aux) (void)hipStreamDestroy(c->aux);
     for (hipStream_t s : c->aux_retired) (void)hipStreamDestroy(s);
-    if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->stream && c->owns_stream) (void)hipStreamDestroy(c->stream);
 }
 
 // `locals` is a permutation of the local ranks of one communicator (and nothing else)
@@ -370,6 +374,22 @@ int exchange_tiles(const std::vector<Comm*>& locals, void* const* positions, uns
         const int last = one_group ? G - 1 : ((waited_for > 0 && first > waited_for) ? G - 1 : first);  // rounds first .. last form one group
         int       rc   = lib->GroupStart();
         for (int s = first; s <= last && rc == 0; ++s) {
+            if (locals.front()->inprocess) {
+                // every transfer is a self-transfer of the ONE ncclComm: the k-th send meets the k-th receive, so the receives are issued
+                // in the order of the ranks whose data they take -- rank d = c - s receives what rank c sends
+                std::vector<size_t> at(static_cast<size_t>(G));
+                for (size_t k = 0; k < locals.size(); ++k) at[static_cast<size_t>(locals[k]->rank)] = k;
+                for (int c0 = 0; c0 < G && rc == 0; ++c0) {
+                    Comm* c = locals[at[static_cast<size_t>(c0)]];
+                    rc      = lib->Send(static_cast<char*>(positions[at[static_cast<size_t>(c0)]]) + static_cast<size_t>(c0) * slice_bodies * bytes_per_body, slice_values, nccl_type, 0, c->nccl, c->stream);
+                }
+                for (int c0 = 0; c0 < G && rc == 0; ++c0) {
+                    const int d = (c0 - s + G) % G;
+                    Comm*     c = locals[at[static_cast<size_t>(d)]];
+                    rc          = lib->Recv(static_cast<char*>(positions[at[static_cast<size_t>(d)]]) + static_cast<size_t>(c0) * slice_bodies * bytes_per_body, slice_values, nccl_type, 0, c->nccl, c->stream);
+                }
+                continue;
+            }
             for (size_t k = 0; k < locals.size() && rc == 0; ++k) {
                 Comm*      c    = locals[k];
                 const int  dst  = (c->rank - s + G) % G, src = (c->rank + s) % G;
@@ -640,7 +660,19 @@ template <typename T> int reaction_exchange(const std::vector<Comm*>& locals, co
             if (const auto err = hipStreamWaitEvent(c->stream, c->react_ready[s], 0); err != hipSuccess) return static_cast<int>(err);
         }
         int rc = lib->GroupStart();
-        for (size_t k = 0; k < locals.size() && rc == 0; ++k) {
+        if (locals.front()->inprocess) {  // (routed by order, as in exchange_tiles: rank c + s receives what rank c sends)
+            std::vector<size_t> at(static_cast<size_t>(G));
+            for (size_t k = 0; k < locals.size(); ++k) at[static_cast<size_t>(locals[k]->rank)] = k;
+            for (int c0 = 0; c0 < G && rc == 0; ++c0) {
+                Comm* c = locals[at[static_cast<size_t>(c0)]];
+                rc      = lib->Send(static_cast<T*>(c->workspace) + plan.send_at + (s - 1) * plane3, plane3, Api<T>::nccl_type, 0, c->nccl, c->stream);
+            }
+            for (int c0 = 0; c0 < G && rc == 0; ++c0) {
+                Comm* c = locals[at[static_cast<size_t>((c0 + static_cast<int>(s)) % G)]];
+                rc      = lib->Recv(static_cast<T*>(c->workspace) + plan.recv_at + (s - 1) * plane3, plane3, Api<T>::nccl_type, 0, c->nccl, c->stream);
+            }
+        }
+        for (size_t k = 0; k < locals.size() && rc == 0 && !locals.front()->inprocess; ++k) {
             Comm*     c    = locals[k];
             T* const  work = static_cast<T*>(c->workspace);
             const int to = (c->rank + static_cast<int>(s)) % G, from = (c->rank - static_cast<int>(s) + G) % G;
@@ -1010,7 +1042,8 @@ int nb_comm_destroy(nb_comm_t comm) {
         DeviceScope scope(c->device);
         (void)hipStreamSynchronize(c->stream);
     }
-    if (c->nccl != nullptr)
+    if (c->shared_nccl) c->shared_nccl.reset();  // (the last rank of an in-process world destroys the ncclComm they share)
+    else if (c->nccl != nullptr)
         if (Rccl* lib = rccl(); lib != nullptr) (void)lib->CommDestroy(c->nccl);
     free_resources(c);
     delete c;
@@ -1119,6 +1152,49 @@ int nb_comm_selftest_open(nb_comm_t* comm, const void* id) { return init_rank(co
 int nb_comm_loopback_open(nb_comm_t* comm, const void* id, int nominal_world, int nominal_rank) {
     if (nominal_world < 2) return NB_ERR_INVALID_ARGUMENT;
     return init_rank(comm, id, nominal_world, nominal_rank, true, true);
+}
+
+// An IN-PROCESS world: all G ranks in this process, on the current device, sharing ONE real one-rank ncclComm and one exchange stream.
+// Every transfer is a self-transfer of that communicator; RCCL matches the sends and receives of one peer first in, first out, so
+// the library routes rank a's send to rank b's receive by the ORDER in which it issues them (exchange_tiles, reaction_exchange).  The
+// full G-rank step -- even G, split rectangles and all -- then runs through the product's own calls into the REAL library, its
+// results comparable with the CPU path: what RCCL's refusal of two ranks per device otherwise leaves to the transport double.
+int nb_comm_inprocess_open_all(nb_comm_t* comms, int world, const void* id) {
+    NB_KEEP_RAND_STREAM;
+    if (comms == nullptr || id == nullptr || world < 2) return NB_ERR_INVALID_ARGUMENT;
+    Rccl* lib = rccl();
+    if (lib == nullptr) return NB_ERR_UNSUPPORTED;
+    ncclUniqueId uid;
+    std::memcpy(uid.internal, id, sizeof(uid.internal));
+    ncclComm_t real = nullptr;
+    if (const int rc = lib->CommInitRank(&real, 1, uid, 0); rc != 0) return nccl_status(rc);
+    std::shared_ptr<void> owner(real, [lib](void* p) { (void)lib->CommDestroy(static_cast<ncclComm_t>(p)); });
+    int device = 0;
+    if (const auto err = hipGetDevice(&device); err != hipSuccess) return static_cast<int>(err);
+    std::vector<Comm*> made;
+    int                rc = 0;
+    for (int k = 0; k < world && rc == 0; ++k) {
+        auto* c      = new Comm;
+        c->nccl      = real, c->shared_nccl = owner;
+        c->rank      = k, c->world = world, c->device = device;
+        c->loopback  = true, c->inprocess = true;
+        made.push_back(c);
+        rc = make_resources(c);
+        if (rc == 0 && k > 0) {  // one exchange stream for all: the ranks' self-transfers of a round are ONE RCCL group on one stream
+            (void)hipStreamDestroy(c->stream);
+            c->stream = made.front()->stream, c->owns_stream = false;
+        }
+    }
+    if (rc != 0) {
+        for (Comm* c : made) {
+            free_resources(c);
+            delete c;
+        }
+        return rc;
+    }
+    for (Comm* c : made) c->group = made;
+    for (int k = 0; k < world; ++k) comms[k] = made[static_cast<size_t>(k)];
+    return 0;
 }
 
 int nb_comm_transport_info(nb_comm_t comm, int* version, char* library_path, size_t path_bytes) {

@@ -84,6 +84,12 @@ NB_API int nb_comm_selftest_open(nb_comm_t* comm, const void* id /* NB_COMM_ID_B
  * a real step minus what the xGMI links would add (tools/exchange_contention.py, bench.py's one-GPU projection).
  * nb_comm_set_workspace stays the collective it is (the notes travel to the rank itself). */
 NB_API int nb_comm_loopback_open(nb_comm_t* comm, const void* id /* NB_COMM_ID_BYTES */, int nominal_world, int nominal_rank);
+/* An IN-PROCESS world: `world` ranks in this process, all on the current device, sharing ONE real one-rank RCCL communicator -- every
+ * transfer a self-transfer, rank a's send routed to rank b's receive by the order in which the library issues them (RCCL matches the
+ * sends and receives of one peer first in, first out).  nb_sharded_step_all_* on these comms is the full G-rank step -- even G, the
+ * split rectangle and all -- through the product's own calls into the REAL library, comparable with the CPU path
+ * (tests/test_comm_fake_rccl.py runs its `all` cases this way too).  Destroy every rank with nb_comm_destroy. */
+NB_API int nb_comm_inprocess_open_all(nb_comm_t* comms /* [world] */, int world, const void* id /* NB_COMM_ID_BYTES */);
 NB_API int nb_comm_selftest_f32(nb_comm_t comm, size_t bytes, nb_stream_t stream, nb_comm_selftest_t* report);
 NB_API int nb_comm_self_transfer_f32(nb_comm_t comm, const float* src, float* dst, size_t count, int rounds, int one_group, nb_stream_t after,
                                      nb_event_t begin, nb_event_t end);

@@ -7,7 +7,7 @@ library resolves RCCL, which happens once per process -- hence a process of its 
 
 `ws`: every rank is lent the workspace nb_comm_workspace_bytes_* asks for (FAST then takes the pairwise step across the ranks).
 Environment: WORKER_ONE_GROUP=0|1 -> nb_comm_set_exchange_grouping on every communicator (unset: the library's default);
-WORKER_LATE_DIAGONAL=0|1 -> nb_set_late_diagonal;
+WORKER_LATE_DIAGONAL=0|1 -> nb_set_late_diagonal; WORKER_REAL_RCCL=1 -> the `all` case over the REAL RCCL (an in-process world);
 WORKER_NO_WORKSPACE_RANK=k -> rank k lends nothing (nb_comm_set_workspace(comm, NULL, 0)): the layout must then be one-sided on
 EVERY rank.  The output holds `layout` (nb_comm_layout_* per rank) and `setup_counters` (what the transport had seen before the
 first step: nb_comm_set_workspace's exchange with one process -- here: thread -- per rank).
@@ -29,7 +29,12 @@ sys.path.insert(0, ROOT)
 import __graft_entry__ as entry  # noqa: E402
 
 
+REAL_RCCL = os.environ.get("WORKER_REAL_RCCL") == "1"  # the `all` case as an IN-PROCESS world over the REAL library (nb_comm_inprocess_open_all)
+
+
 def counters():
+    if REAL_RCCL:  # (the real library keeps no such counters)
+        return dict.fromkeys(("sends", "recvs", "allgathers", "groups", "copies"), 0)
     fake = ctypes.CDLL(os.environ["NBODY_RCCL_LIB"])
     vals = [ctypes.c_long(0) for _ in range(5)]
     fake.fake_rccl_counters(*[ctypes.byref(v) for v in vals])
@@ -61,7 +66,8 @@ def main():
     mode_name = sys.argv[6] if len(sys.argv) > 6 else "strict"
     own_streams = (sys.argv[7] if len(sys.argv) > 7 else "streams") == "streams"
     with_workspace = len(sys.argv) > 8 and sys.argv[8] == "ws"
-    assert os.environ.get("NBODY_RCCL_LIB", "").endswith("libfake_rccl.so"), "the parent must point NBODY_RCCL_LIB at the test double"
+    assert REAL_RCCL or os.environ.get("NBODY_RCCL_LIB", "").endswith("libfake_rccl.so"), "the parent must point NBODY_RCCL_LIB at the test double"
+    assert not (REAL_RCCL and "NBODY_RCCL_LIB" in os.environ), "WORKER_REAL_RCCL=1 binds the real library"
 
     pkg = entry.load_package()
     lib = pkg.lib()
@@ -126,7 +132,12 @@ def main():
     if case == "all":
         # ONE thread drives every rank: nb_comm_init_all + nb_sharded_step_all_* (every RCCL round is one group over the ranks)
         comms = (ctypes.c_void_p * G)()
-        pkg.check(lib.nb_comm_init_all(comms, G, (ctypes.c_int * G)(*([0] * G))), "nb_comm_init_all")
+        if REAL_RCCL:  # RCCL refuses two ranks per device: the ranks share ONE real one-rank communicator, transfers routed by order
+            uid = ctypes.create_string_buffer(128)
+            pkg.check(lib.nb_comm_unique_id(uid), "nb_comm_unique_id")
+            pkg.check(lib.nb_comm_inprocess_open_all(comms, G, uid), "nb_comm_inprocess_open_all")
+        else:
+            pkg.check(lib.nb_comm_init_all(comms, G, (ctypes.c_int * G)(*([0] * G))), "nb_comm_init_all")
         ranks = [Rank(pkg, pos0, vel0, own_streams) for _ in range(G)]
         arr = lambda xs: (ctypes.c_void_p * G)(*xs)  # noqa: E731
         # argument checks first (nothing is launched by a rejected call): a subset of the group, a rank twice, the per-rank form

@@ -36,11 +36,16 @@ def _env(**extra):
     return env
 
 
-def _run(tmp_path, case, pos0, vel0, world, steps, mode, streams="streams", workspace=False, **env):
+def _run(tmp_path, case, pos0, vel0, world, steps, mode, streams="streams", workspace=False, real_rccl=False, **env):
     src, dst = tmp_path / f"in_{case}.npz", tmp_path / f"out_{case}.npz"
     np.savez(src, pos=pos0, vel=vel0)
+    environment = _env(**env)
+    if real_rccl:  # the `all` case as an in-process world over the REAL library (nb_comm_inprocess_open_all)
+        environment.pop("NBODY_RCCL_LIB")
+        environment.pop("NCCL_DEBUG", None)
+        environment["WORKER_REAL_RCCL"] = "1"
     r = subprocess.run([sys.executable, os.path.join(FAKE_DIR, "worker.py"), case, str(src), str(dst), str(world), str(steps), mode, streams, "ws" if workspace else "-"],
-                       env=_env(**env), capture_output=True, text=True, timeout=900)
+                       env=environment, capture_output=True, text=True, timeout=300 if real_rccl else 900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     with np.load(dst, allow_pickle=False) as data:  # read everything now: the next run of the same case rewrites the file
         return {k: data[k] for k in data.files}
@@ -404,3 +409,35 @@ def test_layout_is_agreed_by_the_whole_communicator(tmp_path, oracle, case):
         assert got[f"pos_{k}"].tobytes() == plain["pos_0"].tobytes()
     everyone = _run(tmp_path, case, pos0, vel0, world, steps, "fast", workspace=True)
     assert list(everyone["layout"]) == [1] * world and everyone["pos_0"].tobytes() != plain["pos_0"].tobytes()
+
+
+# ------------------------------------------------------------------------------------------------ ... and through the REAL library
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_even_worlds_through_the_real_rccl_in_one_process(tmp_path, oracle, world):
+    """RCCL refuses two ranks on one device, so every test above runs on the transport double.  An IN-PROCESS world
+    (nb_comm_inprocess_open_all, tuning header) closes the gap for the world sizes the benchmark runs at: all G ranks in one process
+    on the one GPU share ONE real one-rank ncclComm, every transfer is a self-transfer, and the library routes rank a's send to
+    rank b's receive by the order in which it issues them (RCCL matches the sends and receives of one peer first in, first out).
+    nb_sharded_step_all_f32 is then the FULL G-rank step -- split rectangle, reaction leg in ready order, late diagonal, the group of
+    tiles nobody waits for -- through the product's own calls into the real ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd:
+    STRICT == the CPU path bit for bit on every rank, FAST pairwise across the ranks within the single-GPU tolerance and the same
+    bits as the same step over the transport double."""
+    n, steps = world * 1024, 3
+    pos0, vel0 = oracle.startup_state(n, np.float32)
+    ref_p, ref_v = pos0.copy(), vel0.copy()
+    oracle.update(ref_p, ref_v, np.float32(0.016), steps=steps)
+    strict = _run(tmp_path, "all", pos0, vel0, world, steps, "strict", real_rccl=True)
+    for k in range(world):
+        assert strict[f"pos_{k}"].tobytes() == ref_p.tobytes()
+    assert np.concatenate([strict[f"vel_{k}"] for k in range(world)]).tobytes() == ref_v.tobytes()
+    fast = _run(tmp_path, "all", pos0, vel0, world, steps, "fast", workspace=True, real_rccl=True)
+    assert list(fast["layout"]) == [1] * world
+    for k in range(1, world):
+        assert fast[f"pos_{k}"].tobytes() == fast["pos_0"].tobytes()
+    np.testing.assert_allclose(fast["pos_0"], ref_p, rtol=1e-5, atol=1e-5)
+    double = _run(tmp_path, "all", pos0, vel0, world, steps, "fast", workspace=True)
+    assert double["pos_0"].tobytes() == fast["pos_0"].tobytes()  # the transport changes nothing: the same sums in the same order
+    one_sided = _run(tmp_path, "all", pos0, vel0, world, steps, "fast", workspace=False, real_rccl=True)
+    np.testing.assert_allclose(one_sided["pos_0"], ref_p, rtol=1e-5, atol=1e-5)
+    assert one_sided["pos_0"].tobytes() != fast["pos_0"].tobytes()
