@@ -441,3 +441,24 @@ def test_even_worlds_through_the_real_rccl_in_one_process(tmp_path, oracle, worl
     one_sided = _run(tmp_path, "all", pos0, vel0, world, steps, "fast", workspace=False, real_rccl=True)
     np.testing.assert_allclose(one_sided["pos_0"], ref_p, rtol=1e-5, atol=1e-5)
     assert one_sided["pos_0"].tobytes() != fast["pos_0"].tobytes()
+
+
+@pytest.mark.gpu
+def test_full_size_eight_ranks_through_the_real_rccl(tmp_path, oracle):
+    """BASELINE configs[2] as the strong-scaling series shards it over 8 ranks -- 262 144 bodies, slices of 32 768 -- as an in-process
+    world over the REAL RCCL: STRICT two steps == one rank's nb_integrate_f32 on ALL bodies, bit for bit (512 KiB position tiles);
+    FAST pairwise across the ranks (384 KiB reaction arrays, the late diagonal, rounds in ready order) one step against one rank at the
+    tolerance of the transport-double test above, and the very bits the double gives."""
+    n, world = 262144, 8
+    pos0, vel0 = oracle.startup_state(n, np.float32)
+    strict = _run(tmp_path, "all", pos0, vel0, world, 2, "strict", real_rccl=True)
+    for k in range(world):
+        assert strict[f"pos_{k}"].tobytes() == strict["single_pos"].tobytes()
+    assert np.concatenate([strict[f"vel_{k}"] for k in range(world)]).tobytes() == strict["single_vel"].tobytes()
+    fast = _run(tmp_path, "all", pos0, vel0, world, 1, "fast", workspace=True, real_rccl=True)
+    assert list(fast["layout"]) == [1] * world
+    for k in range(1, world):
+        assert fast[f"pos_{k}"].tobytes() == fast["pos_0"].tobytes()
+    np.testing.assert_allclose(fast["pos_0"], fast["single_pos"], rtol=0, atol=2e-5)
+    double = _run(tmp_path, "all", pos0, vel0, world, 1, "fast", workspace=True)
+    assert double["pos_0"].tobytes() == fast["pos_0"].tobytes()
