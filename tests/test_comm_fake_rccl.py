@@ -462,3 +462,21 @@ def test_full_size_eight_ranks_through_the_real_rccl(tmp_path, oracle):
     np.testing.assert_allclose(fast["pos_0"], fast["single_pos"], rtol=0, atol=2e-5)
     double = _run(tmp_path, "all", pos0, vel0, world, 1, "fast", workspace=True)
     assert double["pos_0"].tobytes() == fast["pos_0"].tobytes()
+
+
+@pytest.mark.gpu
+def test_fp64_four_ranks_through_the_real_rccl_in_one_process(tmp_path, oracle):
+    """... and in double precision (ncclFloat64 tiles of 32 B per body, reaction arrays of 24 B): STRICT == the CPU path bit for bit, FAST
+    pairwise across the ranks at the fp64 tolerance and the bits of the transport double."""
+    n, steps, world = 4096, 3, 4
+    pos0, vel0 = oracle.startup_state(n, np.float64)
+    ref_p, ref_v = pos0.copy(), vel0.copy()
+    oracle.update(ref_p, ref_v, np.float64(np.float32(0.016)), steps=steps)
+    strict = _run(tmp_path, "all", pos0, vel0, world, steps, "strict", real_rccl=True)
+    for k in range(world):
+        assert strict[f"pos_{k}"].tobytes() == ref_p.tobytes()
+    fast = _run(tmp_path, "all", pos0, vel0, world, steps, "fast", workspace=True, real_rccl=True)
+    assert list(fast["layout"]) == [1] * world
+    np.testing.assert_allclose(fast["pos_0"], ref_p, rtol=1e-12, atol=1e-12)
+    double = _run(tmp_path, "all", pos0, vel0, world, steps, "fast", workspace=True)
+    assert double["pos_0"].tobytes() == fast["pos_0"].tobytes()
