@@ -147,6 +147,7 @@ struct Comm {
     bool        inprocess = false;         // nb_comm_inprocess_open_all (tuning header): all G ranks live in this process on ONE device and share one real
     bool        owns_stream = true;        // one-rank ncclComm and one exchange stream; a send of rank a is routed to the receive of rank b by the ORDER of the
     std::shared_ptr<void> shared_nccl;     // self-transfers (RCCL matches sends and receives of one peer first in, first out)
+    std::shared_ptr<void> shared_stream;   // ... both go with the LAST rank of that world to be destroyed, in whatever order the ranks are
     bool        loopback = false;          // nb_comm_loopback_open (tuning header): rank / world are NOMINAL, the ncclComm has one rank and every peer is this rank itself
 };
 
@@ -662,7 +663,7 @@ template <typename T> int reaction_exchange(const std::vector<Comm*>& locals, co
         int rc = lib->GroupStart();
         if (locals.front()->inprocess) {  // (routed by order, as in exchange_tiles: rank c + s receives what rank c sends)
             std::vector<size_t> at(static_cast<size_t>(G));
-            for (size_t k = 0; k < locals.size(); ++k) at[static_cast<size_t>(locals[k]->rank)] = k;
+            for (size_t m = 0; m < locals.size(); ++m) at[static_cast<size_t>(locals[m]->rank)] = m;
             for (int c0 = 0; c0 < G && rc == 0; ++c0) {
                 Comm* c = locals[at[static_cast<size_t>(c0)]];
                 rc      = lib->Send(static_cast<T*>(c->workspace) + plan.send_at + (s - 1) * plane3, plane3, Api<T>::nccl_type, 0, c->nccl, c->stream);
@@ -672,8 +673,8 @@ template <typename T> int reaction_exchange(const std::vector<Comm*>& locals, co
                 rc      = lib->Recv(static_cast<T*>(c->workspace) + plan.recv_at + (s - 1) * plane3, plane3, Api<T>::nccl_type, 0, c->nccl, c->stream);
             }
         }
-        for (size_t k = 0; k < locals.size() && rc == 0 && !locals.front()->inprocess; ++k) {
-            Comm*     c    = locals[k];
+        for (size_t m = 0; m < locals.size() && rc == 0 && !locals.front()->inprocess; ++m) {
+            Comm*     c    = locals[m];
             T* const  work = static_cast<T*>(c->workspace);
             const int to = (c->rank + static_cast<int>(s)) % G, from = (c->rank - static_cast<int>(s) + G) % G;
             rc              = lib->Send(work + plan.send_at + (s - 1) * plane3, plane3, Api<T>::nccl_type, peer_of(c, to), c->nccl, c->stream);
@@ -1192,7 +1193,11 @@ int nb_comm_inprocess_open_all(nb_comm_t* comms, int world, const void* id) {
         }
         return rc;
     }
-    for (Comm* c : made) c->group = made;
+    std::shared_ptr<void> stream_owner(made.front()->stream, [device](void* s) {
+        DeviceScope scope(device);
+        (void)hipStreamDestroy(static_cast<hipStream_t>(s));
+    });
+    for (Comm* c : made) c->group = made, c->shared_stream = stream_owner, c->owns_stream = false;
     for (int k = 0; k < world; ++k) comms[k] = made[static_cast<size_t>(k)];
     return 0;
 }

@@ -167,7 +167,7 @@ def main():
             p, v = r.results(comms[k], pos0, vel0)
             out[f"pos_{k}"] = p
             out[f"vel_{k}"] = v.reshape(n, 4)[k * ni:(k + 1) * ni].ravel()  # velocities live with their owner
-        for c in comms:
+        for c in (reversed(list(comms)) if REAL_RCCL else comms):  # (an in-process world shares its ncclComm and exchange stream: any order must do)
             pkg.check(lib.nb_comm_destroy(c), "nb_comm_destroy")
 
     elif case in ("threads", "exchange"):
