@@ -24,6 +24,7 @@ LIB_PATH = os.environ.get("NBODY_HIP_LIB", os.path.join(HERE, "libnbody_hip.so")
 NB_MODE_STRICT, NB_MODE_FAST = 0, 1
 NB_SHARD_ACC_IN, NB_SHARD_FINALIZE = 1, 2
 NB_ERR_INVALID_ARGUMENT, NB_ERR_UNSUPPORTED, NB_ERR_RCCL_BASE = 10001, 10002, 20000
+NB_ERR_OUT_OF_MEMORY = 2  # = hipErrorOutOfMemory: what nb_alloc answers when the device has no room
 
 # enum class NBodyConfig, src/nbody/nbody_config.hpp:3
 NBODY_CONFIG_RANDOM, NBODY_CONFIG_SHELL, NBODY_CONFIG_EXPAND = 0, 1, 2

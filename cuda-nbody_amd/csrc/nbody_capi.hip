@@ -37,6 +37,7 @@ std::atomic<int>   g_pair_slices{0};                                    // nb_se
 std::atomic<size_t> g_total_memory[64] = {};  // per device, filled by the one-time warm-up below (0: unknown)
 std::atomic<size_t> g_memory_budget{0};       // nb_set_memory_budget: what to assume instead (0: the device's own figure)
 std::atomic<size_t> g_alloc_limit{0};         // nb_set_alloc_limit: nb_alloc requests above this are made to fail IN THE RUNTIME (0: none)
+static_assert(NB_ERR_OUT_OF_MEMORY == hipErrorOutOfMemory, "the header names the runtime's own value");
 
 int current_device_ready() {
     static std::atomic<int> cu_count[64] = {};

@@ -51,28 +51,38 @@ template <std::floating_point T> auto BodySystemHIPSharded<T>::allocate(std::spa
     comms_.assign(devices.size(), nullptr);
     hip_check(nb_comm_init_all(comms_.data(), static_cast<int>(devices.size()), devices.data()), "nb_comm_init_all");
     shards_.resize(devices.size());
-    for (std::size_t g = 0; g < devices.size(); ++g) {
-        auto&         shard = shards_[g];
-        shard.device        = devices[g];
-        CurrentDevice scope(shard.device);
-        shard.pos[0] = DeviceArray<T>(values), shard.pos[1] = DeviceArray<T>(values);
-        shard.vel = DeviceArray<T>(values), shard.acc = DeviceArray<T>(values);
-        hip_check(nb_comm_stream_create(comms_[g], &shard.stream), "nb_comm_stream_create");
+    try {
+        for (std::size_t g = 0; g < devices.size(); ++g) {
+            auto&         shard = shards_[g];
+            shard.device        = devices[g];
+            CurrentDevice scope(shard.device);
+            shard.pos[0] = DeviceArray<T>(values), shard.pos[1] = DeviceArray<T>(values);
+            shard.vel = DeviceArray<T>(values), shard.acc = DeviceArray<T>(values);
+            hip_check(nb_comm_stream_create(comms_[g], &shard.stream), "nb_comm_stream_create");
+        }
+    } catch (...) {  // (a constructor that throws runs no destructor: the communicators -- RCCL's included -- and streams made so far would stay)
+        release();
+        throw;
     }
 }
 
-template <std::floating_point T> BodySystemHIPSharded<T>::~BodySystemHIPSharded() {
+template <std::floating_point T> BodySystemHIPSharded<T>::~BodySystemHIPSharded() { release(); }
+
+template <std::floating_point T> auto BodySystemHIPSharded<T>::release() noexcept -> void {
     for (auto& shard : shards_) {
         if (shard.stream == nullptr) continue;
         (void)nb_set_device(shard.device);
         (void)nb_stream_synchronize(shard.stream);
     }
-    for (auto comm : comms_)
+    for (auto& comm : comms_) {
         if (comm != nullptr) (void)nb_comm_destroy(comm);
+        comm = nullptr;
+    }
     for (auto& shard : shards_) {
         if (shard.stream == nullptr) continue;
         (void)nb_set_device(shard.device);
         (void)nb_stream_destroy(shard.stream);
+        shard.stream = nullptr;
     }
     if (!shards_.empty()) (void)nb_set_device(shards_.front().device);
 }
@@ -139,7 +149,7 @@ template <std::floating_point T> auto BodySystemHIPSharded<T>::ensure_workspaces
             hip_check(nb_device_synchronize(), "nb_device_synchronize");  // nothing may still be using the old one
             try {
                 shards_[g].workspace = DeviceArray<unsigned char>(need[g]);
-            } catch (const std::exception&) {
+            } catch (const std::bad_alloc&) {
                 lend = false;  // no memory for it on this device: nobody steps pairwise
             }
         }

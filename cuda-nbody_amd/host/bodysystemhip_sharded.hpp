@@ -45,6 +45,7 @@ template <std::floating_point T> class BodySystemHIPSharded final : public BodyS
         nb_stream_t    stream = nullptr;  // the shard steps here: nb_comm_stream_create (non-blocking, clear of the null stream's hardware queue)
     };
     auto allocate(std::span<const int> devices) -> void;
+    auto release() noexcept -> void;  // communicators and streams (the destructor's work; also allocate()'s when a constructor throws half-way)
     auto ensure_workspaces() -> void;  // (re)lends every shard what the current mode asks for
     int  workspace_mode_ = -1;
 

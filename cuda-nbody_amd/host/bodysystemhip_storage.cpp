@@ -72,7 +72,7 @@ template <std::floating_point T, template <std::floating_point> class Storage> a
         try {
             workspace_ = DeviceArray<unsigned char>(need);
             break;
-        } catch (const std::runtime_error&) {
+        } catch (const std::bad_alloc&) {  // (out of device memory -- DeviceBadAlloc; any other failure is not ours to paper over)
             cap  = need / 2;
             need = 0;
         }

@@ -8,15 +8,24 @@
 
 #include <algorithm>
 #include <cstddef>
+#include <new>
 #include <span>
 #include <utility>
+
+// what thrust::device_vector throws when the device has no room (thrust::system::detail::bad_alloc IS a std::bad_alloc: the
+// reference's main answers it with "Unable to allocate memory!" and exit code 3, nbody.cpp:396-408)
+struct DeviceBadAlloc : std::bad_alloc {
+    auto what() const noexcept -> const char* override { return "nb_alloc: out of device memory"; }
+};
 
 template <typename T> class DeviceArray {
  public:
     DeviceArray() = default;
     explicit DeviceArray(std::size_t n) : size_(n) {
         void* p = nullptr;
-        hip_check(nb_alloc(&p, n * sizeof(T)), "nb_alloc");
+        const int status = nb_alloc(&p, n * sizeof(T));
+        if (status == NB_ERR_OUT_OF_MEMORY) throw DeviceBadAlloc{};
+        hip_check(status, "nb_alloc");
         ptr_ = static_cast<T*>(p);
         hip_check(nb_memset(ptr_, 0, n * sizeof(T), nullptr), "nb_memset");
     }

@@ -39,6 +39,10 @@ extern "C" {
 
 #define NB_API __attribute__((visibility("default")))
 
+/* The one hipError_t value a host has to tell from the others: nb_alloc / nb_host_alloc_mapped could not get the memory
+ * (thrust::device_vector throws a std::bad_alloc there, which the reference's main turns into exit code 3: nbody.cpp:396-408). */
+#define NB_ERR_OUT_OF_MEMORY 2 /* = hipErrorOutOfMemory */
+
 /* Host-side argument errors (outside hipError_t's range). */
 #define NB_ERR_INVALID_ARGUMENT 10001
 #define NB_ERR_UNSUPPORTED      10002

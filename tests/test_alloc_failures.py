@@ -32,7 +32,7 @@ def test_steps_after_a_refused_allocation_succeed(gpu, oracle):
     def refused():
         p = ctypes.c_void_p()
         rc = lib.nb_alloc(ctypes.byref(p), 1 << 60)
-        assert rc != 0 and not p.value and b"emory" in lib.nb_error_string(rc)  # hipErrorOutOfMemory (or ...MemoryAllocation)
+        assert rc == gpu.NB_ERR_OUT_OF_MEMORY and not p.value and b"emory" in lib.nb_error_string(rc)  # hipErrorOutOfMemory: the value the host turns into std::bad_alloc
         return rc
 
     refused()
@@ -45,7 +45,7 @@ def test_steps_after_a_refused_allocation_succeed(gpu, oracle):
     try:
         gpu.check(lib.nb_set_alloc_limit(1 << 20))
         p = ctypes.c_void_p()
-        assert lib.nb_alloc(ctypes.byref(p), (1 << 20) + 1) != 0 and not p.value
+        assert lib.nb_alloc(ctypes.byref(p), (1 << 20) + 1) == gpu.NB_ERR_OUT_OF_MEMORY and not p.value
         assert lib.nb_integrate_ws_f32(bufs[1].ptr, bufs[0].ptr, bufs[2].ptr, *args, work.ptr, need, None) == 0
         assert lib.nb_alloc(ctypes.byref(p), 1 << 20) == 0 and p.value
         gpu.check(lib.nb_free(p))
@@ -91,3 +91,16 @@ def test_cli_shards_lend_nothing_when_one_allocation_is_refused(tmp_path):
     lent = _dump(tmp_path, "lent", "--devices=0,0,0,0", env=env)
     refused = _dump(tmp_path, "refused", "--devices=0,0,0,0", "--alloc-limit-mib=8", env=env)  # (the body arrays are 4 MiB each)
     assert lent.tobytes() != plain.tobytes() and refused.tobytes() == plain.tobytes()
+
+
+@pytest.mark.gpu
+def test_cli_leaves_cleanly_when_the_body_arrays_themselves_are_refused(tmp_path):
+    """The body arrays are the caller's to allocate; when the device refuses THEM there is nothing to fall back to: std::bad_alloc,
+    exit code 3 as in the reference's main (nbody.cpp:396-408) -- for the sharded system too, whose constructor has by then made its
+    communicators and streams and must take them down again (BodySystemHIPSharded::allocate), not hang or abort in their destructors."""
+    from test_comm_fake_rccl import _env
+
+    for flags, env in ((("--numbodies=262144",), None), (("--numbodies=262144", "--devices=0,0,0,0"), _env())):
+        r = subprocess.run([CLI, *flags, "--steps=1", "--alloc-limit-mib=2", f"--dump={tmp_path / 'never.bin'}"], capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode == 3, (flags, r.returncode, r.stdout[-800:], r.stderr[-1500:])
+        assert not (tmp_path / "never.bin").exists()

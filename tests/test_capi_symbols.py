@@ -581,3 +581,14 @@ def test_pair_plan_fills_whole_rounds_at_any_body_count(pkg):
             if n >= 200000:
                 assert p.bodies_per_lane // W == 8, (n, p.bodies_per_lane)  # large systems: sixteen (eight) bodies i per lane
     assert worst["float32"] >= 0.88 and worst["float64"] >= 0.88
+
+
+def test_python_mirror_constants_are_the_headers(pkg):
+    """Every `#define NB_<NAME> <integer>` of include/nbody_hip.h that the Python mirror names has the header's value."""
+    text = open(os.path.join(ROOT, "include", "nbody_hip.h")).read()
+    defines = {m.group(1): int(m.group(2), 0) for m in re.finditer(r"^#define\s+(NB_[A-Z0-9_]+)\s+(-?(?:0x[0-9a-fA-F]+|\d+))u?\b", text, re.M)}
+    defines.update({m.group(1): int(m.group(2), 0) for m in re.finditer(r"^\s*(NB_[A-Z0-9_]+)\s*=\s*(-?(?:0x[0-9a-fA-F]+|\d+))u?\s*,?\s*(?:/\*.*)?$", text, re.M)})  # enumerators
+    shared = {name: value for name, value in defines.items() if hasattr(pkg, name)}
+    assert {"NB_ERR_INVALID_ARGUMENT", "NB_ERR_UNSUPPORTED", "NB_ERR_RCCL_BASE", "NB_ERR_OUT_OF_MEMORY", "NB_MODE_FAST", "NB_MODE_STRICT"} <= set(shared), sorted(shared)
+    for name, value in shared.items():
+        assert getattr(pkg, name) == value, (name, getattr(pkg, name), value)
