@@ -367,7 +367,10 @@ int nb_alloc(void** device_ptr, size_t bytes) {
     const auto err = hipMalloc(device_ptr, bytes);
     // The caller gets the status; the thread's "last error" is cleared, so that the fall-backs built on a refused allocation
     // (halve the workspace and try again, step without one) do not see it again as the status of their next launch.
-    if (err != hipSuccess) (void)hipGetLastError();
+    if (err != hipSuccess) {
+        (void)hipGetLastError();
+        *device_ptr = nullptr;
+    }
     return static_cast<int>(err);
 }
 int nb_free(void* device_ptr) {
