@@ -361,6 +361,13 @@ def test_config4_shape_eight_ranks_at_one_mi_bodies(tmp_path, oracle):
     np.testing.assert_allclose(got["pos_0"], got["single_pos"], rtol=0, atol=5e-5)
     vel = np.concatenate([got[f"vel_{k}"] for k in range(world)])
     np.testing.assert_allclose(vel, got["single_vel"], rtol=0, atol=1e-2)
+    # round 5: the same step as an in-process world over the REAL RCCL (2 MiB position tiles, 1.5 MiB reaction arrays; slices of
+    # 131 072 bodies: the diagonal is one launch at this size) -- the very bits of the double, on every rank
+    real = _run(tmp_path, "all", pos0, vel0, world, 1, "fast", workspace=True, real_rccl=True)
+    assert list(real["layout"]) == [1] * world
+    for k in range(world):
+        assert real[f"pos_{k}"].tobytes() == got["pos_0"].tobytes()
+    assert np.concatenate([real[f"vel_{k}"] for k in range(world)]).tobytes() == vel.tobytes()
 
 
 @pytest.mark.gpu
