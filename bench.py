@@ -109,7 +109,8 @@ def self_launch(n_ranks: int, explicit_exchange: bool, attempt_s: float, budget_
     as a whole gets `budget_s`; an attempt gets `attempt_s` of it at most, and is ended early when no rank has reported its
     exchange up (BRINGUP_MARK on stderr) `bringup_s` after the first rank imported torch (IMPORTED_MARK; `import_s` at the
     latest after the start) -- a run that will finish has printed that line within seconds, one that sits in a rendezvous or in
-    RCCL's bring-up never does.  `make_cmd(extra_flags, port) -> argv`: the command of an attempt (tests pass stand-in ranks)."""
+    RCCL's bring-up never does.  An attempt's own time counts from that import mark too; once its line is out, an attempt may use
+    what is left of the whole budget (the diagnostics run after the line).  `make_cmd(extra_flags, port) -> argv`: the command of an attempt (tests pass stand-in ranks)."""
     import signal
     import socket
     import subprocess
@@ -173,12 +174,18 @@ def self_launch(n_ranks: int, explicit_exchange: bool, attempt_s: float, budget_
                 rc = child.wait(timeout=0.5)
             except subprocess.TimeoutExpired:
                 now = time.monotonic()
-                if now - begun > limit:
+                # an attempt's time counts from the first rank's import mark (a fresh box pages torch in for a minute or two: not the
+                # run's fault), from `import_s` after its start at the latest
+                imported = seen["imported_at"]
+                ran = now - (imported if imported is not None else begun + import_s)
+                if seen["metric"]:
+                    # the line is out: what follows (diagnostics, tear-down) may take what is left of the whole budget, no more
+                    if now - started > budget_s:
+                        rc = end_group(child, f"the line is out and the launcher's budget of {budget_s:.0f} s is spent")
+                elif ran > limit:
                     rc = end_group(child, f"ranks still running after {limit:.0f} s")
-                elif not seen["up"] and not seen["metric"]:
-                    clock = seen["imported_at"] if seen["imported_at"] is not None else begun + import_s - bringup_s
-                    if now - clock > bringup_s:
-                        rc = end_group(child, f"no rank has its exchange up {now - begun:.0f} s after the start")
+                elif not seen["up"] and (ran > bringup_s or (imported is None and ran > 0)):  # (no rank even imported torch in `import_s`)
+                    rc = end_group(child, f"no rank has its exchange up {now - begun:.0f} s after the start")
         for r in readers:
             r.join(timeout=10)
         return rc, seen["metric"]

@@ -77,6 +77,30 @@ def test_launcher_ends_hung_attempts_inside_its_budget(tmp_path):
     assert took < 40, took  # 2-3 s (no bring-up) + 8 s (hung after bring-up) + the attempt that reports: well inside the 60 s budget
 
 
+def test_launcher_does_not_charge_a_slow_import_to_the_attempt(tmp_path):
+    """A fresh box pages torch in for a minute or two.  An attempt's limit counts from the first rank's import mark, and once the line
+    is out the attempt may finish its diagnostics inside what is left of the whole budget: a healthy run that imports for longer than
+    `attempt_s` and keeps working after its line is relayed whole and returns 0, without a retry."""
+    rank = tmp_path / "stand_in_rank.py"
+    rank.write_text(
+        "import sys, time\n"
+        "time.sleep(6)\n"
+        "print('[bench rank 0] torch imported', file=sys.stderr, flush=True)\n"
+        "print('[bench rank 0] up: exchange rccl', file=sys.stderr, flush=True)\n"
+        "time.sleep(2)\n"
+        "print('{\"metric\": \"stand-in\"}', flush=True)\n"
+        "time.sleep(5)\n"
+        "print('[bench rank 0] diagnostics done', file=sys.stderr, flush=True)\n")
+    driver = tmp_path / "driver.py"
+    driver.write_text(
+        f"import sys\nsys.path.insert(0, {ROOT!r})\nimport bench\n"
+        f"rc = bench.self_launch(2, False, attempt_s=4.0, budget_s=60.0, bringup_s=2.0, import_s=20.0, make_cmd=lambda extra, port: [sys.executable, {str(rank)!r}] + extra)\n"
+        f"print('LAUNCHER', rc, flush=True)\n")
+    out = subprocess.run([sys.executable, str(driver)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "LAUNCHER 0" in out.stdout and out.stdout.count('"metric"') == 1, (out.stdout, out.stderr[-2000:])
+    assert "diagnostics done" in out.stderr and "ending process group" not in out.stderr and "one more attempt" not in out.stderr
+
+
 def test_launcher_stops_when_its_budget_is_spent(tmp_path):
     """Every attempt hangs after bring-up: the launcher shares what is left of the budget among the attempts that may follow, ends
     each, and returns a failure INSIDE the budget instead of running into the caller's own limit."""
