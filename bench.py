@@ -78,6 +78,9 @@ def parse_args():
                     help="plain `bench.py --gpus N`: seconds the launcher gives ONE attempt of the N ranks before ending them (see self_launch)")
     ap.add_argument("--launch-budget", type=float, default=560.0,
                     help="plain `bench.py --gpus N`: seconds for the whole command -- the first attempt and up to three plainer exchanges (under the driver's 600 s)")
+    ap.add_argument("--rccl-init-timeout", type=float, default=90.0,
+                    help="N>1, --exchange rccl: seconds a rank gives nb_comm_init_rank (ncclCommInitRank) before it calls it hung; ALL ranks then take "
+                         "the RCCL-free exchange (gloo through host memory, 'exchange_fallback': true) instead of waiting for the headline watchdog")
     ap.add_argument("--bringup-timeout", type=float, default=60.0,
                     help="plain `bench.py --gpus N`: an attempt is ended when no rank has its exchange up this long after the first rank imported torch")
     ap.add_argument("--headline-timeout", type=float, default=240.0,
@@ -373,7 +376,7 @@ def main():
             enter("C-ABI communicator bring-up (nb_comm_unique_id / nb_comm_init_rank / nb_comm_set_workspace / first exchange)")
             bufs = [pos_t, pos_t.clone()]
             acc_t = torch.zeros_like(pos_t)
-            problem = None
+            problem, init_hung = None, False
             try:
                 ids = [pkg.comm_unique_id() if (rank == 0 and world > 1) else None]
             except pkg.NBodyHipError as exc:
@@ -382,10 +385,33 @@ def main():
             if world > 1 and ids[0] is None:
                 problem = problem or RuntimeError("rank 0 could not create the RCCL unique id")
             else:
-                try:
-                    capi_rank = pkg.ShardedRank(ids[0], world, rank, [b.data_ptr() for b in bufs], vel_t.data_ptr(), acc_t.data_ptr(), n, dtype, mode, 256, stream_ptr)
-                except pkg.NBodyHipError as exc:
-                    problem = exc
+                # ncclCommInitRank is the one call of the bring-up that can wait for a peer for ever with nothing on the GPU yet, so it
+                # runs in a thread of its own with a limit: a rank whose call has not returned says so, and ALL ranks then take the
+                # RCCL-free exchange below (the stuck thread is left behind; whatever it may still make is never used)
+                made = {}
+
+                def init_rank():
+                    try:
+                        pkg.check(lib.nb_set_device(local_rank), "nb_set_device")  # (HIP's current device is per thread)
+                        made["rank"] = pkg.ShardedRank(ids[0], world, rank, [b.data_ptr() for b in bufs], vel_t.data_ptr(), acc_t.data_ptr(), n, dtype, mode, 256, stream_ptr)
+                    except pkg.NBodyHipError as exc:
+                        made["problem"] = exc
+
+                worker = threading.Thread(target=init_rank, daemon=True)
+                worker.start()
+                worker.join(args.rccl_init_timeout if world > 1 else None)
+                if worker.is_alive():
+                    init_hung = True
+                    problem = TimeoutError(f"nb_comm_init_rank has not returned after {args.rccl_init_timeout:.0f} s")
+                else:
+                    capi_rank, problem = made.get("rank"), made.get("problem")
+            if world > 1 and not everyone(not init_hung):  # (collective: a hang on ANY rank sends every rank the RCCL-free way)
+                if capi_rank is not None:  # (this rank's call did return: its communicator goes, in a thread -- the peers' may never answer)
+                    threading.Thread(target=capi_rank.destroy, daemon=True).start()
+                print(f"[bench rank {rank}] RCCL's bring-up hung on some rank ({problem!r} on this one); ALL ranks fall back to the exchange without RCCL (gloo through host memory)",
+                      file=sys.stderr, flush=True)
+                capi_rank, exchange_fallback, pairwise, init_hung = None, True, False, True
+                args.exchange = "staged"
             if capi_rank is not None and world > 1 and problem is None:
                 # Never step on the null stream (torch's current stream) next to RCCL: a rank that computes there -- or on a stream
                 # that shares its hardware queue, one created stream in three -- steps ~40 % slower (measured with the real RCCL,
@@ -396,7 +422,7 @@ def main():
                     stream_ptr = own_stream
                 except pkg.NBodyHipError as exc:
                     problem = exc
-            if everyone(problem is None):
+            if not init_hung and everyone(problem is None):
                 # The communicator is up on every rank.  Lend it the workspace: with several ranks nb_comm_set_workspace is a
                 # COLLECTIVE (every rank calls it, with nothing if it has nothing), after which the layout of a step -- pairwise
                 # across the ranks or one-sided tiles -- is the communicator's, the same on every rank.
@@ -420,7 +446,7 @@ def main():
                     torch.cuda.synchronize()
                 except pkg.NBodyHipError as exc:
                     problem = exc
-            if not everyone(problem is None):
+            if not init_hung and not everyone(problem is None):
                 print(f"[bench rank {rank}] the C-ABI RCCL path could not be brought up ({problem!r} on this rank); "
                       "ALL ranks fall back to the tile schedule over torch.distributed", file=sys.stderr, flush=True)
                 if capi_rank is not None:

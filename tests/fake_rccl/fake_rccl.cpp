@@ -385,6 +385,11 @@ FAKE_API int ncclGetUniqueId(ncclUniqueId* id) {
 
 FAKE_API int ncclCommInitRank(ncclComm_t* comm, int nranks, ncclUniqueId id, int rank) {
     if (comm == nullptr || nranks < 1 || rank < 0 || rank >= nranks) return kInvalidArgument;
+    // FAKE_RCCL_HANG_INIT=<rank> | all: this call never returns on that rank (a bootstrap that waits for a peer for ever) -- what
+    // bench.py's bounded bring-up is tested against
+    if (const char* hang = std::getenv("FAKE_RCCL_HANG_INIT"); hang != nullptr && hang[0] != 0 && (std::strcmp(hang, "all") == 0 || std::atoi(hang) == rank)) {
+        for (;;) sleep(3600);
+    }
     if (id.internal[16] == 'I' && std::memcmp(id.internal, "FAKERCCL", 8) == 0) {  // one process per rank: no shared World
         auto* c = new ncclComm;
         c->ipc = true, c->size = nranks, c->rank = rank;

@@ -10,10 +10,11 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run_bench(*flags, timeout=600):
+def run_bench(*flags, timeout=600, extra_env=None):
     env = dict(os.environ)
     for name in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(name, None)
+    env.update(extra_env or {})
     return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *flags], capture_output=True, text=True, env=env, timeout=timeout)
 
 
@@ -334,3 +335,18 @@ def test_line_takes_counters_only_from_a_profile_of_the_same_launch_plan(pkg):
     assert "strict" in strict["source"] and strict["valu_busy"] > 0.9
     one_sided = plan_dict(pkg, 262144, np.float32, "one-sided")
     assert one_sided == {"bodies_per_lane": 4, "lane_groups": 8, "lds_tile_bodies": 2048, "grid": 1024, "lds_bytes": one_sided["lds_bytes"]}
+
+
+@pytest.mark.gpu
+def test_a_hung_rccl_bring_up_ends_in_a_line_without_rccl():
+    """Under the driver's own launch (torch.distributed.run, no launcher of ours around it) a rank that never comes back from
+    ncclCommInitRank used to end the job with the headline watchdog's status 5 and no line.  nb_comm_init_rank runs in a thread with a
+    limit (--rccl-init-timeout): here rank 1's call never returns (the double's FAKE_RCCL_HANG_INIT), rank 0's does; the ranks decide
+    TOGETHER, and all of them step with the exchange that needs no RCCL at all -- a line marked exchange_fallback, never a hang."""
+    out = run_bench("--gpus", "2", "--rehearse-one-gpu", "--steps", "3", "--warmup", "1", "--bodies", "16384", "--no-cpu-baseline", "--rccl-init-timeout", "5",
+                    extra_env={"FAKE_RCCL_HANG_INIT": "1"}, timeout=300)
+    assert out.returncode == 0, out.stderr[-4000:]
+    line = _metric_line(out.stdout)
+    assert line["n_gpus"] == 2 and line["exchange_fallback"] is True and line["value"] > 0
+    assert "RCCL's bring-up hung on some rank" in out.stderr and "nb_comm_init_rank has not returned after 5 s" in out.stderr
+    assert line["config"]["step_entry_point"] != "nb_sharded_step_*" and "gloo" in line["config"]["exchange"].lower()
