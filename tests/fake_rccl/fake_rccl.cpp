@@ -452,6 +452,11 @@ FAKE_API int ncclGroupEnd() {
     if (t_group_depth <= 0) return kInvalidUsage;
     if (--t_group_depth > 0) return kSuccess;
     g_groups.fetch_add(1);
+    // FAKE_RCCL_HANG_GROUP_END=<rank>: the process whose RANK (torch.distributed.run's) that is never comes back from its first group
+    // -- an exchange that waits for a peer for ever: what bench.py's headline watchdog is tested against
+    if (const char* hang = std::getenv("FAKE_RCCL_HANG_GROUP_END"), *me = std::getenv("RANK"); hang != nullptr && me != nullptr && hang[0] != 0 && std::atoi(hang) == std::atoi(me)) {
+        for (;;) sleep(3600);
+    }
     return post_and_wait(t_group_ops);
 }
 

@@ -350,3 +350,20 @@ def test_a_hung_rccl_bring_up_ends_in_a_line_without_rccl():
     assert line["n_gpus"] == 2 and line["exchange_fallback"] is True and line["value"] > 0
     assert "RCCL's bring-up hung on some rank" in out.stderr and "nb_comm_init_rank has not returned after 5 s" in out.stderr
     assert line["config"]["step_entry_point"] != "nb_sharded_step_*" and "gloo" in line["config"]["exchange"].lower()
+
+
+@pytest.mark.gpu
+def test_a_rank_stuck_in_an_exchange_says_where_and_leaves():
+    """What cannot be fallen back from -- a rank that never returns from an RCCL group once the communicators are up (its peers'
+    kernels would wait on the GPU for ever) -- must at least end, and say where: the headline watchdog (--headline-timeout) names the
+    stage the rank is stuck in and leaves with status 5, so that the job fails inside the caller's limit with its reason on stderr."""
+    import time
+
+    t0 = time.monotonic()
+    out = run_bench("--gpus", "2", "--rehearse-one-gpu", "--steps", "3", "--warmup", "1", "--bodies", "16384", "--no-cpu-baseline", "--headline-timeout", "12",
+                    extra_env={"FAKE_RCCL_HANG_GROUP_END": "1", "FAKE_RCCL_TIMEOUT_S": "100"}, timeout=300)
+    took = time.monotonic() - t0
+    assert out.returncode != 0 and '"metric"' not in out.stdout, out.stdout[-2000:]
+    assert "no headline after 12 s: stuck in 'C-ABI communicator bring-up" in out.stderr and "leaving with status 5" in out.stderr, out.stderr[-3000:]
+    assert took < 90, took
+
