@@ -726,13 +726,16 @@ def main():
             print(json.dumps(line), flush=True)
 
     if world > 1:
+        print(f"[bench rank {rank}] headline timed: post-headline measurements start", file=sys.stderr, flush=True)
+
         def stalled():
             emit({"diagnostics_incomplete": f"the post-headline measurements did not finish within {args.diagnostics_timeout:.0f} s"})
             sys.stderr.write(f"[bench rank {rank}] post-headline measurements stalled: leaving\n")
             sys.stderr.flush()
-            os._exit(0 if rank == 0 else 3)
+            os._exit(0)  # (the headline is valid and, on rank 0, out: not a failure of the job)
 
-        watchdog = threading.Timer(args.diagnostics_timeout, stalled)
+        # rank 0 first: a launcher that sees another rank leave may end the ones that are left -- the line must be out by then
+        watchdog = threading.Timer(args.diagnostics_timeout + (0.0 if rank == 0 else 5.0), stalled)
         watchdog.daemon = True
         watchdog.start()
         extra = {}

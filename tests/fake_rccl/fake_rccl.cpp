@@ -457,6 +457,10 @@ FAKE_API int ncclGroupEnd() {
     if (const char* hang = std::getenv("FAKE_RCCL_HANG_GROUP_END"), *me = std::getenv("RANK"); hang != nullptr && me != nullptr && hang[0] != 0 && std::atoi(hang) == std::atoi(me)) {
         for (;;) sleep(3600);
     }
+    // FAKE_RCCL_HANG_WHEN_EXISTS=<path>: ... from the moment that file exists (a test makes it when the run has reached the stage to hang in)
+    if (const char* path = std::getenv("FAKE_RCCL_HANG_WHEN_EXISTS"); path != nullptr && path[0] != 0 && access(path, F_OK) == 0) {
+        for (;;) sleep(3600);
+    }
     return post_and_wait(t_group_ops);
 }
 

@@ -367,3 +367,42 @@ def test_a_rank_stuck_in_an_exchange_says_where_and_leaves():
     assert "no headline after 12 s: stuck in 'C-ABI communicator bring-up" in out.stderr and "leaving with status 5" in out.stderr, out.stderr[-3000:]
     assert took < 90, took
 
+
+@pytest.mark.gpu
+def test_stalled_diagnostics_never_cost_the_headline(tmp_path):
+    """Everything after the timed region of an N > 1 run is collective work under a watchdog (--diagnostics-timeout): when it stalls --
+    here every RCCL group hangs from the moment the ranks say the headline is timed -- rank 0 prints the line with what it has
+    ("diagnostics_incomplete"), first, and every rank leaves with status 0: the measured headline is never lost to what explains it."""
+    import threading
+
+    env = dict(os.environ)
+    for name in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(name, None)
+    trigger = tmp_path / "hang_now"
+    env.update({"FAKE_RCCL_HANG_WHEN_EXISTS": str(trigger), "FAKE_RCCL_TIMEOUT_S": "100"})
+    child = subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse-one-gpu", "--steps", "3", "--warmup", "1", "--bodies", "16384", "--no-cpu-baseline",
+                              "--diagnostics-timeout", "10"], stdout=open(tmp_path / "out.txt", "w"), stderr=subprocess.PIPE, text=True, env=env)
+    err = []
+
+    def watch():
+        for text in child.stderr:
+            err.append(text)
+            if "post-headline measurements start" in text and not trigger.exists():
+                trigger.write_text("now\n")
+
+    watcher = threading.Thread(target=watch, daemon=True)
+    watcher.start()
+    try:
+        child.wait(timeout=240)
+    except subprocess.TimeoutExpired:
+        child.kill()
+        raise
+    watcher.join(timeout=10)
+    out = (tmp_path / "out.txt").read_text()
+    stderr = "".join(err)
+    assert child.returncode == 0, stderr[-3000:]
+    line = _metric_line(out)
+    assert line["n_gpus"] == 2 and line["value"] > 0 and line["exchange_fallback"] is False
+    assert "did not finish within 10 s" in line["diagnostics_incomplete"] and "diagnostics" not in line
+    assert stderr.count("post-headline measurements stalled: leaving") == 2
+
