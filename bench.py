@@ -769,6 +769,17 @@ def main():
     else:
         emit()
 
+    if world > 1:
+        # the line is out; taking the communicators down is collective work too (ncclCommDestroy, gloo's tear-down): a rank that does not
+        # come back from it leaves after 30 s with status 0 rather than keep the whole job until the caller's limit
+        def leave():
+            sys.stderr.write(f"[bench rank {rank}] tear-down did not finish within 30 s: leaving\n")
+            sys.stderr.flush()
+            os._exit(0)
+
+        last = threading.Timer(30.0, leave)
+        last.daemon = True
+        last.start()
     if capi_rank is not None:
         torch.cuda.synchronize()
         capi_rank.destroy()
