@@ -360,11 +360,11 @@ def test_a_rank_stuck_in_an_exchange_says_where_and_leaves():
     import time
 
     t0 = time.monotonic()
-    out = run_bench("--gpus", "2", "--rehearse-one-gpu", "--steps", "3", "--warmup", "1", "--bodies", "16384", "--no-cpu-baseline", "--headline-timeout", "12",
+    out = run_bench("--gpus", "2", "--rehearse-one-gpu", "--steps", "3", "--warmup", "1", "--bodies", "16384", "--no-cpu-baseline", "--headline-timeout", "8",
                     extra_env={"FAKE_RCCL_HANG_GROUP_END": "1", "FAKE_RCCL_TIMEOUT_S": "100"}, timeout=300)
     took = time.monotonic() - t0
     assert out.returncode != 0 and '"metric"' not in out.stdout, out.stdout[-2000:]
-    assert "no headline after 12 s: stuck in 'C-ABI communicator bring-up" in out.stderr and "leaving with status 5" in out.stderr, out.stderr[-3000:]
+    assert "no headline after 8 s: stuck in 'C-ABI communicator bring-up" in out.stderr and "leaving with status 5" in out.stderr, out.stderr[-3000:]
     assert took < 90, took
 
 
@@ -381,7 +381,7 @@ def test_stalled_diagnostics_never_cost_the_headline(tmp_path):
     trigger = tmp_path / "hang_now"
     env.update({"FAKE_RCCL_HANG_WHEN_EXISTS": str(trigger), "FAKE_RCCL_TIMEOUT_S": "100"})
     child = subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse-one-gpu", "--steps", "3", "--warmup", "1", "--bodies", "16384", "--no-cpu-baseline",
-                              "--diagnostics-timeout", "10"], stdout=open(tmp_path / "out.txt", "w"), stderr=subprocess.PIPE, text=True, env=env)
+                              "--diagnostics-timeout", "6"], stdout=open(tmp_path / "out.txt", "w"), stderr=subprocess.PIPE, text=True, env=env)
     err = []
 
     def watch():
@@ -403,6 +403,6 @@ def test_stalled_diagnostics_never_cost_the_headline(tmp_path):
     assert child.returncode == 0, stderr[-3000:]
     line = _metric_line(out)
     assert line["n_gpus"] == 2 and line["value"] > 0 and line["exchange_fallback"] is False
-    assert "did not finish within 10 s" in line["diagnostics_incomplete"] and "diagnostics" not in line
+    assert "did not finish within 6 s" in line["diagnostics_incomplete"] and "diagnostics" not in line
     assert stderr.count("post-headline measurements stalled: leaving") == 2
 
