@@ -325,3 +325,55 @@ def test_real_rccl_carries_a_real_step_and_one_gpu_agrees(world, torch_first):
     assert got["strict_bitwise"] and got["strict_every_tile_arrived"]
     for name in ("fast_one_sided", "fast_pairwise"):
         assert got[name + "_every_tile_arrived"] and got[name + "_finite"] and got[name + "_max_err_rel_to_size"] < 5e-6
+
+
+@pytest.mark.gpu
+def test_a_placed_stream_can_be_torchs_current_stream(tmp_path):
+    """bench.py's torch.distributed fall-backs (--exchange torch | allgather) step on a stream from nb_stream_create_placed that is made
+    torch's CURRENT stream (sharded.py orders its kernels against torch's collectives there) -- a path no one-GPU run reaches, so its
+    mechanics are held here: the handle becomes torch.cuda.current_stream(), torch's own kernels and the library's launch on it in
+    order, and the result is the CPU path's, bit for bit."""
+    import subprocess
+    import sys
+
+    script = tmp_path / "placed.py"
+    script.write_text(f"""
+import ctypes, sys
+import numpy as np
+import torch
+sys.path.insert(0, {ROOT!r})
+import __graft_entry__ as entry
+pkg = entry.load_package(); lib = pkg.lib(); oracle = entry.load_oracle().Oracle()
+torch.cuda.set_device(0); pkg.check(lib.nb_set_device(0))
+dev = torch.device("cuda", 0)
+placed = ctypes.c_void_p()
+pkg.check(lib.nb_stream_create_placed(ctypes.byref(placed)), "nb_stream_create_placed")
+assert placed.value
+torch.cuda.synchronize()
+torch.cuda.set_stream(torch.cuda.ExternalStream(placed.value, device=dev))
+assert torch.cuda.current_stream().cuda_stream == placed.value
+n, steps = 2048, 3
+pos0, vel0 = oracle.startup_state(n, np.float32)
+ref_p, ref_v = pos0.copy(), vel0.copy()
+oracle.update(ref_p, ref_v, np.float32(0.016), steps=steps)
+pkg.check(lib.nb_set_softening_sq_f32(np.float32(0.1) * np.float32(0.1)))
+a = torch.from_numpy(pos0.reshape(n, 4)).to(dev)       # (torch's copies and kernels: on the placed stream now)
+b = torch.zeros_like(a) + 7.0
+v = torch.from_numpy(vel0.reshape(n, 4)).to(dev)
+stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+bufs = [a, b]
+for s in range(steps):
+    src, dst = bufs[s % 2], bufs[1 - s % 2]
+    pkg.check(lib.nb_integrate_f32(dst.data_ptr(), src.data_ptr(), v.data_ptr(), np.float32(0.016), np.float32(1.0), n, 256, pkg.NB_MODE_STRICT, stream), "nb_integrate_f32")
+    dst.add_(0.0)                                         # a torch kernel between the library's launches, same stream: ordered
+got = bufs[steps % 2].cpu().numpy().ravel()               # (.cpu() synchronises the current stream)
+assert got.tobytes() == ref_p.tobytes(), "not the CPU path's bits"
+assert v.cpu().numpy().ravel().tobytes() == ref_v.tobytes()
+torch.cuda.synchronize()
+print("PLACED OK")
+""")
+    env = dict(os.environ)
+    for name in ("NBODY_RCCL_LIB", "FAKE_RCCL_IPC"):
+        env.pop(name, None)
+    out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=240, env=env)
+    assert out.returncode == 0 and "PLACED OK" in out.stdout, (out.stdout[-1500:], out.stderr[-3000:])
