@@ -491,7 +491,7 @@ template <typename T> PairShard plan_pair_shard(unsigned num_bodies, int G, int 
     // TWO launches (round 5): the block offsets q = 0 .. q_split-1 first, under which the position tiles arrive, and the rest as
     // the rank's LAST force kernel, under which the last rectangle's reaction sums travel to their owner (the finish kernel of
     // that owner waits for them: with the diagonal whole and first, that hop sat bare at the end of every step).  Whole offsets
-    // per launch keep their reaction slots apart; each launch has its own i-side sums.  nb_comm_set_late_diagonal(comm, 0): one launch.
+    // per launch keep their reaction slots apart; each launch has its own i-side sums.  nb_set_late_diagonal(0) (tuning header): one launch, first.
     {
         const unsigned tiles = static_cast<unsigned>(R) * W, offsets = p.blocks / 2 + 1;
         // ... for slices up to 65 536 bodies: the hop is ~40 us whatever the size, the second launch costs a rank ~0.3 % of its kernel
