@@ -52,6 +52,10 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--settle-seconds", type=float, default=0.3,
+                    help="untimed steps BEFORE the --warmup steps, for about this long: from idle the card needs ~0.2 s under load to reach the clock it then holds "
+                         "(profiles/round4_clock_and_power.txt), and K steps of an N-GPU job can be over in 25 ms.  The count is in the line (settle_steps); "
+                         "0 = none (also with --dump-state: the state after exactly warmup + steps steps)")
     ap.add_argument("--bodies", type=int, default=262144)
     ap.add_argument("--fp64", action="store_true")
     ap.add_argument("--mode", choices=["fast", "strict"], default="fast")
@@ -526,6 +530,30 @@ def main():
     chip = ChipWatch(None if args.no_chip_watch else pci_address(torch, local_rank))
     if distributed:  # (BRINGUP_MARK: what the launcher waits for before it trusts an attempt with its full time)
         print(f"[bench rank {rank}] up: exchange {args.exchange}, {'pairwise across the ranks' if pairwise else 'one-sided'}, {world} rank(s)", file=sys.stderr, flush=True)
+    # From idle the card ramps its clock for ~0.2 s under load (2.10 -> 2.29 GHz measured, profiles/round4_clock_and_power.txt); W warm-up
+    # steps are 48 ms at N = 1 and 6 ms at N = 8, so the K timed steps would measure the ramp, not the integrator.  Untimed steps for
+    # ~settle_seconds come first -- the SAME number on every rank (a step is collective): two steps are timed, the slowest rank's time
+    # decides the count -- and the line says how many ("settle_steps").  Then W warm-up steps and exactly K timed steps, as before.
+    settle_steps = 0
+    if args.settle_seconds > 0 and not args.dump_state:
+        enter("clock settle (untimed steps)")
+        fence()
+        t_probe = time.perf_counter()
+        step()
+        step()
+        finish()
+        torch.cuda.synchronize()
+        probe = torch.tensor([(time.perf_counter() - t_probe) / 2.0], dtype=torch.float64)
+        if distributed:
+            dist.all_reduce(probe, op=dist.ReduceOp.MAX)  # gloo: every rank derives the same count
+        settle_steps = int(min(4000, max(0, round(args.settle_seconds / max(float(probe.item()), 1e-6)))))
+        settle_steps += settle_steps & 1  # (even: the ping-pong ends where it began)
+        for k in range(settle_steps):
+            step()
+            if k % 16 == 15:  # (keep the host a bounded distance ahead)
+                finish()
+                torch.cuda.synchronize()
+        settle_steps += 2
     enter("warm-up steps")
     for _ in range(args.warmup):
         step()
@@ -657,6 +685,7 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
+            "settle_steps": settle_steps,  # untimed steps before the warm-up steps (--settle-seconds: the card's clock ramp from idle)
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
             "scaling": "strong",

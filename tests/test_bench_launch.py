@@ -217,6 +217,8 @@ def test_default_line_carries_every_baseline_config():
             (50000, "f32", "fast", "pairwise"), (100000, "f32", "fast", "pairwise"), (300000, "f32", "fast", "pairwise")} <= got
     assert (262144, "f32", "fast", "pairwise") not in got  # that one IS the headline
     assert line["config"]["step_entry_point"] == "nb_integrate_ws_*" and line["config"]["kernel_plan"]["layout"] == "pairwise"
+    # the protocol: untimed steps for ~0.3 s first (the card's clock ramp from idle; the count is stated), then W warm-up and exactly K timed steps
+    assert line["warmup"] == 1 and line["steps"] == 5 and 10 <= line["settle_steps"] <= 80
     roof = line["roofline"]
     assert roof["executed"]["frac"] < roof["frac"] and roof["executed"]["frac"] < 1
     # the dominant kernel is timed on its own (an event between the two launches of a step); the two kernels add up to the step
