@@ -20,6 +20,11 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NBODY_HIP_LIB", os.path.join(HERE, "libnbody_hip.so"))
+# The lab bench (include/nbody_hip_lab.h: real-RCCL self-test, loopback rank, in-process world, allocation-failure hook) is a second
+# library made of the SAME object files plus csrc/nbody_comm_lab.hip.  A process uses ONE of the two: use_lab() (or NBODY_HIP_LAB=1 in
+# the environment) before the first lib() call makes lib() load libnbody_hip_lab.so instead -- tests/ and tools/ that need the lab
+# do that in a process of their own; the product library never exports the lab's symbols.
+LAB_LIB_PATH = os.environ.get("NBODY_HIP_LAB_LIB", os.path.join(HERE, "libnbody_hip_lab.so"))
 
 NB_MODE_STRICT, NB_MODE_FAST = 0, 1
 NB_SHARD_ACC_IN, NB_SHARD_FINALIZE = 1, 2
@@ -174,35 +179,55 @@ TUNING_SIGNATURES = {
     "nb_comm_reaction_exchange_f64": (_ci, [_vp, _cu, _vp]),
     "nb_set_pair_probe_event": (_ci, [_vp]),
     "nb_set_memory_budget": (_ci, [_sz]),
-    "nb_set_alloc_limit": (_ci, [_sz]),
     "nb_lds_optin_count": (_ci, [_P(_ci)]),
+    "nb_comm_transport_info": (_ci, [_vp, _P(_ci), ctypes.c_char_p, _sz]),
+    "nb_comm_last_step_trace": (_ci, [_vp, ctypes.c_char_p, _sz]),
+    "nb_comm_side_stream_collisions": (_ci, [_vp, _P(_ci)]),
+    "nb_comm_settle_side_stream": (_ci, [_vp, _vp]),
+    "nb_comm_caller_stream_placement": (_ci, [_vp, _P(_ci)]),
+    "nb_comm_pair_work_f32": (_ci, [_vp, _cu, _P(ctypes.c_ulonglong), _P(_ci)]),
+    "nb_comm_pair_work_f64": (_ci, [_vp, _cu, _P(ctypes.c_ulonglong), _P(_ci)]),
+    "nb_comm_last_enqueue_ms": (_ci, [_vp, _P(_cd)]),
+}
+
+# include/nbody_hip_lab.h: exported by libnbody_hip_lab.so only
+LAB_SIGNATURES = {
+    "nb_set_alloc_limit": (_ci, [_sz]),
     "nb_comm_selftest_open": (_ci, [_P(_vp), _vp]),
     "nb_comm_loopback_open": (_ci, [_P(_vp), _vp, _ci, _ci]),
     "nb_comm_inprocess_open_all": (_ci, [_P(_vp), _ci, _vp]),
     "nb_comm_selftest_f32": (_ci, [_vp, _sz, _vp, _P(CommSelftest)]),
     "nb_comm_self_transfer_f32": (_ci, [_vp, _vp, _vp, _sz, _ci, _ci, _vp, _vp, _vp]),
-    "nb_comm_transport_info": (_ci, [_vp, _P(_ci), ctypes.c_char_p, _sz]),
-    "nb_comm_last_step_trace": (_ci, [_vp, ctypes.c_char_p, _sz]),
-    "nb_comm_side_stream_collisions": (_ci, [_vp, _P(_ci)]),
-    "nb_comm_settle_side_stream": (_ci, [_vp, _vp]),
     "nb_comm_replace_side_stream": (_ci, [_vp]),
-    "nb_comm_caller_stream_placement": (_ci, [_vp, _P(_ci)]),
-    "nb_comm_pair_work_f32": (_ci, [_vp, _cu, _P(ctypes.c_ulonglong), _P(_ci)]),
-    "nb_comm_pair_work_f64": (_ci, [_vp, _cu, _P(ctypes.c_ulonglong), _P(_ci)]),
 }
 
 _lib = None
+_lab = os.environ.get("NBODY_HIP_LAB") == "1"
+
+
+def use_lab() -> None:
+    """This process works with the lab library (libnbody_hip_lab.so: everything libnbody_hip.so exports + include/nbody_hip_lab.h).
+    Must come before the first lib() call: communicators, streams and the process-global settings belong to ONE loaded library."""
+    global _lab
+    if _lib is not None and not _lab:
+        raise RuntimeError("use_lab() after libnbody_hip.so was loaded: a process uses one of the two libraries (set NBODY_HIP_LAB=1 or call it first)")
+    _lab = True
+
+
+def is_lab() -> bool:
+    return _lab
 
 
 def lib() -> ctypes.CDLL:
-    """Load libnbody_hip.so (fails loudly when the HIP extension has not been built)."""
+    """Load libnbody_hip.so -- or, after use_lab(), libnbody_hip_lab.so (fails loudly when the HIP extension has not been built)."""
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise FileNotFoundError(f"{LIB_PATH} not found: build it with `make -C {os.path.join(HERE, 'csrc')}` "
+        path = LAB_LIB_PATH if _lab else LIB_PATH
+        if not os.path.exists(path):
+            raise FileNotFoundError(f"{path} not found: build it with `make -C {os.path.join(HERE, 'csrc')}` "
                                     "(or __graft_entry__.build()); there is no CPU fallback")
-        handle = ctypes.CDLL(LIB_PATH)
-        for name, (restype, argtypes) in {**SIGNATURES, **TUNING_SIGNATURES}.items():
+        handle = ctypes.CDLL(path)
+        for name, (restype, argtypes) in {**SIGNATURES, **TUNING_SIGNATURES, **(LAB_SIGNATURES if _lab else {})}.items():
             fn = getattr(handle, name)  # AttributeError if the symbol is not exported
             fn.restype, fn.argtypes = restype, argtypes
         _lib = handle

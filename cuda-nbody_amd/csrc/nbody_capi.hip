@@ -36,7 +36,6 @@ std::atomic<int>   g_pair_slices{0};                                    // nb_se
 // without ever being the call that triggers a lazy initialisation.
 std::atomic<size_t> g_total_memory[64] = {};  // per device, filled by the one-time warm-up below (0: unknown)
 std::atomic<size_t> g_memory_budget{0};       // nb_set_memory_budget: what to assume instead (0: the device's own figure)
-std::atomic<size_t> g_alloc_limit{0};         // nb_set_alloc_limit: nb_alloc requests above this are made to fail IN THE RUNTIME (0: none)
 static_assert(NB_ERR_OUT_OF_MEMORY == hipErrorOutOfMemory, "the header names the runtime's own value");
 
 int current_device_ready() {
@@ -298,6 +297,10 @@ size_t device_memory_budget() {
     return g_total_memory[dev].load();
 }
 hipEvent_t pair_probe_event() { return static_cast<hipEvent_t>(g_pair_probe.load(std::memory_order_relaxed)); }
+std::atomic<size_t>& alloc_limit() {  // nb_alloc requests above this are made to fail IN THE RUNTIME (0: none); only the lab library has a setter
+    static std::atomic<size_t> limit{0};
+    return limit;
+}
 void pair_plan_overrides(int* vectors_per_lane, int* waves, int* splits) {
     *vectors_per_lane = g_pair_r.load(), *waves = g_pair_s.load(), *splits = g_pair_c.load();
 }
@@ -363,7 +366,7 @@ int nb_alloc(void** device_ptr, size_t bytes) {
     (void)current_device_ready();
     // (tests of the out-of-memory fall-backs: a request above the limit is turned into one the runtime itself refuses, so that what
     // follows -- the status, the thread's last error -- is exactly what a real refusal leaves behind)
-    if (const size_t limit = g_alloc_limit.load(); limit != 0 && bytes > limit) bytes = ~size_t{0} >> 4;
+    if (const size_t limit = nb::alloc_limit().load(); limit != 0 && bytes > limit) bytes = ~size_t{0} >> 4;
     const auto err = hipMalloc(device_ptr, bytes);
     // The caller gets the status; the thread's "last error" is cleared, so that the fall-backs built on a refused allocation
     // (halve the workspace and try again, step without one) do not see it again as the status of their next launch.
@@ -552,10 +555,6 @@ int nb_set_memory_budget(size_t bytes) {
     return 0;
 }
 
-int nb_set_alloc_limit(size_t bytes) {
-    g_alloc_limit.store(bytes);
-    return 0;
-}
 
 int nb_set_pair_probe_event(nb_event_t event) {
     g_pair_probe.store(event);

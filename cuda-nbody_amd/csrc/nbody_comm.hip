@@ -29,9 +29,8 @@
 #include "../../include/nbody_hip.h"
 #include "../../include/nbody_hip_tuning.h"
 
-#include "nbody_kernels.h"
+#include "nbody_comm_internal.h"
 #include "rand_stream_guard.h"
-#include "rccl_api.h"
 
 #include <hip/hip_runtime.h>
 
@@ -39,37 +38,18 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
+#include <condition_variable>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
-namespace {
-
-// ---- the few RCCL entry points used, resolved at run time: their types live in rccl_api.h, which `make check-rccl-abi` holds
-// against /opt/rocm/include/rccl/rccl.h at compile time ----------------------------------------------------------------------
-using ncclComm_t   = nb_rccl::Comm;
-using ncclUniqueId = nb_rccl::UniqueId;
-static_assert(sizeof(ncclUniqueId) == NB_COMM_ID_BYTES, "nb_comm_unique_id hands out exactly one ncclUniqueId");
-enum { ncclFloat32 = nb_rccl::kFloat32, ncclFloat64 = nb_rccl::kFloat64 };
-
-struct Rccl {
-    void*       handle = nullptr;
-    std::string path;  // the file the entry points were bound from (dladdr), for the record
-    nb_rccl::GetVersionFn     GetVersion     = nullptr;  // (optional: only reported)
-    nb_rccl::GetUniqueIdFn    GetUniqueId    = nullptr;
-    nb_rccl::CommInitRankFn   CommInitRank   = nullptr;
-    nb_rccl::CommInitAllFn    CommInitAll    = nullptr;
-    nb_rccl::CommDestroyFn    CommDestroy    = nullptr;
-    nb_rccl::SendFn           Send           = nullptr;
-    nb_rccl::RecvFn           Recv           = nullptr;
-    nb_rccl::AllGatherFn      AllGather      = nullptr;
-    nb_rccl::GroupStartFn     GroupStart     = nullptr;
-    nb_rccl::GroupEndFn       GroupEnd       = nullptr;
-    nb_rccl::GetErrorStringFn GetErrorString = nullptr;
-};
+namespace nbc {
 
 Rccl* rccl() {
     static Rccl           lib;
@@ -115,70 +95,10 @@ Rccl* rccl() {
     return lib.handle != nullptr ? &lib : nullptr;
 }
 
-// ---- one local rank ------------------------------------------------------------------------------------------------------
-struct Comm {
-    ncclComm_t  nccl   = nullptr;
-    int         rank   = 0;
-    int         world  = 1;
-    int         device = 0;
-    hipStream_t stream = nullptr;          // the exchange runs here (high priority: its few workgroups must not queue behind a force kernel)
-    hipEvent_t  ready  = nullptr;          // "what the exchange has to wait for has been enqueued" (recorded on the compute stream)
-    std::vector<hipEvent_t> arrived;       // [world]: arrived[p] = the round that brings rank p's tile is done
-    const void* in_flight = nullptr;       // the array whose tiles are (or were last) being exchanged
-    void*       workspace = nullptr;       // caller-owned scratch memory (nb_comm_set_workspace)
-    size_t      workspace_bytes = 0;
-    size_t      agreed_bytes    = 0;       // one process per rank: the SMALLEST amount any rank of the communicator was lent (set_workspace's exchange)
-    size_t      agreed_budget   = 0;       // ... and the smallest device memory budget of any rank (0 until that exchange: this rank's own)
-    bool        one_group       = false;   // nb_comm_set_exchange_grouping: all G-1 position rounds of a step in one RCCL group (default: a group per round)
-    unsigned long long* notes   = nullptr; // [world][kNoteWords] device memory of the communicator: what set_workspace's ranks tell each other
-    hipStream_t aux       = nullptr;       // pairwise step: every other rectangle runs here, so that the tails and launch gaps of
-    hipEvent_t  aux_begin = nullptr;       // one stream's kernels are filled by the other's (events: aux may start / aux is done)
-    hipEvent_t  aux_done  = nullptr;
-    hipStream_t aux_settled_beside = nullptr;  // the caller's stream `aux` was last probed against (settle_side_stream); aux_probed: whether it ever was
-    bool        aux_probed = false;
-    int         aux_collisions = 0;        // how many candidates shared a hardware queue with the caller's stream (nb_comm_transport_info reports it)
-    std::vector<hipStream_t> aux_retired;  // ... kept until the communicator goes
-    hipStream_t caller_last = nullptr;     // the caller's stream last looked at, whether it was, and the verdict (note_caller_stream)
-    bool        caller_checked = false, caller_bad = false;
-    std::vector<hipEvent_t> react_ready;   // [world/2 + 1] pairwise step: "the reaction sums for partner s are in the send buffer" (compute stream)
-    std::vector<hipEvent_t> react_arrived; // [world/2 + 1] ... "round s of the reaction exchange is done" (exchange stream)
-    std::vector<Comm*> group;              // all local ranks of this communicator (just {this} with one process per GPU)
-    std::string trace;                     // what the rank's last pairwise step enqueued, in host order (nb_comm_last_step_trace: tests read the order)
-    bool        inprocess = false;         // nb_comm_inprocess_open_all (tuning header): all G ranks live in this process on ONE device and share one real
-    bool        owns_stream = true;        // one-rank ncclComm and one exchange stream; a send of rank a is routed to the receive of rank b by the ORDER of the
-    std::shared_ptr<void> shared_nccl;     // self-transfers (RCCL matches sends and receives of one peer first in, first out)
-    std::shared_ptr<void> shared_stream;   // ... both go with the LAST rank of that world to be destroyed, in whatever order the ranks are
-    bool        loopback = false;          // nb_comm_loopback_open (tuning header): rank / world are NOMINAL, the ncclComm has one rank and every peer is this rank itself
-};
-
-// the RCCL rank behind rank `logical` of the communicator (a loopback rank sends to, and receives from, itself)
-inline int peer_of(const Comm* c, int logical) { return c->loopback ? 0 : logical; }
-
-constexpr int kNoteWords = 8;  // {workspace bytes, min slice, pair plan overrides R S C, device memory budget, late diagonal, spare}
-
 bool default_one_group() {  // NBODY_EXCHANGE_ONE_GROUP=1 flips the default of nb_comm_set_exchange_grouping (a group per round since round 5)
     const char* v = std::getenv("NBODY_EXCHANGE_ONE_GROUP");
     return v != nullptr && v[0] == '1';
 }
-
-inline Comm* as_comm(nb_comm_t c) { return static_cast<Comm*>(c); }
-inline int   nccl_status(int r) { return r == 0 ? 0 : NB_ERR_RCCL_BASE + r; }
-
-class DeviceScope {  // switch device for a few calls, restore on exit (single-process multi-GPU)
- public:
-    explicit DeviceScope(int device) {
-        (void)hipGetDevice(&saved_);
-        if (saved_ != device) (void)hipSetDevice(device);
-    }
-    ~DeviceScope() {
-        int now = 0;
-        (void)hipGetDevice(&now);
-        if (now != saved_) (void)hipSetDevice(saved_);
-    }
-
- private:
-    int saved_ = 0;
-};
 
 // ---- the second compute stream of a pairwise step (every other rectangle runs there, next to the caller's stream) ----------------
 // The HIP runtime maps the streams of one priority onto a small pool of hardware queues (four by default, GPU_MAX_HW_QUEUES) and
@@ -245,19 +165,33 @@ bool streams_run_side_by_side(hipStream_t a, hipStream_t b) {
     return side_by_side;
 }
 
-// `side` runs next to `beside` from now on: make sure it can (see above).  `retired`: streams that collided, destroyed with their owner.
-// NBODY_AUX_PROBE=0 switches the probe off (for A/B timings of the collision itself).
-hipError_t settle_side_stream(hipStream_t* side, hipStream_t beside, std::vector<hipStream_t>* retired, int* collisions) {
+bool stream_is_capturing(hipStream_t s) {
+    if (s == nullptr) return false;  // (the null stream cannot capture)
+    hipStreamCaptureStatus status = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &status) != hipSuccess) {
+        (void)hipGetLastError();
+        return true;  // (cannot tell: behave as if it were -- no probe, no synchronisation)
+    }
+    return status != hipStreamCaptureStatusNone;
+}
+
+// NBODY_AUX_PROBE=0 switches every probe of this file off (for A/B timings of the collisions themselves)
+bool probing_enabled() {
     static const bool probing = [] {
         const char* v = std::getenv("NBODY_AUX_PROBE");
         return v == nullptr || v[0] != '0';
     }();
+    return probing;
+}
+
+// `side` runs next to `beside` from now on: make sure it can (see above).  `retired`: streams that collided, destroyed with their owner.
+hipError_t settle_side_stream(hipStream_t* side, hipStream_t beside, std::vector<hipStream_t>* retired, int* collisions) {
     if (*side == nullptr) {
         if (const auto err = create_side_stream(side); err != hipSuccess) return err;
     }
     // (the null stream too: RCCL puts work of its own there, and a stream on the null stream's hardware queue waits behind it)
     auto fits = [&](hipStream_t candidate) { return streams_run_side_by_side(beside, candidate) && (beside == nullptr || streams_run_side_by_side(nullptr, candidate)); };
-    for (int attempt = 0; probing && attempt < 8 && !fits(*side); ++attempt) {
+    for (int attempt = 0; probing_enabled() && attempt < 8 && !fits(*side); ++attempt) {
         if (collisions != nullptr) ++*collisions;
         retired->push_back(*side);
         *side = nullptr;
@@ -271,13 +205,52 @@ hipError_t settle_side_stream(hipStream_t* side, hipStream_t beside, std::vector
 // a stream that shares the null stream's hardware queue: one created stream in three or four -- steps in 1.80 ms instead of 1.29
 // (8 ranks, 262 144 bodies).  RCCL puts work of its own on the null stream, and whatever shares that queue waits behind it.
 // Computing on a stream of the communicator's own, ordered after / before the caller's with events, was built and measured: no
-// help (1.75 ms) -- the events themselves sit on the bad queue.  So the library only LOOKS (one spin-kernel probe per caller's
-// stream) and says so (nb_comm_caller_stream_placement; bench.py's ranks_seen), and nb_comm_stream_create hands out a stream that
-// is well placed: what bench.py and BodySystemHIPSharded step on.
-void note_caller_stream(Comm* c, hipStream_t caller) {
-    if (c->world < 2 || (c->caller_checked && c->caller_last == caller)) return;
-    c->caller_bad     = caller == nullptr || !streams_run_side_by_side(nullptr, caller);
-    c->caller_checked = true, c->caller_last = caller;
+// help (1.75 ms) -- the events themselves sit on the bad queue.  So the library only LOOKS and says so
+// (nb_comm_caller_stream_placement; bench.py's ranks_seen), and nb_comm_stream_create hands out a stream that is well placed: what
+// bench.py and BodySystemHIPSharded step on.
+//
+// Round 6 (advisor): the look is taken ONCE PER STREAM -- a rank keeps a note per stream it has stepped on (a handful: a caller
+// that alternates two streams is probed twice in all, not twice per step) --, never while the stream is capturing (the probe
+// synchronises streams), never for a stream nb_comm_stream_create handed out (probed when it was made), and not at all with
+// NBODY_AUX_PROBE=0.  `need_aux`: the step is about to use the second compute stream beside this one.  A verdict is a timing
+// (two 40 us kernels side by side or not) and steers speed only, never results.  A stream handle the runtime recycles after
+// hipStreamDestroy inherits its predecessor's note; nb_comm_settle_side_stream takes a fresh look.
+StreamNote* find_note(Comm* c, hipStream_t s) {
+    for (StreamNote& n : c->seen)
+        if (n.stream == s) return &n;
+    return nullptr;
+}
+void note_stream(Comm* c, hipStream_t caller, bool need_aux, bool fresh_look = false) {
+    if (c->world < 2) return;
+    c->last_caller   = caller;
+    StreamNote* note = find_note(c, caller);
+    if (note == nullptr) {
+        if (c->seen.size() >= 8) c->seen.erase(c->seen.begin());
+        c->seen.push_back(StreamNote{});
+        note         = &c->seen.back();
+        note->stream = caller;
+    } else if (fresh_look) {
+        note->placement = -1, note->aux_beside = false;
+    }
+    const bool may_probe = probing_enabled() && !stream_is_capturing(caller);
+    if (note->placement < 0) {
+        const bool handed_out = std::find(c->placed.begin(), c->placed.end(), caller) != c->placed.end();
+        if (caller == nullptr) note->placement = 1;
+        else if (handed_out && !fresh_look) note->placement = 0;
+        else if (may_probe) note->placement = streams_run_side_by_side(nullptr, caller) ? 0 : 1;
+    }
+    if (need_aux && !note->aux_beside && may_probe) {
+        hipStream_t before = c->aux;
+        if (settle_side_stream(&c->aux, caller, &c->aux_retired, &c->aux_collisions) != hipSuccess) {
+            (void)hipGetLastError();
+            return;  // (the step goes on with the stream there is)
+        }
+        if (c->aux != before)
+            for (StreamNote& n : c->seen) n.aux_beside = false;  // (a new second stream has met none of the others)
+        note             = find_note(c, caller);
+        note->aux_beside = true;
+        c->aux_probed    = true;
+    }
 }
 
 int make_resources(Comm* c) {
@@ -288,7 +261,7 @@ int make_resources(Comm* c) {
     if (err != hipSuccess) return static_cast<int>(err);
     err = hipEventCreateWithFlags(&c->ready, hipEventDisableTiming);
     if (err != hipSuccess) return static_cast<int>(err);
-    err = create_side_stream(&c->aux);  // (probed against the caller's stream at its first pairwise step: settle_side_stream)
+    err = create_side_stream(&c->aux);  // (probed against a caller's stream the first time the two meet: note_stream)
     if (err == hipSuccess) err = hipEventCreateWithFlags(&c->aux_begin, hipEventDisableTiming);
     if (err == hipSuccess) err = hipEventCreateWithFlags(&c->aux_done, hipEventDisableTiming);
     if (err != hipSuccess) return static_cast<int>(err);
@@ -338,7 +311,21 @@ bool same_group(const std::vector<Comm*>& locals) {
     return true;
 }
 
+// the local ranks in ascending rank order (indices into `locals`)
+std::vector<size_t> by_rank(const std::vector<Comm*>& locals) {
+    std::vector<size_t> order(locals.size());
+    for (size_t k = 0; k < order.size(); ++k) order[k] = k;
+    std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return locals[a]->rank < locals[b]->rank; });
+    return order;
+}
+
 // The G-1 rounds for every local rank of a communicator.  `bytes_per_body` = 4 * sizeof(T).
+//
+// Inside a round's RCCL group the calls are issued in ONE canonical order: every local rank's send, in ascending rank order, then
+// every local rank's receive, in ascending order of the rank the data comes FROM.  Between different peers the order inside a
+// group means nothing to RCCL; between the same two peers it matches sends and receives first in, first out -- so the canonical
+// order is also what carries a world whose ranks share one RCCL communicator (the lab's in-process world: every transfer a
+// self-transfer, the k-th send meeting the k-th receive) without a line of its own here.
 int exchange_tiles(const std::vector<Comm*>& locals, void* const* positions, unsigned num_bodies, size_t bytes_per_body, int nccl_type, const hipStream_t* after, int waited_for = 0) {
     Rccl* lib = rccl();
     if (lib == nullptr) return NB_ERR_UNSUPPORTED;
@@ -362,41 +349,36 @@ int exchange_tiles(const std::vector<Comm*>& locals, void* const* positions, uns
     // kernels hold every CU does wait for one of them to retire -- a pair_forces<float,8,8> workgroup owns its CU's register file -- but
     // with a group per round those waits fall on tiles that are not needed yet.  nb_comm_set_exchange_grouping(comm, 1) issues all
     // rounds of a step as ONE group instead: a per-communicator setting, so that one job can time both (bench.py's diagnostics do).
-    // Same data, same bits either way (tested with the transport double).
+    // Same data, same bits either way (tested with the transport double).  PROVISIONAL: both defaults (a group per round; the tail
+    // group below) were chosen on one GPU, where a transfer has no link latency and no peer to be late; the first run on a node
+    // times the alternatives (bench.py's diagnostics) and may flip them.
     // `waited_for` (the pairwise step passes G/2): only the tiles of the first `waited_for` rounds are waited for by a kernel of
     // the next step -- a rank's rectangles run against ranks r+1 .. r+G/2 --, the others complete the position array for the caller:
-    // those travel as ONE more group (a group costs the host ~60 us and the chip a kernel launch: 8 ranks 11 -> 9 RCCL launches per
-    // step, the host's enqueue time per step 0.71 -> 0.59 ms).
+    // those travel as ONE more group (a group costs the host and the chip a kernel launch: 8 ranks 11 -> 9 RCCL launches per step).
     const bool one_group = locals.front()->one_group;
     for (Comm* c : locals)
         if (c->one_group != one_group) return NB_ERR_INVALID_ARGUMENT;  // the local ranks of a group must agree (all ranks must)
+    const std::vector<size_t> order = by_rank(locals);
+    std::vector<size_t>       by_source(order);
     int first = 1;
     while (first < G) {
         const int last = one_group ? G - 1 : ((waited_for > 0 && first > waited_for) ? G - 1 : first);  // rounds first .. last form one group
         int       rc   = lib->GroupStart();
         for (int s = first; s <= last && rc == 0; ++s) {
-            if (locals.front()->inprocess) {
-                // every transfer is a self-transfer of the ONE ncclComm: the k-th send meets the k-th receive, so the receives are issued
-                // in the order of the ranks whose data they take -- rank d = c - s receives what rank c sends
-                std::vector<size_t> at(static_cast<size_t>(G));
-                for (size_t k = 0; k < locals.size(); ++k) at[static_cast<size_t>(locals[k]->rank)] = k;
-                for (int c0 = 0; c0 < G && rc == 0; ++c0) {
-                    Comm* c = locals[at[static_cast<size_t>(c0)]];
-                    rc      = lib->Send(static_cast<char*>(positions[at[static_cast<size_t>(c0)]]) + static_cast<size_t>(c0) * slice_bodies * bytes_per_body, slice_values, nccl_type, 0, c->nccl, c->stream);
-                }
-                for (int c0 = 0; c0 < G && rc == 0; ++c0) {
-                    const int d = (c0 - s + G) % G;
-                    Comm*     c = locals[at[static_cast<size_t>(d)]];
-                    rc          = lib->Recv(static_cast<char*>(positions[at[static_cast<size_t>(d)]]) + static_cast<size_t>(c0) * slice_bodies * bytes_per_body, slice_values, nccl_type, 0, c->nccl, c->stream);
-                }
-                continue;
+            for (size_t k : order) {
+                Comm*     c    = locals[k];
+                const int dst  = (c->rank - s + G) % G;
+                char*     base = static_cast<char*>(positions[k]);
+                rc             = lib->Send(base + static_cast<size_t>(c->rank) * slice_bodies * bytes_per_body, slice_values, nccl_type, peer_of(c, dst), c->nccl, c->stream);
+                if (rc != 0) break;
             }
-            for (size_t k = 0; k < locals.size() && rc == 0; ++k) {
-                Comm*      c    = locals[k];
-                const int  dst  = (c->rank - s + G) % G, src = (c->rank + s) % G;
-                char*      base = static_cast<char*>(positions[k]);
-                rc              = lib->Send(base + static_cast<size_t>(c->rank) * slice_bodies * bytes_per_body, slice_values, nccl_type, peer_of(c, dst), c->nccl, c->stream);
-                if (rc == 0) rc = lib->Recv(base + static_cast<size_t>(src) * slice_bodies * bytes_per_body, slice_values, nccl_type, peer_of(c, src), c->nccl, c->stream);
+            std::sort(by_source.begin(), by_source.end(), [&](size_t a, size_t b) { return (locals[a]->rank + s) % G < (locals[b]->rank + s) % G; });
+            for (size_t k : by_source) {
+                if (rc != 0) break;
+                Comm*     c    = locals[k];
+                const int src  = (c->rank + s) % G;
+                char*     base = static_cast<char*>(positions[k]);
+                rc             = lib->Recv(base + static_cast<size_t>(src) * slice_bodies * bytes_per_body, slice_values, nccl_type, peer_of(c, src), c->nccl, c->stream);
             }
         }
         const int end = lib->GroupEnd();
@@ -446,17 +428,7 @@ template <> struct Api<double> {
 // and the finish kernel adds a body's own sums, its diagonal reaction slots and the H arrays it RECEIVED, in a fixed order.
 // Half the arithmetic per rank, one more exchange leg of the size of the existing one (same stream, same rounds, after the
 // tiles' kernels; the position exchange is unchanged, so every rank still ends a step with all positions).
-struct PairShard {
-    bool         applies = false;
-    nb::PairGeom diag{}, diag_late{}, rect{}, rect_upper{};  // rect_upper: the split rectangle as the HIGHER partner runs it (half of its blocks of bodies i: twice the workgroups per block)
-    unsigned     ni = 0, block = 0, blocks = 0, plane = 0, half = 0, H = 0, diag_slots = 0;
-    unsigned     send_order[nb::kMaxRecv] = {};  // the reaction rounds s = 1 .. H in the order their rectangles' folds are expected to complete (send_order[k] = s)
-    unsigned     early_units = 0, late_units = 0;  // the diagonal's units per block as two launches: block offsets q < q_split first, the rest LAST (late_units == 0: one launch)
-    bool         even = false;
-    size_t       self_at = 0, react_d_at = 0, react_r_at = 0, send_at = 0, recv_at = 0, elements = 0;  // offsets in T
-};
-
-std::atomic<int> g_late_diagonal{1};  // nb_set_late_diagonal (tuning header): 0 = the diagonal as ONE launch, first (the order up to round 4), for A/B timings
+std::atomic<int> g_late_diagonal{1};  // the lab's nb_set_late_diagonal: 0 = the diagonal as ONE launch, first (the order up to round 4), for A/B timings
 
 template <typename T> PairShard plan_pair_shard(unsigned num_bodies, int G, int min_slice, size_t budget) {
     const bool late_diagonal = g_late_diagonal.load() != 0;
@@ -533,7 +505,7 @@ template <typename T> PairShard plan_pair_shard(unsigned num_bodies, int G, int 
     return p;
 }
 
-std::atomic<int> g_pair_shard_min{0};  // nb_set_pair_plan_override(.., min_bodies): tests run the pairwise step on small slices
+std::atomic<int> g_pair_shard_min{0};  // nb_comm_set_pair_min_slice: tests run the pairwise step on small slices
 
 // The kernels ONE rank launches in a pairwise step, up to (not including) the finish kernel: the diagonal, then per partner
 // the rectangle and the fold of its reaction sums into the send buffer.  `c` == nullptr: no communicator (nb_emulate_pair_rank_*:
@@ -541,10 +513,9 @@ std::atomic<int> g_pair_shard_min{0};  // nb_set_pair_plan_override(.., min_bodi
 // `part`: kWholeStep = everything; kBeforeSends = up to the folds of the rectangles (what the reaction sends wait for), kAfterSends =
 // the late diagonal launch and the join of the second stream -- a communicator enqueues its reaction rounds between the two, so that
 // the last of them is under way before the rank's last force kernel.
-enum RankPart { kWholeStep = 0, kBeforeSends = 1, kAfterSends = 2 };
 template <typename T>
 int pair_rank_tiles(Comm* c, unsigned r, int G, const PairShard& plan, T* work, T* new_pos, const T* old_pos, T* vel, unsigned num_bodies, T dt, T damping, T eps2, hipStream_t stream, bool waiting, nb::FinishArgs<T>& f,
-                    hipStream_t aux, hipEvent_t aux_begin, hipEvent_t aux_done, RankPart part = kWholeStep) {
+                    hipStream_t aux, hipEvent_t aux_begin, hipEvent_t aux_done, RankPart part) {
     const unsigned ni     = plan.ni, own = r * ni;
     const size_t   plane3 = 3 * static_cast<size_t>(plan.plane);
     nb::PairArgs<T> a{};
@@ -647,38 +618,34 @@ inline void pair_rank_work(const PairShard& plan, unsigned r, int G, unsigned lo
 
 // The reaction leg of a pairwise step: round s = send to rank r+s what was summed for its bodies, receive from r-s what it
 // summed for ours; one RCCL group per round on the exchange stream, round s waiting for react_ready[s] (the fold of rectangle s)
-// and signalling react_arrived[s].
+// and signalling react_arrived[s].  Calls inside a group in the canonical order of exchange_tiles: sends by ascending rank, then
+// receives by ascending source rank.
 template <typename T> int reaction_exchange(const std::vector<Comm*>& locals, const PairShard& plan) {
     Rccl* lib = rccl();
     if (lib == nullptr) return NB_ERR_UNSUPPORTED;
     const int    G      = locals.front()->world;
     const size_t plane3 = 3 * static_cast<size_t>(plan.plane);
     NB_KEEP_RAND_STREAM;
+    const std::vector<size_t> order = by_rank(locals);
+    std::vector<size_t>       by_source(order);
     for (unsigned k = 0; k < plan.H; ++k) {
         const unsigned s = plan.send_order[k];
         for (Comm* c : locals) {
             DeviceScope scope(c->device);
             if (const auto err = hipStreamWaitEvent(c->stream, c->react_ready[s], 0); err != hipSuccess) return static_cast<int>(err);
         }
-        int rc = lib->GroupStart();
-        if (locals.front()->inprocess) {  // (routed by order, as in exchange_tiles: rank c + s receives what rank c sends)
-            std::vector<size_t> at(static_cast<size_t>(G));
-            for (size_t m = 0; m < locals.size(); ++m) at[static_cast<size_t>(locals[m]->rank)] = m;
-            for (int c0 = 0; c0 < G && rc == 0; ++c0) {
-                Comm* c = locals[at[static_cast<size_t>(c0)]];
-                rc      = lib->Send(static_cast<T*>(c->workspace) + plan.send_at + (s - 1) * plane3, plane3, Api<T>::nccl_type, 0, c->nccl, c->stream);
-            }
-            for (int c0 = 0; c0 < G && rc == 0; ++c0) {
-                Comm* c = locals[at[static_cast<size_t>((c0 + static_cast<int>(s)) % G)]];
-                rc      = lib->Recv(static_cast<T*>(c->workspace) + plan.recv_at + (s - 1) * plane3, plane3, Api<T>::nccl_type, 0, c->nccl, c->stream);
-            }
+        const int shift = static_cast<int>(s);
+        int       rc    = lib->GroupStart();
+        for (size_t m : order) {
+            if (rc != 0) break;
+            Comm* c = locals[m];
+            rc      = lib->Send(static_cast<T*>(c->workspace) + plan.send_at + (s - 1) * plane3, plane3, Api<T>::nccl_type, peer_of(c, (c->rank + shift) % G), c->nccl, c->stream);
         }
-        for (size_t m = 0; m < locals.size() && rc == 0 && !locals.front()->inprocess; ++m) {
-            Comm*     c    = locals[m];
-            T* const  work = static_cast<T*>(c->workspace);
-            const int to = (c->rank + static_cast<int>(s)) % G, from = (c->rank - static_cast<int>(s) + G) % G;
-            rc              = lib->Send(work + plan.send_at + (s - 1) * plane3, plane3, Api<T>::nccl_type, peer_of(c, to), c->nccl, c->stream);
-            if (rc == 0) rc = lib->Recv(work + plan.recv_at + (s - 1) * plane3, plane3, Api<T>::nccl_type, peer_of(c, from), c->nccl, c->stream);
+        std::sort(by_source.begin(), by_source.end(), [&](size_t a, size_t b) { return (locals[a]->rank - shift + G) % G < (locals[b]->rank - shift + G) % G; });
+        for (size_t m : by_source) {
+            if (rc != 0) break;
+            Comm* c = locals[m];
+            rc      = lib->Recv(static_cast<T*>(c->workspace) + plan.recv_at + (s - 1) * plane3, plane3, Api<T>::nccl_type, peer_of(c, (c->rank - shift + G) % G), c->nccl, c->stream);
         }
         const int end = lib->GroupEnd();
         if (rc == 0) rc = end;
@@ -692,43 +659,145 @@ template <typename T> int reaction_exchange(const std::vector<Comm*>& locals, co
     return 0;
 }
 
+// ---- the crew: who enqueues a step over several local ranks ---------------------------------------------------------------------
+// One process driving G devices (nb_comm_init_all: `nbody --numdevices G`, BodySystemHIPSharded -- the process model SURVEY 8(e)
+// names) used to enqueue every rank's kernels, events and RCCL calls from the calling thread: 0.13-0.19 ms per rank and step
+// (measured, a loopback rank of 8 at 262 144 bodies: profiles/round6_graph_capture_probe.txt), i.e. ~1.2 ms for 8 ranks against a
+// 1.3 ms step -- host-bound.  Capturing a rank's step into a hipGraph was tried first (same file): RCCL's send/recv groups ARE
+// captured and replay (the position exchange alone: 3 us of host time per replay; the one-sided step: 4 us per step at the same
+// stream time), but the pairwise step replays in 2.41 ms instead of 1.28 -- the graph runs the two compute streams' branches one
+// after the other, the very figure of two streams on one hardware queue -- and two pairwise steps in one capture end in a
+// segmentation fault inside hipStreamEndCapture.  So the step stays eager and its per-rank parts are enqueued IN PARALLEL:
+// a crew of persistent threads, one per local rank, made the first time a group of several ranks steps and kept until the last
+// of its communicators goes.  The RCCL calls of a round stay one group over the local ranks, issued by the calling thread
+// between the crew's phases (a group that misses a peer hangs; and ranks that share an RCCL communicator cannot call into it
+// concurrently at all).  The crew spins for up to ~0.3 ms between phases and steps, then sleeps on a condition variable.
+// NBODY_STEP_THREADS=0: the calling thread does everything (A/B timings; the same calls in the same per-rank order, so the
+// same bits -- tested).
+class StepCrew {
+ public:
+    explicit StepCrew(const std::vector<Comm*>& group) {
+        for (size_t k = 1; k < group.size(); ++k) workers_.emplace_back([this, k, device = group[k]->device] { work(k, device); });
+    }
+    ~StepCrew() {
+        {
+            std::lock_guard<std::mutex> lock(mutex_);
+            quit_ = true;
+            ++ticket_;
+        }
+        wake_.notify_all();
+        for (auto& t : workers_) t.join();
+    }
+    StepCrew(const StepCrew&)            = delete;
+    StepCrew& operator=(const StepCrew&) = delete;
+
+    // fn(k) for k = 0 .. n-1, k = 0 on the calling thread, the others on the crew; returns the first non-zero result
+    int run(size_t n, const std::function<int(size_t)>& fn) {
+        if (n > workers_.size() + 1) return NB_ERR_INVALID_ARGUMENT;
+        results_.assign(n, 0);
+        job_ = &fn, job_size_ = n;
+        pending_.store(static_cast<int>(n) - 1, std::memory_order_release);
+        {
+            std::lock_guard<std::mutex> lock(mutex_);  // (the ticket changes under the lock: a worker about to sleep cannot miss it)
+            ticket_.fetch_add(1, std::memory_order_release);
+        }
+        if (sleepers_.load(std::memory_order_acquire) != 0) wake_.notify_all();
+        results_[0] = fn(0);
+        for (int spins = 0; pending_.load(std::memory_order_acquire) != 0; ++spins)
+            if (spins > 2000) std::this_thread::yield();
+        for (int r : results_)
+            if (r != 0) return r;
+        return 0;
+    }
+
+ private:
+    void work(size_t k, int device) {
+        (void)hipSetDevice(device);
+        unsigned long long seen = 0;
+        for (;;) {
+            const auto idle_since = std::chrono::steady_clock::now();
+            while (ticket_.load(std::memory_order_acquire) == seen) {
+                if (std::chrono::steady_clock::now() - idle_since > std::chrono::microseconds(300)) {
+                    std::unique_lock<std::mutex> lock(mutex_);
+                    sleepers_.fetch_add(1, std::memory_order_acq_rel);
+                    wake_.wait(lock, [&] { return ticket_.load(std::memory_order_acquire) != seen; });
+                    sleepers_.fetch_sub(1, std::memory_order_acq_rel);
+                }
+            }
+            seen = ticket_.load(std::memory_order_acquire);
+            if (quit_) return;
+            if (k < job_size_) results_[k] = (*job_)(k);
+            if (k < job_size_) pending_.fetch_sub(1, std::memory_order_acq_rel);
+        }
+    }
+
+    std::vector<std::thread>           workers_;
+    std::mutex                         mutex_;
+    std::condition_variable            wake_;
+    std::atomic<unsigned long long>    ticket_{0};
+    std::atomic<int>                   pending_{0}, sleepers_{0};
+    const std::function<int(size_t)>*  job_      = nullptr;
+    size_t                             job_size_ = 0;
+    std::vector<int>                   results_;
+    bool                               quit_ = false;
+};
+
+bool crew_enabled() {
+    static const bool on = [] {
+        const char* v = std::getenv("NBODY_STEP_THREADS");
+        return v == nullptr || v[0] != '0';
+    }();
+    return on;
+}
+
+// fn(k) for every local rank: on the group's crew when there is more than one, else (or with NBODY_STEP_THREADS=0) in turn
+int for_each_rank(const std::vector<Comm*>& locals, const std::function<int(size_t)>& fn) {
+    if (locals.size() > 1 && crew_enabled()) {
+        Comm* owner = locals.front()->group.front();
+        if (!owner->crew) {
+            auto crew = std::make_shared<StepCrew>(owner->group);
+            for (Comm* c : owner->group) c->crew = crew;
+        }
+        return static_cast<StepCrew*>(owner->crew.get())->run(locals.size(), fn);
+    }
+    for (size_t k = 0; k < locals.size(); ++k)
+        if (const int rc = fn(k); rc != 0) return rc;
+    return 0;
+}
+
 template <typename T>
 int pair_sharded_step(const std::vector<Comm*>& locals, const PairShard& plan, T* const* new_pos, const T* const* old_pos, T* const* vel, unsigned num_bodies, T dt, T damping, T eps2, const nb_stream_t* streams) {
     if (rccl() == nullptr) return NB_ERR_UNSUPPORTED;
     const int G = locals.front()->world;
     std::vector<nb::FinishArgs<T>> finish(locals.size());
-    for (size_t k = 0; k < locals.size(); ++k) {
+    // phase 1, every rank at once: the early diagonal, the rectangles (each waiting for its tile) and their folds
+    int rc = for_each_rank(locals, [&](size_t k) {
         Comm*       c = locals[k];
         DeviceScope scope(c->device);
         const bool  waiting = c->in_flight == static_cast<const void*>(old_pos[k]);
-        if (plan.H >= 2 && (!c->aux_probed || c->aux_settled_beside != reinterpret_cast<hipStream_t>(streams[k]))) {  // (the second stream is used from two partners on)
-            if (const auto err = settle_side_stream(&c->aux, reinterpret_cast<hipStream_t>(streams[k]), &c->aux_retired, &c->aux_collisions); err != hipSuccess) return static_cast<int>(err);
-            c->aux_probed = true, c->aux_settled_beside = reinterpret_cast<hipStream_t>(streams[k]);
-        }
-        const int   rc = pair_rank_tiles<T>(c, static_cast<unsigned>(c->rank), G, plan, static_cast<T*>(c->workspace), new_pos[k], old_pos[k], vel[k], num_bodies, dt, damping, eps2,
-                                            reinterpret_cast<hipStream_t>(streams[k]), waiting, finish[k], c->aux, c->aux_begin, c->aux_done, kBeforeSends);
-        if (rc != 0) return rc;
-    }
+        note_stream(c, reinterpret_cast<hipStream_t>(streams[k]), /*need_aux=*/plan.H >= 2);  // (the second stream is used from two partners on)
+        return pair_rank_tiles<T>(c, static_cast<unsigned>(c->rank), G, plan, static_cast<T*>(c->workspace), new_pos[k], old_pos[k], vel[k], num_bodies, dt, damping, eps2,
+                                  reinterpret_cast<hipStream_t>(streams[k]), waiting, finish[k], c->aux, c->aux_begin, c->aux_done, kBeforeSends);
+    });
+    if (rc != 0) return rc;
     // every reaction round is enqueued (each waits for the fold of its rectangle) BEFORE the ranks' last force kernel: the late half of the diagonal
-    if (const int rc = reaction_exchange<T>(locals, plan); rc != 0) return rc;
-    for (size_t k = 0; k < locals.size(); ++k) {
-        Comm*       c = locals[k];
-        DeviceScope scope(c->device);
-        const int   rc = pair_rank_tiles<T>(c, static_cast<unsigned>(c->rank), G, plan, static_cast<T*>(c->workspace), new_pos[k], old_pos[k], vel[k], num_bodies, dt, damping, eps2,
-                                            reinterpret_cast<hipStream_t>(streams[k]), false, finish[k], c->aux, c->aux_begin, c->aux_done, kAfterSends);
-        if (rc != 0) return rc;
-    }
-    for (size_t k = 0; k < locals.size(); ++k) {
+    if (rc = reaction_exchange<T>(locals, plan); rc != 0) return rc;
+    // phase 2, every rank at once: the late diagonal, the join of the second stream, the waits for what was received, the finish kernel
+    return for_each_rank(locals, [&](size_t k) {
         Comm*       c = locals[k];
         DeviceScope scope(c->device);
         hipStream_t stream = reinterpret_cast<hipStream_t>(streams[k]);
+        if (const int r = pair_rank_tiles<T>(c, static_cast<unsigned>(c->rank), G, plan, static_cast<T*>(c->workspace), new_pos[k], old_pos[k], vel[k], num_bodies, dt, damping, eps2, stream, false, finish[k], c->aux,
+                                             c->aux_begin, c->aux_done, kAfterSends);
+            r != 0)
+            return r;
         for (unsigned s = 1; s <= plan.H; ++s) {
             if (const auto err = hipStreamWaitEvent(stream, c->react_arrived[s], 0); err != hipSuccess) return static_cast<int>(err);
         }
         if (const auto err = nb::launch_pair_finish<T>(finish[k], stream); err != hipSuccess) return static_cast<int>(err);
         c->trace += "finish\n";
-    }
-    return 0;
+        return 0;
+    });
 }
 
 // What every rank of the communicator is known to have been lent: one process driving all ranks sees them all; one process
@@ -774,24 +843,10 @@ template <typename T> bool step_is_pairwise(const std::vector<Comm*>& locals, un
 
 // One step for every local rank: kernels of the own slice and of each tile as it arrives, integrate, start the next exchange.
 template <typename T>
-int sharded_step(nb_comm_t const* comms, int n_local, T* const* new_pos, const T* const* old_pos, T* const* vel, T* const* acc, unsigned num_bodies, T dt, T damping, int block_size, int mode, const nb_stream_t* streams) {
-    if (comms == nullptr || n_local < 1 || !new_pos || !old_pos || !vel || !acc || !streams) return NB_ERR_INVALID_ARGUMENT;
-    std::vector<Comm*> locals(static_cast<size_t>(n_local));
-    for (int k = 0; k < n_local; ++k) {
-        locals[static_cast<size_t>(k)] = as_comm(comms[k]);
-        if (locals[static_cast<size_t>(k)] == nullptr) return NB_ERR_INVALID_ARGUMENT;
-    }
-    // The comms must be exactly the local ranks of ONE communicator (any order): a round is one RCCL group over all of
-    // them, and a group that misses a peer hangs inside RCCL instead of failing.
-    if (!same_group(locals)) return NB_ERR_INVALID_ARGUMENT;
-    const int G = locals.front()->world;
-    if (num_bodies == 0 || num_bodies % static_cast<unsigned>(G)) return NB_ERR_INVALID_ARGUMENT;  // pad with zero-mass bodies (as tipsy.cpp:111-119 does)
-    const unsigned ni = num_bodies / static_cast<unsigned>(G);
-    for (int k = 0; k < n_local && G > 1; ++k) {  // (a look at the stream the caller computes on, once per stream: see note_caller_stream)
-        Comm*       c = locals[static_cast<size_t>(k)];
-        DeviceScope scope(c->device);
-        note_caller_stream(c, reinterpret_cast<hipStream_t>(streams[k]));
-    }
+int sharded_step_locals(const std::vector<Comm*>& locals, T* const* new_pos, const T* const* old_pos, T* const* vel, T* const* acc, unsigned num_bodies, T dt, T damping, int block_size, int mode, const nb_stream_t* streams) {
+    const int      G       = locals.front()->world;
+    const size_t   n_local = locals.size();
+    const unsigned ni      = num_bodies / static_cast<unsigned>(G);
     bool           done_pairwise = false;
     {   // every rank of the COMMUNICATOR lent a large enough workspace (decided identically on every rank): pairs once, across the ranks too
         PairShard plan;
@@ -806,11 +861,11 @@ int sharded_step(nb_comm_t const* comms, int n_local, T* const* new_pos, const T
                 (void)nb_get_softening_sq_f64(&e);
                 eps2 = e;
             }
-            for (int k = 0; k < n_local; ++k) {  // the same argument rules as nb_integrate_ws_*: four separate ranges
+            for (size_t k = 0; k < n_local; ++k) {  // the same argument rules as nb_integrate_ws_*: four separate ranges
                 if (new_pos[k] == nullptr || old_pos[k] == nullptr || vel[k] == nullptr || new_pos[k] == old_pos[k]) return NB_ERR_INVALID_ARGUMENT;
                 const auto lo = [](const void* q) { return reinterpret_cast<size_t>(q); };
                 const size_t body_bytes = static_cast<size_t>(num_bodies) * 4 * sizeof(T), work_bytes = plan.elements * sizeof(T);
-                const void*  work       = locals[static_cast<size_t>(k)]->workspace;
+                const void*  work       = locals[k]->workspace;
                 for (const void* body_array : {static_cast<const void*>(old_pos[k]), static_cast<const void*>(new_pos[k]), static_cast<const void*>(vel[k])}) {
                     if (lo(work) < lo(body_array) + body_bytes && lo(body_array) < lo(work) + work_bytes) return NB_ERR_INVALID_ARGUMENT;
                 }
@@ -820,34 +875,58 @@ int sharded_step(nb_comm_t const* comms, int n_local, T* const* new_pos, const T
             done_pairwise = true;
         }
     }
-    for (int k = 0; k < n_local && !done_pairwise; ++k) {
-        Comm*         c = locals[static_cast<size_t>(k)];
-        DeviceScope   scope(c->device);
-        hipStream_t   stream   = reinterpret_cast<hipStream_t>(streams[k]);
-        const bool    waiting  = c->in_flight == static_cast<const void*>(old_pos[k]);  // else: every rank holds the whole array already
-        const unsigned i0      = static_cast<unsigned>(c->rank) * ni;
-        if (G == 1 && c->workspace != nullptr) {  // one rank holds every body: the single-GPU step, with its workspace
-            const int rc = Api<T>::whole(new_pos[k], old_pos[k], vel[k], dt, damping, num_bodies, block_size, mode, c->workspace, c->workspace_bytes, streams[k]);
-            if (rc != 0) return rc;
-            continue;
-        }
-        for (int t = 0; t < G; ++t) {
-            // FAST: own slice, then the tiles in arrival order (rank+1, rank+2, ...); STRICT: ascending rank = ascending j
-            const int  peer = mode == NB_MODE_STRICT ? t : (c->rank + t) % G;
-            if (peer != c->rank && waiting) {
-                const auto err = hipStreamWaitEvent(stream, c->arrived[static_cast<size_t>(peer)], 0);
-                if (err != hipSuccess) return static_cast<int>(err);
+    if (!done_pairwise) {  // the one-sided tile schedule, every rank at once
+        const int rc = for_each_rank(locals, [&](size_t k) -> int {
+            Comm*          c = locals[k];
+            DeviceScope    scope(c->device);
+            hipStream_t    stream  = reinterpret_cast<hipStream_t>(streams[k]);
+            const bool     waiting = c->in_flight == static_cast<const void*>(old_pos[k]);  // else: every rank holds the whole array already
+            const unsigned i0      = static_cast<unsigned>(c->rank) * ni;
+            note_stream(c, stream, /*need_aux=*/false);
+            if (G == 1 && c->workspace != nullptr)  // one rank holds every body: the single-GPU step, with its workspace
+                return Api<T>::whole(new_pos[k], old_pos[k], vel[k], dt, damping, num_bodies, block_size, mode, c->workspace, c->workspace_bytes, streams[k]);
+            for (int t = 0; t < G; ++t) {
+                // FAST: own slice, then the tiles in arrival order (rank+1, rank+2, ...); STRICT: ascending rank = ascending j
+                const int peer = mode == NB_MODE_STRICT ? t : (c->rank + t) % G;
+                if (peer != c->rank && waiting) {
+                    const auto err = hipStreamWaitEvent(stream, c->arrived[static_cast<size_t>(peer)], 0);
+                    if (err != hipSuccess) return static_cast<int>(err);
+                }
+                const unsigned flags = (t > 0 ? NB_SHARD_ACC_IN : 0u) | (t == G - 1 ? NB_SHARD_FINALIZE : 0u);
+                const int      rc    = Api<T>::shard(new_pos[k], old_pos[k], vel[k], acc[k], i0, ni, static_cast<unsigned>(peer) * ni, ni, flags, dt, damping, block_size, mode, streams[k]);
+                if (rc != 0) return rc;
             }
-            const unsigned flags = (t > 0 ? NB_SHARD_ACC_IN : 0u) | (t == G - 1 ? NB_SHARD_FINALIZE : 0u);
-            const int      rc    = Api<T>::shard(new_pos[k], old_pos[k], vel[k], acc[k], i0, ni, static_cast<unsigned>(peer) * ni, ni, flags, dt, damping, block_size, mode, streams[k]);
-            if (rc != 0) return rc;
-        }
+            return 0;
+        });
+        if (rc != 0) return rc;
     }
     if (G == 1) return 0;
-    std::vector<void*>       arrays(static_cast<size_t>(n_local));
-    std::vector<hipStream_t> after(static_cast<size_t>(n_local));
-    for (int k = 0; k < n_local; ++k) arrays[static_cast<size_t>(k)] = new_pos[k], after[static_cast<size_t>(k)] = reinterpret_cast<hipStream_t>(streams[k]);
+    std::vector<void*>       arrays(n_local);
+    std::vector<hipStream_t> after(n_local);
+    for (size_t k = 0; k < n_local; ++k) arrays[k] = new_pos[k], after[k] = reinterpret_cast<hipStream_t>(streams[k]);
     return exchange_tiles(locals, arrays.data(), num_bodies, 4 * sizeof(T), Api<T>::nccl_type, after.data(), done_pairwise ? G / 2 : 0);
+}
+
+template <typename T>
+int sharded_step(nb_comm_t const* comms, int n_local, T* const* new_pos, const T* const* old_pos, T* const* vel, T* const* acc, unsigned num_bodies, T dt, T damping, int block_size, int mode, const nb_stream_t* streams) {
+    if (comms == nullptr || n_local < 1 || !new_pos || !old_pos || !vel || !acc || !streams) return NB_ERR_INVALID_ARGUMENT;
+    const auto         t0 = std::chrono::steady_clock::now();
+    std::vector<Comm*> locals(static_cast<size_t>(n_local));
+    for (int k = 0; k < n_local; ++k) {
+        locals[static_cast<size_t>(k)] = as_comm(comms[k]);
+        if (locals[static_cast<size_t>(k)] == nullptr) return NB_ERR_INVALID_ARGUMENT;
+    }
+    // The comms must be exactly the local ranks of ONE communicator (any order): a round is one RCCL group over all of
+    // them, and a group that misses a peer hangs inside RCCL instead of failing.
+    if (!same_group(locals)) return NB_ERR_INVALID_ARGUMENT;
+    const int G = locals.front()->world;
+    if (num_bodies == 0 || num_bodies % static_cast<unsigned>(G)) return NB_ERR_INVALID_ARGUMENT;  // pad with zero-mass bodies (as tipsy.cpp:111-119 does)
+    const int rc = sharded_step_locals<T>(locals, new_pos, old_pos, vel, acc, num_bodies, dt, damping, block_size, mode, streams);
+    // what the HOST needed to enqueue this step for all its local ranks (nb_comm_last_enqueue_ms): a step whose enqueue takes longer
+    // than its kernels is bound by the host
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    for (Comm* c : locals) c->last_enqueue_ms = ms;
+    return rc;
 }
 
 template <typename T> int comm_workspace_bytes(nb_comm_t comm, unsigned num_bodies, int mode, size_t* bytes) {
@@ -945,24 +1024,9 @@ template <typename T> int comm_pair_work(nb_comm_t comm, unsigned num_bodies, un
     pair_rank_work(plan, static_cast<unsigned>(c->rank), c->world, evaluations, launches);
     return 0;
 }
-}  // namespace
-
-extern "C" {
-
-int nb_comm_unique_id(void* id) {
-    NB_KEEP_RAND_STREAM;
-    Rccl* lib = rccl();
-    if (lib == nullptr) return NB_ERR_UNSUPPORTED;
-    if (id == nullptr) return NB_ERR_INVALID_ARGUMENT;
-    ncclUniqueId uid;
-    const int    rc = lib->GetUniqueId(&uid);
-    if (rc == 0) std::memcpy(id, uid.internal, sizeof(uid.internal));
-    return nccl_status(rc);
-}
-
-// `alone_too`: bind RCCL and make a real communicator even for a world of one (nb_comm_selftest_open: the self-loop check);
-// `loopback`: the ncclComm has ONE rank whatever `world` says -- rank r of a nominal world whose every peer is itself
-static int init_rank(nb_comm_t* comm, const void* id, int world, int rank, bool alone_too, bool loopback = false) {
+// `alone_too`: bind RCCL and make a real communicator even for a world of one (the lab's self-loop check);
+// `self_peers`: the ncclComm has ONE rank whatever `world` says -- rank r of a nominal world whose every peer is itself (the lab's loopback rank)
+int init_rank(nb_comm_t* comm, const void* id, int world, int rank, bool alone_too, bool self_peers) {
     NB_KEEP_RAND_STREAM;
     if (!comm || (!id && (world > 1 || alone_too)) || world < 1 || rank < 0 || rank >= world) return NB_ERR_INVALID_ARGUMENT;
     *comm     = nullptr;
@@ -980,9 +1044,9 @@ static int init_rank(nb_comm_t* comm, const void* id, int world, int rank, bool 
     if (transport) {
         ncclUniqueId uid;
         std::memcpy(uid.internal, id, sizeof(uid.internal));
-        rc = nccl_status(loopback ? lib->CommInitRank(&c->nccl, 1, uid, 0) : lib->CommInitRank(&c->nccl, world, uid, rank));
+        rc = nccl_status(self_peers ? lib->CommInitRank(&c->nccl, 1, uid, 0) : lib->CommInitRank(&c->nccl, world, uid, rank));
     }
-    c->loopback = loopback;
+    c->self_peers = self_peers;
     if (rc == 0) rc = make_resources(c);
     if (rc != 0) {
         if (c->nccl) (void)lib->CommDestroy(c->nccl);
@@ -993,6 +1057,24 @@ static int init_rank(nb_comm_t* comm, const void* id, int world, int rank, bool 
     c->group = {c};
     *comm    = c;
     return 0;
+}
+
+
+}  // namespace nbc
+
+using namespace nbc;
+
+extern "C" {
+
+int nb_comm_unique_id(void* id) {
+    NB_KEEP_RAND_STREAM;
+    Rccl* lib = rccl();
+    if (lib == nullptr) return NB_ERR_UNSUPPORTED;
+    if (id == nullptr) return NB_ERR_INVALID_ARGUMENT;
+    ncclUniqueId uid;
+    const int    rc = lib->GetUniqueId(&uid);
+    if (rc == 0) std::memcpy(id, uid.internal, sizeof(uid.internal));
+    return nccl_status(rc);
 }
 
 int nb_comm_init_rank(nb_comm_t* comm, const void* id, int world, int rank) { return init_rank(comm, id, world, rank, false); }
@@ -1043,7 +1125,7 @@ int nb_comm_destroy(nb_comm_t comm) {
         DeviceScope scope(c->device);
         (void)hipStreamSynchronize(c->stream);
     }
-    if (c->shared_nccl) c->shared_nccl.reset();  // (the last rank of an in-process world destroys the ncclComm they share)
+    if (c->shared_nccl) c->shared_nccl.reset();  // (ranks that share an ncclComm: the last of them destroys it)
     else if (c->nccl != nullptr)
         if (Rccl* lib = rccl(); lib != nullptr) (void)lib->CommDestroy(c->nccl);
     free_resources(c);
@@ -1147,61 +1229,6 @@ int nb_comm_set_pair_min_slice(int min_bodies_per_rank) {
     return 0;
 }
 
-// ---- the REAL transport on one GPU (tuning header): a communicator of one rank that does own an RCCL communicator, and a
-// self-loop through it with the event choreography of exchange_tiles -----------------------------------------------------------
-int nb_comm_selftest_open(nb_comm_t* comm, const void* id) { return init_rank(comm, id, 1, 0, true); }
-int nb_comm_loopback_open(nb_comm_t* comm, const void* id, int nominal_world, int nominal_rank) {
-    if (nominal_world < 2) return NB_ERR_INVALID_ARGUMENT;
-    return init_rank(comm, id, nominal_world, nominal_rank, true, true);
-}
-
-// An IN-PROCESS world: all G ranks in this process, on the current device, sharing ONE real one-rank ncclComm and one exchange stream.
-// Every transfer is a self-transfer of that communicator; RCCL matches the sends and receives of one peer first in, first out, so
-// the library routes rank a's send to rank b's receive by the ORDER in which it issues them (exchange_tiles, reaction_exchange).  The
-// full G-rank step -- even G, split rectangles and all -- then runs through the product's own calls into the REAL library, its
-// results comparable with the CPU path: what RCCL's refusal of two ranks per device otherwise leaves to the transport double.
-int nb_comm_inprocess_open_all(nb_comm_t* comms, int world, const void* id) {
-    NB_KEEP_RAND_STREAM;
-    if (comms == nullptr || id == nullptr || world < 2) return NB_ERR_INVALID_ARGUMENT;
-    Rccl* lib = rccl();
-    if (lib == nullptr) return NB_ERR_UNSUPPORTED;
-    ncclUniqueId uid;
-    std::memcpy(uid.internal, id, sizeof(uid.internal));
-    ncclComm_t real = nullptr;
-    if (const int rc = lib->CommInitRank(&real, 1, uid, 0); rc != 0) return nccl_status(rc);
-    std::shared_ptr<void> owner(real, [lib](void* p) { (void)lib->CommDestroy(static_cast<ncclComm_t>(p)); });
-    int device = 0;
-    if (const auto err = hipGetDevice(&device); err != hipSuccess) return static_cast<int>(err);
-    std::vector<Comm*> made;
-    int                rc = 0;
-    for (int k = 0; k < world && rc == 0; ++k) {
-        auto* c      = new Comm;
-        c->nccl      = real, c->shared_nccl = owner;
-        c->rank      = k, c->world = world, c->device = device;
-        c->loopback  = true, c->inprocess = true;
-        made.push_back(c);
-        rc = make_resources(c);
-        if (rc == 0 && k > 0) {  // one exchange stream for all: the ranks' self-transfers of a round are ONE RCCL group on one stream
-            (void)hipStreamDestroy(c->stream);
-            c->stream = made.front()->stream, c->owns_stream = false;
-        }
-    }
-    if (rc != 0) {
-        for (Comm* c : made) {
-            free_resources(c);
-            delete c;
-        }
-        return rc;
-    }
-    std::shared_ptr<void> stream_owner(made.front()->stream, [device](void* s) {
-        DeviceScope scope(device);
-        (void)hipStreamDestroy(static_cast<hipStream_t>(s));
-    });
-    for (Comm* c : made) c->group = made, c->shared_stream = stream_owner, c->owns_stream = false;
-    for (int k = 0; k < world; ++k) comms[k] = made[static_cast<size_t>(k)];
-    return 0;
-}
-
 int nb_comm_transport_info(nb_comm_t comm, int* version, char* library_path, size_t path_bytes) {
     NB_KEEP_RAND_STREAM;
     Comm* c = as_comm(comm);
@@ -1219,153 +1246,30 @@ int nb_comm_transport_info(nb_comm_t comm, int* version, char* library_path, siz
     return 0;
 }
 
-// `rounds` send/recv pairs from this rank to ITSELF on the communicator's exchange stream -- round k moves `count` floats from
-// src + k * count to dst + k * count -- all in one RCCL group or a group per round, after what `after` holds now; `begin` / `end`
-// (optional) are recorded on the exchange stream around them, and tile event 0 after them (nb_exchange_wait_tile(comm, .., 0)
-// is not usable for it: a rank never waits for its own tile -- the caller waits for `end`).
-int nb_comm_self_transfer_f32(nb_comm_t comm, const float* src, float* dst, size_t count, int rounds, int one_group, nb_stream_t after, nb_event_t begin, nb_event_t end) {
-    NB_KEEP_RAND_STREAM;
-    Comm* c = as_comm(comm);
-    if (c == nullptr || c->nccl == nullptr || src == nullptr || dst == nullptr || count == 0 || rounds < 1) return NB_ERR_INVALID_ARGUMENT;
-    Rccl* lib = rccl();
-    if (lib == nullptr) return NB_ERR_UNSUPPORTED;
-    DeviceScope scope(c->device);
-    auto        err = hipEventRecord(c->ready, reinterpret_cast<hipStream_t>(after));
-    if (err == hipSuccess) err = hipStreamWaitEvent(c->stream, c->ready, 0);
-    if (err == hipSuccess && begin != nullptr) err = hipEventRecord(reinterpret_cast<hipEvent_t>(begin), c->stream);
-    if (err != hipSuccess) return static_cast<int>(err);
-    int rc = one_group ? static_cast<int>(lib->GroupStart()) : 0;
-    for (int k = 0; k < rounds && rc == 0; ++k) {
-        if (!one_group) rc = lib->GroupStart();
-        if (rc == 0) rc = lib->Send(src + static_cast<size_t>(k) * count, count, ncclFloat32, peer_of(c, c->rank), c->nccl, c->stream);
-        if (rc == 0) rc = lib->Recv(dst + static_cast<size_t>(k) * count, count, ncclFloat32, peer_of(c, c->rank), c->nccl, c->stream);
-        if (!one_group) {
-            const int ended = lib->GroupEnd();
-            if (rc == 0) rc = ended;
-        }
-    }
-    if (one_group) {
-        const int ended = lib->GroupEnd();
-        if (rc == 0) rc = ended;
-    }
-    if (rc != 0) return nccl_status(rc);
-    if (end != nullptr) err = hipEventRecord(reinterpret_cast<hipEvent_t>(end), c->stream);
-    if (err == hipSuccess) err = hipEventRecord(c->arrived[static_cast<size_t>(c->rank)], c->stream);
-    return static_cast<int>(err);
-}
-
-int nb_comm_selftest_f32(nb_comm_t comm, size_t bytes, nb_stream_t stream, nb_comm_selftest_t* report) {
-    NB_KEEP_RAND_STREAM;
-    Comm* c = as_comm(comm);
-    if (c == nullptr || report == nullptr || bytes < 4 || bytes % 4 != 0) return NB_ERR_INVALID_ARGUMENT;
-    std::memset(report, 0, sizeof(*report));
-    if (c->nccl == nullptr || c->world != 1) return NB_ERR_INVALID_ARGUMENT;  // (made by nb_comm_selftest_open)
-    Rccl* lib = rccl();
-    if (lib == nullptr) return NB_ERR_UNSUPPORTED;
-    (void)nb_comm_transport_info(comm, &report->rccl_version, report->library_path, sizeof(report->library_path));
-    DeviceScope  scope(c->device);
-    hipStream_t  on    = reinterpret_cast<hipStream_t>(stream);
-    const size_t count = bytes / 4;
-    std::vector<unsigned> sent(count), got(count);
-    for (size_t k = 0; k < count; ++k) sent[k] = static_cast<unsigned>(k) * 2654435761u + 0x9e3779b9u;
-    float *     src = nullptr, *dst = nullptr, *gathered = nullptr;
-    hipEvent_t  t0 = nullptr, t1 = nullptr;
-    int         result = 0;
-    auto refuse = [&](const char* call, int rc, int* slot) {
-        *slot = nccl_status(rc);
-        if (report->refused_call[0] == 0) std::strncpy(report->refused_call, call, sizeof(report->refused_call) - 1);
-        if (result == 0) result = *slot;
-    };
-    auto wrong_bytes = [&](const float* device) -> size_t {  // what `device` holds against what was sent (after the exchange stream's work)
-        if (hipMemcpyAsync(got.data(), device, bytes, hipMemcpyDeviceToHost, on) != hipSuccess || hipStreamSynchronize(on) != hipSuccess) return bytes;
-        size_t wrong = 0;
-        for (size_t k = 0; k < count; ++k)
-            for (int b = 0; b < 4; ++b) wrong += ((sent[k] >> (8 * b)) & 0xffu) != ((got[k] >> (8 * b)) & 0xffu);
-        return wrong;
-    };
-    hipError_t err = hipMalloc(reinterpret_cast<void**>(&src), bytes);
-    if (err == hipSuccess) err = hipMalloc(reinterpret_cast<void**>(&dst), bytes);
-    if (err == hipSuccess) err = hipMalloc(reinterpret_cast<void**>(&gathered), bytes);
-    if (err == hipSuccess) err = hipEventCreate(&t0);
-    if (err == hipSuccess) err = hipEventCreate(&t1);
-    // what is sent is produced on the CALLER's stream (as a step's positions are); the exchange stream waits for `ready`
-    if (err == hipSuccess) err = hipMemcpyAsync(src, sent.data(), bytes, hipMemcpyHostToDevice, on);
-    if (err == hipSuccess) err = hipMemsetAsync(dst, 0xa5, bytes, on);
-    if (err == hipSuccess) err = hipMemsetAsync(gathered, 0x5a, bytes, on);
-    if (err == hipSuccess) {
-        // (1) GroupStart; Send(to self); Recv(from self); GroupEnd -- exactly one round of exchange_tiles
-        const int rc = nb_comm_self_transfer_f32(comm, src, dst, count, 1, 1, stream, t0, t1);
-        if (rc >= NB_ERR_RCCL_BASE) refuse("ncclSend/ncclRecv (grouped, to self)", rc - NB_ERR_RCCL_BASE, &report->send_recv_status);
-        else if (rc != 0) err = static_cast<hipError_t>(rc);
-        else {
-            err = hipStreamWaitEvent(on, c->arrived[0], 0);  // the consumer of a tile waits for its event, on the compute stream
-            if (err == hipSuccess) report->send_recv_wrong_bytes = wrong_bytes(dst);
-            if (err == hipSuccess) err = hipEventElapsedTime(&report->send_recv_ms, t0, t1);
-        }
-    }
-    if (err == hipSuccess) {
-        // (2) ncclAllGather as nb_allgather_* issues it; out of place first (bytes to check), then in place (the product's form)
-        err = hipEventRecord(c->ready, on);
-        if (err == hipSuccess) err = hipStreamWaitEvent(c->stream, c->ready, 0);
-        if (err == hipSuccess) err = hipEventRecord(t0, c->stream);
-        if (err == hipSuccess) {
-            int rc = lib->AllGather(src, gathered, count, ncclFloat32, c->nccl, c->stream);
-            if (rc == 0) rc = lib->AllGather(gathered, gathered, count, ncclFloat32, c->nccl, c->stream);
-            if (rc != 0) refuse("ncclAllGather", rc, &report->all_gather_status);
-            else {
-                err = hipEventRecord(t1, c->stream);
-                if (err == hipSuccess) err = hipEventRecord(c->arrived[0], c->stream);
-                if (err == hipSuccess) err = hipStreamWaitEvent(on, c->arrived[0], 0);
-                if (err == hipSuccess) report->all_gather_wrong_bytes = wrong_bytes(gathered);
-                if (err == hipSuccess) err = hipEventElapsedTime(&report->all_gather_ms, t0, t1);
-            }
-        }
-    }
-    (void)hipStreamSynchronize(c->stream);
-    (void)hipStreamSynchronize(on);
-    if (t0) (void)hipEventDestroy(t0);
-    if (t1) (void)hipEventDestroy(t1);
-    for (float* p : {src, dst, gathered})
-        if (p) (void)hipFree(p);
-    if (err != hipSuccess) {
-        (void)hipGetLastError();
-        return static_cast<int>(err);
-    }
-    if (result == 0 && (report->send_recv_wrong_bytes != 0 || report->all_gather_wrong_bytes != 0)) result = NB_ERR_UNSUPPORTED;
-    return result;
-}
-
 int nb_comm_settle_side_stream(nb_comm_t comm, nb_stream_t beside) {
     NB_KEEP_RAND_STREAM;
     Comm* c = as_comm(comm);
     if (c == nullptr) return NB_ERR_INVALID_ARGUMENT;
     DeviceScope scope(c->device);
     hipStream_t with = reinterpret_cast<hipStream_t>(beside);
-    note_caller_stream(c, with);
-    if (c->aux_probed && c->aux_settled_beside == with) return 0;
-    if (const auto err = settle_side_stream(&c->aux, with, &c->aux_retired, &c->aux_collisions); err != hipSuccess) return static_cast<int>(err);
-    c->aux_probed = true, c->aux_settled_beside = with;
+    if (stream_is_capturing(with)) return NB_ERR_INVALID_ARGUMENT;  // (the probe synchronises streams)
+    const StreamNote* known = find_note(c, with);
+    note_stream(c, with, /*need_aux=*/true, /*fresh_look=*/known != nullptr && known->aux_beside);  // (asked again for a stream already settled: look afresh -- a recycled handle)
     return 0;
-}
-
-int nb_comm_replace_side_stream(nb_comm_t comm) {  // (experiments: how much does the placement of the second stream matter?)
-    NB_KEEP_RAND_STREAM;
-    Comm* c = as_comm(comm);
-    if (c == nullptr) return NB_ERR_INVALID_ARGUMENT;
-    DeviceScope scope(c->device);
-    if (c->aux != nullptr) {
-        (void)hipStreamSynchronize(c->aux);
-        c->aux_retired.push_back(c->aux);
-        c->aux = nullptr;
-    }
-    c->aux_probed = false;
-    return static_cast<int>(create_side_stream(&c->aux));
 }
 
 int nb_comm_caller_stream_placement(nb_comm_t comm, int* badly_placed) {
     Comm* c = as_comm(comm);
     if (c == nullptr || badly_placed == nullptr) return NB_ERR_INVALID_ARGUMENT;
-    *badly_placed = !c->caller_checked ? -1 : (c->caller_bad ? 1 : 0);
+    const StreamNote* note = c->seen.empty() ? nullptr : find_note(c, c->last_caller);
+    *badly_placed = note == nullptr ? -1 : note->placement;
+    return 0;
+}
+
+int nb_comm_last_enqueue_ms(nb_comm_t comm, double* milliseconds) {
+    Comm* c = as_comm(comm);
+    if (c == nullptr || milliseconds == nullptr) return NB_ERR_INVALID_ARGUMENT;
+    *milliseconds = c->last_enqueue_ms;
     return 0;
 }
 
@@ -1411,6 +1315,9 @@ int nb_comm_stream_create(nb_comm_t comm, nb_stream_t* stream) {
     // goes, so that the pool moves on; with one rank there is no RCCL and nothing to avoid)
     const auto err = c->world > 1 ? settle_side_stream(&made, nullptr, &c->aux_retired, nullptr) : hipStreamCreateWithFlags(&made, hipStreamNonBlocking);
     if (err != hipSuccess) return static_cast<int>(err);
+    // the step takes this stream's placement from here (no probe inside a step); a note left by an earlier stream of the same handle goes
+    c->seen.erase(std::remove_if(c->seen.begin(), c->seen.end(), [&](const StreamNote& n) { return n.stream == made; }), c->seen.end());
+    if (std::find(c->placed.begin(), c->placed.end(), made) == c->placed.end()) c->placed.push_back(made);
     *stream = made;
     return 0;
 }
@@ -1460,7 +1367,7 @@ static int allgather_one(nb_comm_t comm, void* positions, unsigned num_bodies, s
     Comm* c = as_comm(comm);
     if (c == nullptr || positions == nullptr || c->group.size() != 1 || num_bodies % static_cast<unsigned>(c->world)) return NB_ERR_INVALID_ARGUMENT;
     if (c->world == 1) return 0;
-    if (c->loopback) return NB_ERR_UNSUPPORTED;  // (a collective over the nominal world has no one-rank form)
+    if (c->self_peers) return NB_ERR_UNSUPPORTED;  // (a collective over a nominal world has no one-rank form)
     Rccl* lib = rccl();
     if (lib == nullptr) return NB_ERR_UNSUPPORTED;
     DeviceScope  scope(c->device);

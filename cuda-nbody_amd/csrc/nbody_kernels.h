@@ -165,6 +165,10 @@ size_t device_memory_budget();
 // step, so that a benchmark can time the two separately; nullptr = none (defined in nbody_capi.hip)
 hipEvent_t pair_probe_event();
 
+// Tests of the out-of-memory fall-backs: nb_alloc hands the runtime a request no device can serve for anything above this many
+// bytes (0 = no limit).  libnbody_hip.so has no way to set it; the lab library's nb_set_alloc_limit does (defined in nbody_capi.hip).
+std::atomic<size_t>& alloc_limit();
+
 // nb_set_pair_plan_override: 0 = automatic (defined in nbody_capi.hip; the multi-GPU layer honours it for its tiles too)
 void pair_plan_overrides(int* vectors_per_lane, int* waves, int* splits);
 

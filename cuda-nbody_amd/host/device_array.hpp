@@ -27,7 +27,11 @@ template <typename T> class DeviceArray {
         if (status == NB_ERR_OUT_OF_MEMORY) throw DeviceBadAlloc{};
         hip_check(status, "nb_alloc");
         ptr_ = static_cast<T*>(p);
+        // cleared AND the clear complete before the constructor returns: nb_memset is asynchronous on the null stream, and the consumers
+        // of this memory run on non-blocking streams that the null stream orders nothing against (a sharded body system's shards;
+        // round-5 review: a late clear could wipe sums a kernel had already written -- GB-sized workspaces take milliseconds to clear)
         hip_check(nb_memset(ptr_, 0, n * sizeof(T), nullptr), "nb_memset");
+        hip_check(nb_stream_synchronize(nullptr), "nb_stream_synchronize");
     }
     DeviceArray(const DeviceArray&)                    = delete;
     auto operator=(const DeviceArray&) -> DeviceArray& = delete;

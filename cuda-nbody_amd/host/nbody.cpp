@@ -10,7 +10,7 @@
 #include "compute.hpp"
 #include "integrate_nbody_hip.hpp"
 
-#include "../../include/nbody_hip_tuning.h"  // (the --alloc-limit-mib test hook)
+#include <dlfcn.h>  // (the --alloc-limit-mib test hook lives in the lab library: looked up, never linked)
 
 #include <charconv>
 #include <cstdio>
@@ -89,7 +89,7 @@ Options:
   --workspace-mib UINT        Spend at most this many MiB on that workspace (the pair tournament is then cut into slices that share
                               one region of reaction planes; default: what the library asks for, at most a third of the device's memory)
   --inject-error FLOAT        Test hook: added to body 0's x of the fast result before --compare checks it
-  --alloc-limit-mib UINT      Test hook: device allocations above this many MiB are refused (the out-of-memory fall-backs)
+  --alloc-limit-mib UINT      Test hook (needs LD_PRELOAD=libnbody_hip_lab.so): device allocations above this many MiB are refused
 )";
 
 template <typename I> auto parse_number(std::string_view text, I& out) -> bool {
@@ -259,7 +259,13 @@ auto main(int argc, char** argv) -> int {
         nbody_hip::integration_mode() = cmd_options.mode;
         nbody_hip::use_workspace()    = !cmd_options.no_workspace;
         nbody_hip::workspace_cap_bytes() = cmd_options.workspace_mib << 20;
-        if (cmd_options.alloc_limit_mib != 0) (void)nb_set_alloc_limit(cmd_options.alloc_limit_mib << 20);
+        if (cmd_options.alloc_limit_mib != 0) {
+            // nb_set_alloc_limit is exported by libnbody_hip_lab.so only (include/nbody_hip_lab.h): the tests preload that library
+            using SetLimit   = int (*)(std::size_t);
+            const auto limit = reinterpret_cast<SetLimit>(dlsym(RTLD_DEFAULT, "nb_set_alloc_limit"));
+            if (limit == nullptr) throw std::invalid_argument("--alloc-limit-mib is a test hook of the lab library: run with LD_PRELOAD=libnbody_hip_lab.so");
+            (void)limit(cmd_options.alloc_limit_mib << 20);
+        }
 
         const auto compare_to_cpu = (cmd_options.compare || cmd_options.qatest) && (!cmd_options.cpu);
         const auto headless_run   = cmd_options.benchmark || compare_to_cpu || cmd_options.steps > 0 || !cmd_options.dump.empty();

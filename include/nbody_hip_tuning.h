@@ -1,8 +1,11 @@
 /*
- * nbody_hip_tuning.h -- the lab bench of libnbody_hip.so: plan overrides for tuning sweeps, the kernel-time projection of one
- * rank of a multi-GPU step, a probe event between the two kernels of a pairwise step, counters for tests; round 5: the REAL RCCL on
- * a one-GPU box (a self-loop with every byte checked, a loopback rank that steps as rank r of a nominal G-rank communicator) and
- * what a communicator can say about its last step (host-order trace, executed work, hardware-queue collisions of its second stream).
+ * nbody_hip_tuning.h -- what libnbody_hip.so exports beyond the drop-in boundary: plan overrides for tuning sweeps and tests, a probe
+ * event between the two kernels of a pairwise step (bench.py times the headline kernel with it), counters for tests, and what a
+ * communicator can say about its last step (host-order trace, host enqueue time, executed work, the RCCL it is bound to,
+ * hardware-queue collisions of its second stream), and the hooks bench.py's own lines use on the
+ * product's communicators (a rank's kernels alone, the reaction leg alone, the order of the diagonal).  The lab bench proper -- the real RCCL on a one-GPU box (self-test, loopback rank,
+ * in-process world), the stream-placement A/B hook, the allocation-failure hook -- moved to nbody_hip_lab.h in
+ * round 6 and is exported by libnbody_hip_lab.so only.
  *
  * NOT part of the drop-in boundary (that is nbody_hip.h: what a maintainer of the reference binds).  Everything declared here
  * is PROCESS-GLOBAL state and NOT THREAD-SAFE against steps running concurrently: an override set while another thread is
@@ -55,44 +58,8 @@ NB_API int nb_emulate_pair_rank_f64(double* new_positions, const double* old_pos
 NB_API int nb_comm_reaction_exchange_f32(nb_comm_t comm, unsigned num_bodies, nb_stream_t stream);
 NB_API int nb_comm_reaction_exchange_f64(nb_comm_t comm, unsigned num_bodies, nb_stream_t stream);
 
-/* ---- the REAL transport on a one-GPU box.  RCCL refuses two ranks on one device, so everything with more than one rank is
- * tested against a transport double (tests/fake_rccl); what one GPU can still prove against the real library is the binding
- * itself -- the hand-resolved entry points, the dlopen inside whatever process this is, the stream and event semantics.
- * nb_comm_selftest_open: a communicator of ONE rank that does own an RCCL communicator (nb_comm_init_rank binds no transport
- * for a world of one); `id` from nb_comm_unique_id.  nb_comm_selftest_f32: on that communicator, `bytes` of a known pattern
- * produced on `stream`; on the communicator's exchange stream, after the `ready` event: GroupStart, Send(to self),
- * Recv(from self), GroupEnd, the tile's event, which `stream` waits for before it reads the bytes back; then ncclAllGather out
- * of place and in place the same way.  Returns 0 when every call was accepted and every byte arrived; the report says which
- * call refused (status = NB_ERR_RCCL_BASE + ncclResult_t) or how many bytes differ.  Blocking.
- * nb_comm_self_transfer_f32: the measuring form (tools/exchange_contention.py): `rounds` self send/recv pairs of `count` floats
- * each in one group or a group per round, asynchronous, `begin` / `end` recorded on the exchange stream around them.
- * nb_comm_transport_info: version (ncclGetVersion) and file of the RCCL a communicator is bound to (0 / "" for a world of one
- * made by nb_comm_init_rank: none bound). */
-typedef struct nb_comm_selftest {
-    int    rccl_version;
-    int    send_recv_status, all_gather_status;
-    float  send_recv_ms, all_gather_ms;            /* on the exchange stream, events around the calls */
-    size_t send_recv_wrong_bytes, all_gather_wrong_bytes;
-    char   refused_call[64];
-    char   library_path[256];
-} nb_comm_selftest_t;
-NB_API int nb_comm_selftest_open(nb_comm_t* comm, const void* id /* NB_COMM_ID_BYTES */);
-/* A LOOPBACK rank: rank `nominal_rank` of a `nominal_world`-rank communicator whose RCCL communicator has one rank -- every
- * send goes to, every receive comes from, the rank itself.  nb_sharded_step_* on it launches exactly the kernels, RCCL calls,
- * events and waits of that rank of a real multi-GPU step, on one GPU, with the real RCCL kernels competing for the chip; what
- * "arrives" is the rank's own data, so the positions are meaningless after the first step and only the TIME means anything:
- * a real step minus what the xGMI links would add (tools/exchange_contention.py, bench.py's one-GPU projection).
- * nb_comm_set_workspace stays the collective it is (the notes travel to the rank itself). */
-NB_API int nb_comm_loopback_open(nb_comm_t* comm, const void* id /* NB_COMM_ID_BYTES */, int nominal_world, int nominal_rank);
-/* An IN-PROCESS world: `world` ranks in this process, all on the current device, sharing ONE real one-rank RCCL communicator -- every
- * transfer a self-transfer, rank a's send routed to rank b's receive by the order in which the library issues them (RCCL matches the
- * sends and receives of one peer first in, first out).  nb_sharded_step_all_* on these comms is the full G-rank step -- even G, the
- * split rectangle and all -- through the product's own calls into the REAL library, comparable with the CPU path
- * (tests/test_comm_fake_rccl.py runs its `all` cases this way too).  Destroy every rank with nb_comm_destroy. */
-NB_API int nb_comm_inprocess_open_all(nb_comm_t* comms /* [world] */, int world, const void* id /* NB_COMM_ID_BYTES */);
-NB_API int nb_comm_selftest_f32(nb_comm_t comm, size_t bytes, nb_stream_t stream, nb_comm_selftest_t* report);
-NB_API int nb_comm_self_transfer_f32(nb_comm_t comm, const float* src, float* dst, size_t count, int rounds, int one_group, nb_stream_t after,
-                                     nb_event_t begin, nb_event_t end);
+/* Version (ncclGetVersion) and file of the RCCL a communicator is bound to (0 / "" for a world of one made by nb_comm_init_rank: none
+ * bound) -- bench.py's N > 1 line reports it per rank. */
 NB_API int nb_comm_transport_info(nb_comm_t comm, int* rccl_version, char* library_path, size_t path_bytes);
 
 /* What this rank EXECUTES in one pairwise multi-GPU step (the communicator's layout must be pairwise for this system: NB_ERR_UNSUPPORTED
@@ -104,22 +71,25 @@ NB_API int nb_comm_pair_work_f64(nb_comm_t comm, unsigned num_bodies, unsigned l
 /* The second compute stream of a pairwise multi-GPU step must run BESIDE the caller's stream; the HIP runtime lets streams share a
  * hardware queue once a process has more than a few, and two streams on one queue run one after the other.  A communicator
  * probes its side stream against the caller's the first time the two meet and replaces it while they collide (csrc/nbody_comm.hip,
- * settle_side_stream; NBODY_AUX_PROBE=0 switches that off).  *collisions: how many candidates were replaced; -1: not probed yet. */
+ * note_stream / settle_side_stream; NBODY_AUX_PROBE=0 switches every probe off).  *collisions: how many candidates were replaced; -1: not probed yet. */
 NB_API int nb_comm_side_stream_collisions(nb_comm_t comm, int* collisions);
-/* ... and the same probe NOW, against the stream the caller is going to step on (else it runs inside the first pairwise step with two or
- * more partners: two stream synchronisations and ~0.2 ms, once). */
+/* ... and the same probe NOW, against the stream the caller is going to step on (else it runs inside the first step that meets that
+ * stream -- once per stream and rank, never while the stream is capturing, never for a stream made by nb_comm_stream_create: two stream
+ * synchronisations and ~0.2 ms).  Asked again for a stream already settled, it looks afresh (a recycled stream handle). */
 NB_API int nb_comm_settle_side_stream(nb_comm_t comm, nb_stream_t beside);
 /* *badly_placed: 1 = the stream the caller stepped on last is the null stream or shares its hardware queue -- with RCCL active such a
  * rank steps ~40 % slower (profiles/round5_hw_queue_collision.txt): step on a stream from nb_comm_stream_create instead; 0 = fine;
- * -1 = no step with more than one rank yet. */
+ * -1 = not looked at (no step with more than one rank yet, the stream was capturing, or NBODY_AUX_PROBE=0). */
 NB_API int nb_comm_caller_stream_placement(nb_comm_t comm, int* badly_placed);
-/* Retire the second compute stream and make another (experiments on how much its placement matters: tools/side_stream_placement.py). */
-NB_API int nb_comm_replace_side_stream(nb_comm_t comm);
-
 /* What this rank's LAST pairwise multi-GPU step enqueued, in host order, one item per line: "forces diagonal-early", "forces
  * rectangle s", "fold s", "send reaction s", "forces diagonal-late", "finish" (empty before the first such step).  Tests read the
  * ORDER from it: every reaction send is enqueued before the rank's last force kernel. */
 NB_API int nb_comm_last_step_trace(nb_comm_t comm, char* text, size_t bytes);
+
+/* What the HOST needed to enqueue the last nb_sharded_step_* call this rank took part in (wall clock of the whole call, all its local
+ * ranks: with several local ranks their kernels are enqueued by one thread each, the RCCL groups by the caller).  A step whose enqueue
+ * takes longer than its kernels is bound by the host: the CLI's --numdevices run and bench.py report it as host_enqueue_ms_per_step. */
+NB_API int nb_comm_last_enqueue_ms(nb_comm_t comm, double* milliseconds);
 
 /* An event recorded between the forces kernel and the finish kernel of every ONE-GPU pairwise step from now on (NULL = none):
  * bench.py times the two kernels of the headline step separately with it, after the timed region. */
@@ -128,11 +98,6 @@ NB_API int nb_set_pair_probe_event(nb_event_t event);
 /* The device memory the library assumes when it decides whether a workspace is affordable (at most a third of it is ever asked
  * for): 0 = the device's own total; tests of the guard set a small figure. */
 NB_API int nb_set_memory_budget(size_t bytes);
-
-/* Tests of the out-of-memory fall-backs (halve the workspace and ask again; step without one): every nb_alloc request above
- * `bytes` is refused BY THE RUNTIME (the request is replaced by one no device can serve), 0 = no limit.  The CLI's
- * --alloc-limit-mib sets it. */
-NB_API int nb_set_alloc_limit(size_t bytes);
 
 /* How many (kernel, device) pairs have been granted more than 64 KiB of dynamic LDS so far (the opt-in is made once per
  * kernel instantiation and device, on first use, and before any graph capture). */

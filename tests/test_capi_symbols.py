@@ -1,7 +1,10 @@
-"""CPU test: libnbody_hip.so loads and exports every symbol include/nbody_hip.h (the drop-in boundary) and
-include/nbody_hip_tuning.h (process-global tuning / test hooks) declare (no compute calls)."""
+"""CPU test: libnbody_hip.so loads and exports EXACTLY the symbols include/nbody_hip.h (the drop-in boundary) and
+include/nbody_hip_tuning.h (process-global tuning / introspection hooks) declare; libnbody_hip_lab.so -- the same object files plus
+csrc/nbody_comm_lab.hip -- exports those and include/nbody_hip_lab.h (the lab bench) on top (no compute calls)."""
 import os
 import re
+import subprocess
+import sys
 
 from conftest import ROOT
 
@@ -29,20 +32,53 @@ def test_library_exports_every_declared_symbol(pkg):
     assert sorted(pkg.SIGNATURES) == names
 
 
+def exported_symbols(path):
+    out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+    return sorted(line.split()[-1] for line in out.splitlines() if " T " in line)
+
+
 def test_tuning_header_is_separate_and_exported(pkg):
-    """The lab bench (plan overrides, the one-rank projection hook, the probe event, the memory budget, the LDS opt-in counter)
-    lives in its own header: the boundary header declares none of it, the library exports all of it, and the binding's second
-    table covers it exactly."""
+    """Plan overrides, the one-rank projection hook, the probe event, the memory budget, the LDS opt-in counter and what a communicator
+    says about its last step live in their own header: the boundary header declares none of it, the library exports all of it, and
+    the binding's second table covers it exactly."""
     lib = pkg.lib()
     tuning = declared_symbols("nbody_hip_tuning.h")
     boundary = declared_symbols()
     assert tuning and not set(tuning) & set(boundary)
-    for hook in ("nb_set_plan_override", "nb_set_pair_plan_override", "nb_comm_set_pair_min_slice", "nb_emulate_pair_rank_f32", "nb_lds_optin_count"):
+    for hook in ("nb_set_plan_override", "nb_set_pair_plan_override", "nb_comm_set_pair_min_slice", "nb_emulate_pair_rank_f32", "nb_lds_optin_count", "nb_comm_last_enqueue_ms"):
         assert hook in tuning and hook not in boundary
     assert not [n for n in tuning if not hasattr(lib, n)]
     assert sorted(pkg.TUNING_SIGNATURES) == tuning
     text = open(os.path.join(ROOT, "include", "nbody_hip_tuning.h")).read()
     assert "PROCESS-GLOBAL" in text and "NOT THREAD-SAFE" in text
+
+
+def test_product_library_exports_the_two_headers_and_nothing_else(pkg):
+    """Round 6: the lab bench (real-RCCL self-test, loopback rank, in-process world, stream-placement A/B hook, allocation-failure hook)
+    is NOT in libnbody_hip.so any more -- a host links no test scaffolding.  The product's dynamic symbol table is exactly
+    nbody_hip.h + nbody_hip_tuning.h; the lab library's is that plus nbody_hip_lab.h; the lab header repeats nothing."""
+    boundary, tuning, lab = declared_symbols(), declared_symbols("nbody_hip_tuning.h"), declared_symbols("nbody_hip_lab.h")
+    assert lab and not set(lab) & (set(boundary) | set(tuning))
+    for hook in ("nb_comm_selftest_open", "nb_comm_selftest_f32", "nb_comm_self_transfer_f32", "nb_comm_loopback_open", "nb_comm_inprocess_open_all",
+                 "nb_comm_replace_side_stream", "nb_set_alloc_limit"):
+        assert hook in lab
+    assert sorted(pkg.LAB_SIGNATURES) == lab
+    assert exported_symbols(pkg.LIB_PATH) == sorted(boundary + tuning)
+    assert exported_symbols(pkg.LAB_LIB_PATH) == sorted(boundary + tuning + lab)
+    assert len(exported_symbols(pkg.LIB_PATH)) < 98  # (what round 5's library exported)
+    # the product's comm translation unit does not even mention the lab's worlds
+    comm = open(os.path.join(ROOT, "cuda-nbody_amd", "csrc", "nbody_comm.hip")).read()
+    for word in ("inprocess", "nb_comm_selftest", "nb_comm_loopback_open", "nb_set_alloc_limit"):
+        assert word not in comm, word
+    # a process works with one of the two: after the product library is in, the binding refuses to switch
+    pkg.lib()
+    if not pkg.is_lab():
+        try:
+            pkg.use_lab()
+        except RuntimeError:
+            pass
+        else:
+            raise AssertionError("use_lab() after lib() must refuse")
 
 
 def test_host_side_argument_errors_need_no_gpu(pkg):
@@ -59,26 +95,53 @@ def test_host_side_argument_errors_need_no_gpu(pkg):
 
 
 def test_round5_hooks_reject_bad_arguments_on_the_host(pkg):
-    """The tuning header's round-5 entry points (the real-RCCL self-test, the loopback rank, what a communicator says about its last
-    step) check their arguments before they touch HIP or RCCL: no GPU needed, nothing loaded."""
+    """What a communicator says about its last step (tuning header) checks its arguments before it touches HIP or RCCL: no GPU
+    needed, nothing loaded."""
     import ctypes
 
     lib = pkg.lib()
-    comm, word, report = ctypes.c_void_p(), ctypes.c_int(0), pkg.CommSelftest()
+    word = ctypes.c_int(0)
     evals = ctypes.c_ulonglong(0)
+    ms = ctypes.c_double(0)
     text = ctypes.create_string_buffer(64)
-    assert lib.nb_comm_selftest_open(None, None) == 10001 and lib.nb_comm_selftest_open(ctypes.byref(comm), None) == 10001
-    assert lib.nb_comm_loopback_open(ctypes.byref(comm), text, 1, 0) == 10001   # a nominal world of one is no world
-    assert lib.nb_comm_loopback_open(ctypes.byref(comm), None, 8, 4) == 10001   # no id
-    assert lib.nb_comm_loopback_open(ctypes.byref(comm), text, 8, 8) == 10001   # no such rank
-    assert comm.value is None
-    assert lib.nb_comm_selftest_f32(None, 1024, None, ctypes.byref(report)) == 10001
-    assert lib.nb_comm_self_transfer_f32(None, None, None, 0, 0, 1, None, None, None) == 10001
     assert lib.nb_comm_transport_info(None, ctypes.byref(word), text, len(text)) == 10001
     assert lib.nb_comm_pair_work_f32(None, 262144, ctypes.byref(evals), ctypes.byref(word)) == 10001
     assert lib.nb_comm_last_step_trace(None, text, len(text)) == 10001
+    assert lib.nb_comm_last_enqueue_ms(None, ctypes.byref(ms)) == 10001
     assert lib.nb_comm_side_stream_collisions(None, ctypes.byref(word)) == 10001 and lib.nb_comm_settle_side_stream(None, None) == 10001
-    assert lib.nb_set_late_diagonal(-1) == 10001 and lib.nb_set_alloc_limit(0) == 0
+    assert lib.nb_set_late_diagonal(-1) == 10001
+
+
+LAB_ARGUMENT_CHECKS = """
+import ctypes, sys
+sys.path.insert(0, sys.argv[1])
+import __graft_entry__ as entry
+pkg = entry.load_package()
+pkg.use_lab()
+lib = pkg.lib()
+assert pkg.is_lab() and lib._name.endswith("libnbody_hip_lab.so")
+comm, report = ctypes.c_void_p(), pkg.CommSelftest()
+text = ctypes.create_string_buffer(64)
+assert lib.nb_comm_selftest_open(None, None) == 10001 and lib.nb_comm_selftest_open(ctypes.byref(comm), None) == 10001
+assert lib.nb_comm_loopback_open(ctypes.byref(comm), text, 1, 0) == 10001   # a nominal world of one is no world
+assert lib.nb_comm_loopback_open(ctypes.byref(comm), None, 8, 4) == 10001   # no id
+assert lib.nb_comm_loopback_open(ctypes.byref(comm), text, 8, 8) == 10001   # no such rank
+assert comm.value is None
+assert lib.nb_comm_inprocess_open_all(None, 8, text) == 10001 and lib.nb_comm_inprocess_open_all(ctypes.byref(comm), 1, text) == 10001
+assert lib.nb_comm_selftest_f32(None, 1024, None, ctypes.byref(report)) == 10001
+assert lib.nb_comm_self_transfer_f32(None, None, None, 0, 0, 1, None, None, None) == 10001
+assert lib.nb_comm_replace_side_stream(None) == 10001
+assert lib.nb_set_alloc_limit(0) == 0
+assert lib.nb_error_string(10001) == b"NB_ERR_INVALID_ARGUMENT" and lib.nb_set_plan_override(0, 0, 0) == 0   # (the product's own exports are all there too)
+print("lab ok")
+"""
+
+
+def test_lab_hooks_reject_bad_arguments_on_the_host():
+    """The lab header's entry points (libnbody_hip_lab.so), in a process of their own: a process loads one of the two libraries."""
+    env = {k: v for k, v in os.environ.items() if k != "NBODY_HIP_LAB"}
+    done = subprocess.run([sys.executable, "-c", LAB_ARGUMENT_CHECKS, ROOT], capture_output=True, text=True, timeout=120, env=env)
+    assert done.returncode == 0 and "lab ok" in done.stdout, done.stderr[-2000:]
 
 
 def test_strict_translation_unit_has_no_fused_multiply_add():
@@ -503,7 +566,8 @@ def test_makefile_rebuilds_an_object_when_any_header_it_includes_changes():
         return seen
 
     sources = sorted(f for f in os.listdir(csrc) if f.endswith(".hip") and f.startswith("nbody_"))
-    objects = re.search(r"^OBJS\s*:=\s*(.*)$", mk, re.M).group(1).split()
+    objects = re.search(r"^OBJS\s*:=\s*(.*)$", mk, re.M).group(1).split() + re.search(r"^LAB_OBJS\s*:=\s*(.*)$", mk, re.M).group(1).split()
+    assert re.search(r"^-include \$\(LAB_OBJS:\.o=\.d\)$", mk, re.M)
     assert {s[:-4] + ".o" for s in sources} == set(objects), (sources, objects)
     for src in sources:
         with open(os.path.join(csrc, src[:-4] + ".d")) as fh:
@@ -519,7 +583,7 @@ def test_makefile_rebuilds_an_object_when_any_header_it_includes_changes():
         os.utime(header, None)
         assert subprocess.run(["make", "-q", "-C", csrc], capture_output=True).returncode == 1
         would = subprocess.run(["make", "-n", "-C", csrc], capture_output=True, text=True).stdout
-        for obj in ("nbody_comm.o", "nbody_pair.o", "nbody_capi.o", "nbody_fast.o", "nbody_strict.o"):
+        for obj in ("nbody_comm.o", "nbody_comm_lab.o", "nbody_pair.o", "nbody_capi.o", "nbody_fast.o", "nbody_strict.o"):
             assert f"-o {obj}" in would, obj
     finally:
         os.utime(header, ns=(stat.st_atime_ns, stat.st_mtime_ns))
@@ -542,7 +606,7 @@ def test_rccl_entry_points_match_the_rccl_header_at_compile_time(tmp_path):
         pytest.skip("no RCCL header in this image")
     done = subprocess.run(["make", "-s", "-C", csrc, "check-rccl-abi"], capture_output=True, text=True)
     assert done.returncode == 0, done.stderr[-3000:]
-    with open(os.path.join(csrc, "nbody_comm.hip")) as fh:
+    with open(os.path.join(csrc, "nbody_comm_internal.h")) as fh:  # (the binding's struct lives in the header the two comm units share)
         product = fh.read()
     assert '#include "rccl_api.h"' in product and "nb_rccl::SendFn" in product and "(*Send)(" not in product  # (no second spelling of the types)
     for name in ("rccl_api.h", "rccl_abi_check.cpp"):

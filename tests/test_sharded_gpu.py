@@ -177,6 +177,16 @@ def test_cli_numdevices_one_is_the_single_gpu_run(tmp_path):
         raw = np.fromfile(dump, dtype=dtype)
         g = load_golden(n, tag)
         assert raw[:4 * n].tobytes() == g["pos_10"].tobytes() and raw[4 * n:].tobytes() == g["vel_10"].tobytes()
+    # FAST with a LARGE workspace (262 144 bodies: 384 MiB of reaction slots, milliseconds to clear): the shard's workspace is cleared
+    # on the null stream and consumed on the shard's own non-blocking stream -- the clear must be over before the first step (round-5
+    # review).  One shard = nb_integrate_ws_* with the very workspace the default body system owns: the same bits.
+    big = {}
+    for name, flags in (("sharded", ["--numdevices=1"]), ("default", [])):
+        dump = tmp_path / f"fast_{name}.bin"
+        r = subprocess.run([cli, "--numbodies=262144", "--steps=2", f"--dump={dump}", *flags], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr
+        big[name] = np.fromfile(dump, dtype=np.float32)
+    assert np.isfinite(big["sharded"]).all() and big["sharded"].tobytes() == big["default"].tobytes()
     r = subprocess.run([cli, "--benchmark", "--numbodies=4096", "--devices=0", "-i", "4"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "billion interactions per second" in r.stdout
     r = subprocess.run([cli, "--compare", "--numbodies=2048", "--numdevices=1"], capture_output=True, text=True, timeout=300)

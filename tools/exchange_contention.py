@@ -1,6 +1,6 @@
 """What the exchange of a multi-GPU step costs NEXT TO the kernels that ship, measured on one GPU with the real RCCL (round 5).
 
-A LOOPBACK rank (nb_comm_loopback_open, tuning header) is rank r of a nominal G-rank communicator whose RCCL communicator has one
+A LOOPBACK rank (nb_comm_loopback_open, lab header) is rank r of a nominal G-rank communicator whose RCCL communicator has one
 rank: nb_sharded_step_f32 on it launches exactly the kernels, RCCL groups, events and waits of that rank of a real G-GPU step --
 the position tiles and reaction arrays go through ncclSend / ncclRecv to the rank itself, so RCCL's kernels compete with
 pair_forces for the chip as they would on a node; only the xGMI transfer time is missing (a local copy instead).  Per system:
@@ -43,6 +43,7 @@ def main():
     from bench_support import make_bodies
 
     pkg = entry.load_package()
+    pkg.use_lab()  # (the lab library: include/nbody_hip_lab.h)
     lib = pkg.lib()
     pkg.check(lib.nb_set_device(0), "nb_set_device")
     dtype = np.float64 if args.fp64 else np.float32

@@ -4,7 +4,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as entry
 from bench_support import make_bodies
-pkg = entry.load_package(); lib = pkg.lib(); pkg.check(lib.nb_set_device(0))
+pkg = entry.load_package(); pkg.use_lab(); lib = pkg.lib(); pkg.check(lib.nb_set_device(0))
 n, G, r = 262144, 8, 4
 pkg.check(lib.nb_set_softening_sq_f32(np.float32(0.01)))
 dt, damping = np.float32(0.016), np.float32(1.0)

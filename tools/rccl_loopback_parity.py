@@ -38,6 +38,7 @@ def main():
     import __graft_entry__ as entry
 
     pkg = entry.load_package()
+    pkg.use_lab()  # (the lab library: include/nbody_hip_lab.h)
     lib = pkg.lib()
     oracle = entry.load_oracle().Oracle()
     pkg.check(lib.nb_set_device(0), "nb_set_device")

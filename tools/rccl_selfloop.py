@@ -27,6 +27,7 @@ def main():
     import __graft_entry__ as entry
 
     pkg = entry.load_package()
+    pkg.use_lab()  # (the lab library: include/nbody_hip_lab.h)
     lib = pkg.lib()
     pkg.check(lib.nb_set_device(0), "nb_set_device")
     t0 = time.perf_counter()

@@ -29,6 +29,7 @@ def main():
     from bench_support import make_bodies
 
     pkg = entry.load_package()
+    pkg.use_lab()  # (the lab library: include/nbody_hip_lab.h)
     lib = pkg.lib()
     pkg.check(lib.nb_set_device(0))
     n, G, r = 262144, 8, 4
