@@ -662,16 +662,19 @@ template <typename T> int reaction_exchange(const std::vector<Comm*>& locals, co
 // ---- the crew: who enqueues a step over several local ranks ---------------------------------------------------------------------
 // One process driving G devices (nb_comm_init_all: `nbody --numdevices G`, BodySystemHIPSharded -- the process model SURVEY 8(e)
 // names) used to enqueue every rank's kernels, events and RCCL calls from the calling thread: 0.13-0.19 ms per rank and step
-// (measured, a loopback rank of 8 at 262 144 bodies: profiles/round6_graph_capture_probe.txt), i.e. ~1.2 ms for 8 ranks against a
+// (measured, a loopback rank of 8 at 262 144 bodies: profiles/round6_graph_capture_and_host_enqueue.txt), i.e. ~1.2 ms for 8 ranks against a
 // 1.3 ms step -- host-bound.  Capturing a rank's step into a hipGraph was tried first (same file): RCCL's send/recv groups ARE
 // captured and replay (the position exchange alone: 3 us of host time per replay; the one-sided step: 4 us per step at the same
 // stream time), but the pairwise step replays in 2.41 ms instead of 1.28 -- the graph runs the two compute streams' branches one
 // after the other, the very figure of two streams on one hardware queue -- and two pairwise steps in one capture end in a
 // segmentation fault inside hipStreamEndCapture.  So the step stays eager and its per-rank parts are enqueued IN PARALLEL:
 // a crew of persistent threads, one per local rank, made the first time a group of several ranks steps and kept until the last
-// of its communicators goes.  The RCCL calls of a round stay one group over the local ranks, issued by the calling thread
-// between the crew's phases (a group that misses a peer hangs; and ranks that share an RCCL communicator cannot call into it
-// concurrently at all).  The crew spins for up to ~0.3 ms between phases and steps, then sleeps on a condition variable.
+// of its communicators goes.  Two forms (sharded_step_locals): ranks that each own an RCCL communicator -- a real node -- are
+// stepped INDEPENDENTLY, a thread taking one rank's whole step including its RCCL groups (RCCL's thread-per-device model: what
+// one process per GPU does, in threads); ranks that SHARE a communicator (the lab's in-process world, whose transfers are matched
+// by the order of one thread's calls) are stepped in PHASES, the kernels and events of a phase by the crew, the RCCL groups of a
+// round -- one group over all local ranks -- by the calling thread between the phases.  The crew spins for up to ~0.3 ms between
+// phases and steps, then sleeps on a condition variable.
 // NBODY_STEP_THREADS=0: the calling thread does everything (A/B timings; the same calls in the same per-rank order, so the
 // same bits -- tested).
 class StepCrew {
@@ -742,6 +745,14 @@ class StepCrew {
     bool                               quit_ = false;
 };
 
+// no two of these ranks share an RCCL communicator (ranks that do -- the lab's in-process world -- cannot call into it concurrently,
+// and their transfers are matched by the order of ONE thread's calls)
+bool ranks_own_their_transport(const std::vector<Comm*>& locals) {
+    for (const Comm* c : locals)
+        if (c->shared_nccl) return false;
+    return true;
+}
+
 bool crew_enabled() {
     static const bool on = [] {
         const char* v = std::getenv("NBODY_STEP_THREADS");
@@ -765,11 +776,36 @@ int for_each_rank(const std::vector<Comm*>& locals, const std::function<int(size
     return 0;
 }
 
+// NBODY_ENQUEUE_TRACE=1: the host time of each phase of a pairwise step, appended to the first local rank's trace as "host <ms> <phase>"
+// lines (tools/graph_capture_probe.py --what none prints them): where does the enqueue time of a step go?
+class PhaseClock {
+ public:
+    explicit PhaseClock(const std::vector<Comm*>& locals) : to_(enabled() ? locals.front() : nullptr), at_(std::chrono::steady_clock::now()) {}
+    void lap(const char* what) {
+        if (to_ == nullptr) return;
+        const auto now = std::chrono::steady_clock::now();
+        to_->trace += "host " + std::to_string(std::chrono::duration<double, std::milli>(now - at_).count()) + " " + what + "\n";
+        at_ = now;
+    }
+    static bool enabled() {
+        static const bool on = [] {
+            const char* v = std::getenv("NBODY_ENQUEUE_TRACE");
+            return v != nullptr && v[0] == '1';
+        }();
+        return on;
+    }
+
+ private:
+    Comm*                                 to_;
+    std::chrono::steady_clock::time_point at_;
+};
+
 template <typename T>
 int pair_sharded_step(const std::vector<Comm*>& locals, const PairShard& plan, T* const* new_pos, const T* const* old_pos, T* const* vel, unsigned num_bodies, T dt, T damping, T eps2, const nb_stream_t* streams) {
     if (rccl() == nullptr) return NB_ERR_UNSUPPORTED;
     const int G = locals.front()->world;
     std::vector<nb::FinishArgs<T>> finish(locals.size());
+    PhaseClock clock(locals);
     // phase 1, every rank at once: the early diagonal, the rectangles (each waiting for its tile) and their folds
     int rc = for_each_rank(locals, [&](size_t k) {
         Comm*       c = locals[k];
@@ -780,10 +816,12 @@ int pair_sharded_step(const std::vector<Comm*>& locals, const PairShard& plan, T
                                   reinterpret_cast<hipStream_t>(streams[k]), waiting, finish[k], c->aux, c->aux_begin, c->aux_done, kBeforeSends);
     });
     if (rc != 0) return rc;
+    clock.lap("kernels before the sends");
     // every reaction round is enqueued (each waits for the fold of its rectangle) BEFORE the ranks' last force kernel: the late half of the diagonal
     if (rc = reaction_exchange<T>(locals, plan); rc != 0) return rc;
+    clock.lap("reaction rounds");
     // phase 2, every rank at once: the late diagonal, the join of the second stream, the waits for what was received, the finish kernel
-    return for_each_rank(locals, [&](size_t k) {
+    rc = for_each_rank(locals, [&](size_t k) {
         Comm*       c = locals[k];
         DeviceScope scope(c->device);
         hipStream_t stream = reinterpret_cast<hipStream_t>(streams[k]);
@@ -798,6 +836,8 @@ int pair_sharded_step(const std::vector<Comm*>& locals, const PairShard& plan, T
         c->trace += "finish\n";
         return 0;
     });
+    clock.lap("late diagonal and finish");
+    return rc;
 }
 
 // What every rank of the communicator is known to have been lent: one process driving all ranks sees them all; one process
@@ -847,6 +887,15 @@ int sharded_step_locals(const std::vector<Comm*>& locals, T* const* new_pos, con
     const int      G       = locals.front()->world;
     const size_t   n_local = locals.size();
     const unsigned ni      = num_bodies / static_cast<unsigned>(G);
+    if (n_local > 1 && crew_enabled() && ranks_own_their_transport(locals)) {
+        // Every local rank has an RCCL communicator of its own (nb_comm_init_all on G devices): each thread of the crew takes ONE rank's
+        // whole step -- kernels, events AND its RCCL groups, a group per rank and round exactly as with one process per GPU (RCCL's
+        // thread-per-device model; the sends and receives of the ranks meet inside RCCL).  The host then needs what ONE rank needs
+        // (0.13-0.19 ms at 8 ranks and 262 144 bodies), whatever the number of devices.
+        return for_each_rank(locals, [&](size_t k) {
+            return sharded_step_locals<T>(std::vector<Comm*>{locals[k]}, new_pos + k, old_pos + k, vel + k, acc + k, num_bodies, dt, damping, block_size, mode, streams + k);
+        });
+    }
     bool           done_pairwise = false;
     {   // every rank of the COMMUNICATOR lent a large enough workspace (decided identically on every rank): pairs once, across the ranks too
         PairShard plan;
@@ -904,7 +953,10 @@ int sharded_step_locals(const std::vector<Comm*>& locals, T* const* new_pos, con
     std::vector<void*>       arrays(n_local);
     std::vector<hipStream_t> after(n_local);
     for (size_t k = 0; k < n_local; ++k) arrays[k] = new_pos[k], after[k] = reinterpret_cast<hipStream_t>(streams[k]);
-    return exchange_tiles(locals, arrays.data(), num_bodies, 4 * sizeof(T), Api<T>::nccl_type, after.data(), done_pairwise ? G / 2 : 0);
+    PhaseClock clock(locals);
+    const int  rc = exchange_tiles(locals, arrays.data(), num_bodies, 4 * sizeof(T), Api<T>::nccl_type, after.data(), done_pairwise ? G / 2 : 0);
+    clock.lap("position rounds");
+    return rc;
 }
 
 template <typename T>

@@ -45,6 +45,12 @@ template <std::floating_point T> class BodySystemHIP {
     // reference (everything there runs on stream 0); the sharded system steps on streams of its own -- see bodysystemhip_sharded.hpp.
     auto virtual stream() const noexcept -> nb_stream_t { return nullptr; }
 
+    // Extension: what the HOST needed to enqueue a step, averaged over the update() calls since the last reset (milliseconds; < 0 = this
+    // variant does not measure it).  The sharded system reports it (nb_comm_last_enqueue_ms): a step whose enqueue takes longer than
+    // its kernels is bound by the host, and `--benchmark --numdevices N` says so.
+    auto virtual host_enqueue_ms_per_step() const noexcept -> double { return -1.0; }
+    auto virtual reset_host_enqueue() noexcept -> void {}
+
     virtual ~BodySystemHIP() = default;
 
  protected:

@@ -2,6 +2,8 @@
 
 #include "integrate_nbody_hip.hpp"
 
+#include "../../include/nbody_hip_tuning.h"  // (nb_comm_last_enqueue_ms: what the host needed to enqueue a step)
+
 #include <exception>
 
 #include <cassert>
@@ -181,6 +183,7 @@ template <std::floating_point T> auto BodySystemHIPSharded<T>::update(T deltaTim
                                          nbody_hip::integration_mode(), streams.data());
     }
     hip_check(status, "nb_sharded_step_all");
+    if (double ms = 0; nb_comm_last_enqueue_ms(comms_.front(), &ms) == 0) enqueue_ms_ += ms, ++enqueue_steps_;
     std::swap(this->current_read_, this->current_write_);
 }
 

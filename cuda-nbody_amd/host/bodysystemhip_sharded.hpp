@@ -2,7 +2,7 @@
 //
 // New: the reference is single-GPU (NVIDIA's original sample had a -numdevices mode; this fork removed it, SURVEY
 // section 0).  Same interface as every other BodySystemHIP<T>, so ComputeHIP / Compute / the command line drive it
-// unchanged.  One process, one host thread, G devices: device g owns bodies [g*N/G, (g+1)*N/G) -- its velocities, its
+// unchanged.  One process, G devices (the library enqueues a step with one thread per device: csrc/nbody_comm.hip, StepCrew): device g owns bodies [g*N/G, (g+1)*N/G) -- its velocities, its
 // slice of each new position array -- and holds full-size position arrays; every update() is one
 // nb_sharded_step_all_* call (include/nbody_hip.h): per device the kernels of the own slice and of each position tile as
 // it arrives over RCCL / xGMI, then the tile exchange of the new positions.  STRICT mode is bit-identical to one GPU.
@@ -34,6 +34,8 @@ template <std::floating_point T> class BodySystemHIPSharded final : public BodyS
     auto stream() const noexcept -> nb_stream_t override { return shards_.empty() ? nullptr : shards_.front().stream; }
 
     auto nb_devices() const noexcept { return shards_.size(); }
+    auto host_enqueue_ms_per_step() const noexcept -> double override { return enqueue_steps_ == 0 ? -1.0 : enqueue_ms_ / static_cast<double>(enqueue_steps_); }
+    auto reset_host_enqueue() noexcept -> void override { enqueue_ms_ = 0, enqueue_steps_ = 0; }
 
  private:
     struct Shard {
@@ -48,6 +50,8 @@ template <std::floating_point T> class BodySystemHIPSharded final : public BodyS
     auto release() noexcept -> void;  // communicators and streams (the destructor's work; also allocate()'s when a constructor throws half-way)
     auto ensure_workspaces() -> void;  // (re)lends every shard what the current mode asks for
     int  workspace_mode_ = -1;
+    double        enqueue_ms_    = 0;  // host time of the nb_sharded_step_all_* calls since reset_host_enqueue()
+    unsigned long enqueue_steps_ = 0;
 
     std::vector<Shard>     shards_;
     std::vector<nb_comm_t> comms_;

@@ -110,6 +110,10 @@ auto Compute::update_params() -> void { compute_hip_->update_params(active_param
 auto Compute::run_benchmark(int nb_iterations) -> void {
     const auto milliseconds = compute_hip_->run_benchmark(nb_iterations, active_params_.time_step);
     print_benchmark_results(nb_iterations, milliseconds.count());
+    // several devices driven by this one process: is the HOST what bounds a step?  (an extra line, after the reference's three)
+    if (const double enqueue = compute_hip_->host_enqueue_ms_per_step(); enqueue >= 0) {
+        std::printf("= %.3f ms of host time to enqueue a step (host_enqueue_ms_per_step; %.3f ms per step on the devices)\n", enqueue, milliseconds.count() / static_cast<float>(nb_iterations));
+    }
 }
 
 auto Compute::use_graph(bool enable) -> void { compute_hip_->use_graph(enable); }

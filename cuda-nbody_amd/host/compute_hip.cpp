@@ -152,7 +152,9 @@ auto ComputeHIP::run_benchmark(int nb_iterations, float dt) -> Milliseconds {
             return get_milliseconds_passed();
         }
         start_event_.record(nbody.stream());
+        nbody.reset_host_enqueue();
         for (int i = 0; i < nb_iterations; ++i) nbody.update(dt);
+        host_enqueue_ms_per_step_ = nbody.host_enqueue_ms_per_step();
         return get_milliseconds_passed();
     });
 }

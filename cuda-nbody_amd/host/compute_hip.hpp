@@ -50,6 +50,8 @@ class ComputeHIP {
     auto get_milliseconds_passed() -> Milliseconds;                    // since the last call (event pair)
     auto run_benchmark(int nb_iterations, float dt) -> Milliseconds;   // 1 untimed step, then K between two events
     auto use_graph(bool enable) noexcept -> void { use_graph_ = enable; }  // extension (--graph): the K steps as one hipGraph
+    // extension: host milliseconds per step the last run_benchmark needed to ENQUEUE its steps (< 0: the body system does not say -- only the sharded one does)
+    auto host_enqueue_ms_per_step() const noexcept -> double { return host_enqueue_ms_per_step_; }
 
     // One dt = 0.001 step of the FAST kernels against the bit-reproducing STRICT kernels started from the SAME
     // pre-step state, |dp| <= 5e-4 per component (the reference's tolerance, compute_cuda.cpp:297-323).
@@ -70,6 +72,7 @@ class ComputeHIP {
     bool        fp64_enabled_;
     bool        use_host_mem_;
     bool        use_graph_ = false;
+    double      host_enqueue_ms_per_step_ = -1.0;
 
     std::unique_ptr<BodySystemHIP<float>>  nbody_fp32_;
     std::unique_ptr<BodySystemHIP<double>> nbody_fp64_;

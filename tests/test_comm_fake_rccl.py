@@ -11,6 +11,7 @@ The library binds RCCL once per process, so every case runs in a worker process 
 the environment variable; the parent compares what the worker's ranks hold with the CPU oracle / golden fixtures.
 """
 import os
+import re
 import subprocess
 import sys
 
@@ -75,7 +76,14 @@ def test_init_all_four_ranks_on_one_gpu(tmp_path, oracle, dtype, tag, mode):
     got = _run(tmp_path, "all", pos0, vel0, world, steps, mode)
     assert list(got["rejected"]) == [10001, 10001, 10001]  # subset of the group / a rank twice / per-rank form on a multi-rank group
     sends, recvs, gathers, groups, copies = got["counters"]
-    assert sends == recvs == copies == (world - 1) * world * steps and groups == (world - 1) * steps and gathers == 0  # (a group per round: the default since round 5)
+    # a group per round (the default since round 5) -- and, since round 6, per RANK: the ranks own a communicator each, so a crew of
+    # threads steps them independently, every thread issuing its own rank's groups (RCCL's thread-per-device model)
+    assert sends == recvs == copies == (world - 1) * world * steps and groups == (world - 1) * world * steps and gathers == 0
+    # NBODY_STEP_THREADS=0: the calling thread enqueues every rank, a round is ONE group over the local ranks -- the same bits
+    alone = _run(tmp_path, "all", pos0, vel0, world, steps, mode, NBODY_STEP_THREADS="0")
+    assert alone["counters"][3] == (world - 1) * steps and alone["counters"][0] == sends
+    for k in range(world):
+        assert alone[f"pos_{k}"].tobytes() == got[f"pos_{k}"].tobytes() and alone[f"vel_{k}"].tobytes() == got[f"vel_{k}"].tobytes()
     ref_p, ref_v = pos0.copy(), vel0.copy()
     oracle.update(ref_p, ref_v, dtype(np.float32(0.016)), steps=steps)
     pos = [got[f"pos_{k}"] for k in range(world)]
@@ -219,7 +227,10 @@ def test_pairwise_step_across_ranks(tmp_path, oracle, world, dtype):
     # a group per round for the world // 2 tiles the next step's kernels wait for, ONE group for the tiles nobody waits for (round 5),
     # a group per reaction round
     H = world // 2
-    assert sends == recvs == (world - 1 + H) * world * steps and groups == (H + (1 if world - 1 > H else 0) + H) * steps
+    # (each by the thread of its own rank: x world)
+    assert sends == recvs == (world - 1 + H) * world * steps and groups == (H + (1 if world - 1 > H else 0) + H) * steps * world
+    alone = _run(tmp_path, "all", pos0, vel0, world, steps, "fast", workspace=True, NBODY_STEP_THREADS="0")  # the calling thread alone: a group per round over all ranks, the same bits
+    assert alone["counters"][3] == (H + (1 if world - 1 > H else 0) + H) * steps and alone["pos_0"].tobytes() == got["pos_0"].tobytes()
     ref_p, ref_v = pos0.copy(), vel0.copy()
     oracle.update(ref_p, ref_v, dtype(np.float32(0.016)), steps=steps)
     for k in range(1, world):
@@ -345,6 +356,15 @@ def test_cli_sharded_fast_owns_workspaces(tmp_path):
     assert r.returncode == 0 and "  OK" in r.stdout, r.stdout + r.stderr
     r = subprocess.run([cli, "--benchmark", f"--numbodies={n}", "--devices=0,0", "-i", "4"], env=_env(), capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "billion interactions per second" in r.stdout, r.stdout + r.stderr
+    # round 6: a run over several devices says what the HOST needed to enqueue a step (after the reference's three lines)
+    m = re.search(r"^= ([\d.]+) ms of host time to enqueue a step \(host_enqueue_ms_per_step; ([\d.]+) ms per step on the devices\)$", r.stdout, re.M)
+    assert m and 0 < float(m.group(1)) < 50 and float(m.group(2)) > 0, r.stdout
+    # ... with the crew of threads (default) and with the calling thread alone (NBODY_STEP_THREADS=0): the very same bits
+    for name, threads in (("crew", "1"), ("alone", "0")):
+        dump = tmp_path / f"threads_{name}.bin"
+        r = subprocess.run([cli, f"--numbodies={n}", "--steps=3", f"--dump={dump}", "--devices=0,0,0,0"], env={**_env(), "NBODY_STEP_THREADS": threads}, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert np.fromfile(dump, dtype=np.float32).tobytes() == dumps["pairwise"].tobytes(), name
 
 
 @pytest.mark.gpu
@@ -385,10 +405,10 @@ def test_position_exchange_grouping_is_a_setting_not_a_result(tmp_path, oracle, 
     strict = _run(tmp_path, "all", pos0, vel0, world, steps, "strict", workspace=workspace, WORKER_ONE_GROUP="1")
     assert strict["pos_0"].tobytes() == ref_p.tobytes()
     sends, recvs, gathers, groups, copies = strict["counters"]
-    assert sends == recvs == (world - 1) * world * steps and groups == steps  # one group per step
+    assert sends == recvs == (world - 1) * world * steps and groups == steps * world  # one group per step (and rank: each from its own thread)
     fast = _run(tmp_path, "all", pos0, vel0, world, steps, "fast", workspace=workspace, WORKER_ONE_GROUP="1")
     default = _run(tmp_path, "all", pos0, vel0, world, steps, "fast", workspace=workspace)
-    assert default["counters"][3] == (world - 1) * steps + reaction and fast["counters"][3] == steps + reaction
+    assert default["counters"][3] == ((world - 1) * steps + reaction) * world and fast["counters"][3] == (steps + reaction) * world
     explicit = _run(tmp_path, "all", pos0, vel0, world, steps, "fast", workspace=workspace, WORKER_ONE_GROUP="0", NBODY_EXCHANGE_ONE_GROUP="1")  # the API outranks the variable
     by_env = _run(tmp_path, "all", pos0, vel0, world, steps, "fast", workspace=workspace, NBODY_EXCHANGE_ONE_GROUP="1")  # ... which is the default only
     assert explicit["counters"][3] == default["counters"][3] and by_env["counters"][3] == fast["counters"][3] != default["counters"][3]

@@ -69,11 +69,20 @@ def main():
     for world in args.worlds.split(","):
         row = {"what": args.what, "world_kind": world, "bodies": n, "ranks": G, "layout": args.layout, "capture_mode": args.mode}
         uid = ctypes.create_string_buffer(128)
-        pkg.check(lib.nb_comm_unique_id(uid), "nb_comm_unique_id")
+        if world != "double":
+            pkg.check(lib.nb_comm_unique_id(uid), "nb_comm_unique_id")
         if world == "loopback":
             comm = vp()
             pkg.check(lib.nb_comm_loopback_open(ctypes.byref(comm), uid, G, G // 2), "nb_comm_loopback_open")
             comms = [comm]
+        elif world == "double":
+            # G ranks on this one device through the TRANSPORT DOUBLE (NBODY_RCCL_LIB=tests/fake_rccl/libfake_rccl.so): every rank owns a
+            # communicator, so the crew steps the ranks independently, a thread each -- the form a real node takes.  The double's
+            # ncclGroupEnd blocks the host until the peer has posted, which the real library does not: an upper bound.
+            assert os.environ.get("NBODY_RCCL_LIB", "").endswith("libfake_rccl.so"), "world kind `double` needs NBODY_RCCL_LIB=.../libfake_rccl.so"
+            arr = (vp * G)()
+            pkg.check(lib.nb_comm_init_all(arr, G, (ctypes.c_int * G)(*([0] * G))), "nb_comm_init_all")
+            comms = [vp(arr[k]) for k in range(G)]
         else:
             arr = (vp * G)()
             pkg.check(lib.nb_comm_inprocess_open_all(arr, G, uid), "nb_comm_inprocess_open_all")
@@ -144,6 +153,10 @@ def main():
         pkg.check(lib.nb_comm_last_enqueue_ms(comms[0], ctypes.byref(ms)))
         row["last_enqueue_ms_by_the_library"] = round(ms.value, 4)
         row["step_threads"] = os.environ.get("NBODY_STEP_THREADS", "1")
+        if os.environ.get("NBODY_ENQUEUE_TRACE") == "1":
+            text = ctypes.create_string_buffer(8192)
+            pkg.check(lib.nb_comm_last_step_trace(comms[0], text, len(text)))
+            row["host_phases_ms_last_step"] = {" ".join(line.split()[2:]): round(float(line.split()[1]), 4) for line in text.value.decode().splitlines() if line.startswith("host ")}
         if args.what == "none":  # the eager step only: what the host needs to enqueue it (NBODY_STEP_THREADS=0 / 1)
             print(json.dumps(row), flush=True)
             sys.stdout.flush()
