@@ -43,7 +43,7 @@ sys.path.insert(0, ROOT)
 import __graft_entry__ as entry  # noqa: E402
 
 from bench_support import (CONFIG3_BODIES, ChipWatch, FP32_ISSUE_CEILING_INTERACTIONS_PER_S, FP32_VECTOR_PEAK_TFLOPS, FP64_ISSUE_CEILING_INTERACTIONS_PER_S,  # noqa: E402
-                           FP64_VECTOR_PEAK_TFLOPS, cpu_baseline, make_bodies, multi_gpu_diagnostics, other_configs, pair_evaluations, pair_kernel_split,
+                           FP64_PEAK_NOTE, FP64_VECTOR_PEAK_TFLOPS, single_gpu_reference, cpu_baseline, make_bodies, multi_gpu_diagnostics, other_configs, pair_evaluations, pair_kernel_split,
                            plan_dict, pmc_summary, rank_projection)
 
 
@@ -101,6 +101,7 @@ def parse_args():
 
 BRINGUP_MARK = "] up:"          # every rank writes "[bench rank R] up: ..." to stderr once its exchange is up, before the warm-up
 IMPORTED_MARK = "] torch imported"  # ... and "[bench rank R] torch imported" right after the import (a fresh box pages torch in for a minute or two)
+EXPECTS_MARK = "] expects "        # ... and "[bench rank R] expects S s until the headline" once two probe steps have said how long a step takes
 
 
 def self_launch(n_ranks: int, explicit_exchange: bool, attempt_s: float, budget_s: float = 560.0, bringup_s: float = 60.0, import_s: float = 150.0, make_cmd=None) -> int:
@@ -117,7 +118,10 @@ def self_launch(n_ranks: int, explicit_exchange: bool, attempt_s: float, budget_
     exchange up (BRINGUP_MARK on stderr) `bringup_s` after the first rank imported torch (IMPORTED_MARK; `import_s` at the
     latest after the start) -- a run that will finish has printed that line within seconds, one that sits in a rendezvous or in
     RCCL's bring-up never does.  An attempt's own time counts from that import mark too; once its line is out, an attempt may use
-    what is left of the whole budget (the diagnostics run after the line).  `make_cmd(extra_flags, port) -> argv`: the command of an attempt (tests pass stand-in ranks)."""
+    what is left of the whole budget (the diagnostics run after the line).  Round 6 (advisor): ranks that are UP and have said how long
+    they expect to need (EXPECTS_MARK, from two probe steps: a large --bodies / --steps, fp64 or strict run is slow, not hung) are
+    left alone until twice that time + 30 s has passed -- inside the whole budget --, instead of being ended at the attempt's limit and
+    retried with exchanges that are slower still.  `make_cmd(extra_flags, port) -> argv`: the command of an attempt (tests pass stand-in ranks)."""
     import signal
     import socket
     import subprocess
@@ -154,7 +158,7 @@ def self_launch(n_ranks: int, explicit_exchange: bool, attempt_s: float, budget_
             sock.bind(("127.0.0.1", 0))
             port = sock.getsockname()[1]
         child = subprocess.Popen(make_cmd(extra, port), env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
-        seen = {"metric": False, "up": False, "imported_at": None}
+        seen = {"metric": False, "up": False, "imported_at": None, "expected_by": None}
 
         def relay_out():
             for line in child.stdout:
@@ -169,6 +173,11 @@ def self_launch(n_ranks: int, explicit_exchange: bool, attempt_s: float, budget_
                     seen["up"] = True
                 elif IMPORTED_MARK in line and seen["imported_at"] is None:
                     seen["imported_at"] = time.monotonic()
+                elif EXPECTS_MARK in line:
+                    try:  # "[bench rank R] expects 123.4 s until the headline": alive and slow is not hung
+                        seen["expected_by"] = time.monotonic() + 2.0 * float(line.split(EXPECTS_MARK, 1)[1].split()[0]) + 30.0
+                    except (ValueError, IndexError):
+                        pass
                 sys.stderr.write(line)
                 sys.stderr.flush()
 
@@ -189,8 +198,10 @@ def self_launch(n_ranks: int, explicit_exchange: bool, attempt_s: float, budget_
                     # the line is out: what follows (diagnostics, tear-down) may take what is left of the whole budget, no more
                     if now - started > budget_s:
                         rc = end_group(child, f"the line is out and the launcher's budget of {budget_s:.0f} s is spent")
+                elif ran > limit and seen["up"] and seen["expected_by"] is not None and now < seen["expected_by"] and now - started < budget_s - 5.0:
+                    pass  # up, stepping, and within what the ranks themselves said they need: let them work
                 elif ran > limit:
-                    rc = end_group(child, f"ranks still running after {limit:.0f} s")
+                    rc = end_group(child, f"ranks still running after {limit:.0f} s" + (" (and past twice the time they expected to need)" if seen["expected_by"] is not None else ""))
                 elif not seen["up"] and (ran > bringup_s or (imported is None and ran > 0)):  # (no rank even imported torch in `import_s`)
                     rc = end_group(child, f"no rank has its exchange up {now - begun:.0f} s after the start")
         for r in readers:
@@ -249,6 +260,7 @@ def main():
     import torch
 
     distributed_env = world > 1 or "RANK" in os.environ
+    started_at = time.monotonic()
     stage = {"name": "start-up", "since": time.monotonic()}
 
     def enter(name):
@@ -260,7 +272,7 @@ def main():
         print(f"[bench rank {rank}] torch imported", file=sys.stderr, flush=True)  # (IMPORTED_MARK: the launcher's bring-up clock starts here)
 
         def stuck():
-            sys.stderr.write(f"[bench rank {rank}] no headline after {args.headline_timeout:.0f} s: stuck in '{stage['name']}' for {time.monotonic() - stage['since']:.0f} s; leaving with status 5\n")
+            sys.stderr.write(f"[bench rank {rank}] no headline after {time.monotonic() - started_at:.0f} s: stuck in '{stage['name']}' for {time.monotonic() - stage['since']:.0f} s; leaving with status 5\n")
             sys.stderr.flush()
             os._exit(5)
 
@@ -292,6 +304,7 @@ def main():
     distributed = world > 1 or "RANK" in os.environ
     exchange_fallback = os.environ.get("NBODY_BENCH_EXCHANGE_FALLBACK") == "1"  # set by self_launch for its retries
     rccl_group = None
+    rccl_init_hung = False  # a thread of this process is still inside ncclCommInitRank (or ncclCommDestroy): see the end of main()
     if distributed:
         import torch.distributed as dist
 
@@ -415,6 +428,7 @@ def main():
                 print(f"[bench rank {rank}] RCCL's bring-up hung on some rank ({problem!r} on this one); ALL ranks fall back to the exchange without RCCL (gloo through host memory)",
                       file=sys.stderr, flush=True)
                 capi_rank, exchange_fallback, pairwise, init_hung = None, True, False, True
+                rccl_init_hung = True
                 args.exchange = "staged"
             if capi_rank is not None and world > 1 and problem is None:
                 # Never step on the null stream (torch's current stream) next to RCCL: a rank that computes there -- or on a stream
@@ -548,6 +562,15 @@ def main():
             dist.all_reduce(probe, op=dist.ReduceOp.MAX)  # gloo: every rank derives the same count
         settle_steps = int(min(4000, max(0, round(args.settle_seconds / max(float(probe.item()), 1e-6)))))
         settle_steps += settle_steps & 1  # (even: the ping-pong ends where it began)
+        if distributed_env:
+            # alive and slow is not hung: say how long the rest will take (the launcher reads it: EXPECTS_MARK) and give the watchdog that long
+            expected = float(probe.item()) * (settle_steps + args.warmup + args.steps) * 1.25 + 5.0
+            print(f"[bench rank {rank}] expects {expected:.1f} s until the headline ({float(probe.item()) * 1e3:.3f} ms per step by two probe steps)", file=sys.stderr, flush=True)
+            if headline_watchdog is not None and 2.0 * expected + 30.0 > args.headline_timeout - (time.monotonic() - started_at):
+                headline_watchdog.cancel()
+                headline_watchdog = threading.Timer(2.0 * expected + 30.0, stuck)
+                headline_watchdog.daemon = True
+                headline_watchdog.start()
         for k in range(settle_steps):
             step()
             if k % 16 == 15:  # (keep the host a bounded distance ahead)
@@ -565,6 +588,7 @@ def main():
     ev0.record(stream_ptr)
     for _ in range(args.steps):
         step()
+    enqueued = time.perf_counter()  # (the host is through with its K steps here; the device usually is not)
     finish()
     ev1.record(stream_ptr)
     # The closing bracket: this rank's device work done (synchronize), its clock stopped, THEN the barrier.  The figure reported is the
@@ -579,11 +603,19 @@ def main():
         headline_watchdog.cancel()
     enter("after the timed region")
     stream_ms_per_step = ev0.elapsed_ms(ev1) / args.steps  # HIP events on the launch stream: this rank's step, kernels only at N = 1
+    # what the HOST needed to enqueue a timed step (this rank's loop; a step whose enqueue takes longer than its kernels is bound by the
+    # host).  An upper bound: a launch blocks when the device's queue is full.  The library's own figure for the last step stands next to it.
+    host_enqueue_ms = (enqueued - t0) / args.steps * 1e3
+    lib_enqueue_ms = None
+    if capi_rank is not None:
+        ms = ctypes.c_double(0)
+        if lib.nb_comm_last_enqueue_ms(capi_rank.comm, ctypes.byref(ms)) == 0:
+            lib_enqueue_ms = ms.value
 
     if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64)  # gloo
+        t = torch.tensor([elapsed, host_enqueue_ms], dtype=torch.float64)  # gloo
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed, host_enqueue_ms = float(t[0].item()), float(t[1].item())
 
     if args.dump_state and rank == 0:  # (the state after exactly warmup + steps steps: before anything below steps the system further)
         torch.cuda.synchronize()
@@ -601,9 +633,10 @@ def main():
         layout_name = "pairwise" if pairwise else ("one-sided" if args.mode == "fast" else "strict")
         # the dominant kernel's own duration: the pairwise step is two kernels (pair_forces, pair_finish), timed separately AFTER
         # the timed region with an event the library records between them; every other single-GPU step is one kernel
-        forces_ms = finish_ms = None
+        forces_ms = finish_ms = clock_by_kernel = None
         if pair is not None and not distributed:
-            forces_ms, finish_ms = pair_kernel_split(pkg, lib, step, stream_ptr)
+            clocked = pair.slices == 1 and pair.waves_per_block == 8 and pair.bodies_per_lane == (16 if not args.fp64 else 8)  # (the geometry pair_forces_clocked exists for)
+            forces_ms, finish_ms, clock_by_kernel = pair_kernel_split(pkg, lib, step, stream_ptr, grid_blocks=pair.grid_blocks if clocked else 0)
         dominant_ms = forces_ms if forces_ms is not None else stream_ms_per_step
         algorithmic_flops = flops_per * float(n) * float(n) / world  # per launch of the dominant kernel(s) of one rank's step
         achieved_tflops = algorithmic_flops / (dominant_ms * 1e-3) / 1e12
@@ -672,12 +705,25 @@ def main():
         # sits near its power cap and the power management grants 2.0-2.3 GHz by box.  frac_at_delivered_clock = step_frac x 2400 /
         # sclk: the timed steps' algorithmic flop over what the vector ALUs could issue AT THE CLOCK SAMPLED WHILE THEY RAN (step_frac,
         # not frac: the dominant kernel is timed apart, after the region the samples come from).  Never the headline fraction.
+        if args.fp64:
+            roofline.update(FP64_PEAK_NOTE)
         roofline["chip"] = chip.summary()
         if roofline["chip"] and roofline["chip"]["sclk_mhz"]:
-            roofline["frac_at_delivered_clock"] = roofline["step_frac"] * ChipWatch.PEAK_CLOCK_MHZ / roofline["chip"]["sclk_mhz"]
+            roofline["frac_at_hwmon_clock"] = roofline["step_frac"] * ChipWatch.PEAK_CLOCK_MHZ / roofline["chip"]["sclk_mhz"]
             if world == 1 and roofline["chip"]["socket_power_w"]:
                 roofline["chip"]["interactions_per_joule"] = value / roofline["chip"]["socket_power_w"]
         chip_summary = roofline["chip"]
+        # Round 6: the clock read INSIDE the kernel (pair_forces_clocked, after the timed region), not the power management's table: hwmon's
+        # figure reads higher than what a dense vector kernel gets and lags behind a changing load, and cycles per step computed from it
+        # differed by 4 % between boxes for one binary (round-5 review).  frac_at_delivered_clock and the cycle counts use THIS clock.
+        if clock_by_kernel is not None:
+            roofline["chip"] = dict(roofline["chip"] or {}, delivered_mhz_by_kernel=clock_by_kernel["mhz"], delivered_clock=clock_by_kernel)
+            roofline["frac_at_delivered_clock"] = roofline["step_frac"] * ChipWatch.PEAK_CLOCK_MHZ / clock_by_kernel["mhz"]
+            roofline["mcycles_per_step"] = stream_ms_per_step * clock_by_kernel["mhz"] * 1e-3  # (stream time of a timed step x the delivered clock)
+            if forces_ms is not None:
+                roofline["pair_forces_mcycles"] = forces_ms * clock_by_kernel["mhz"] * 1e-3
+        elif roofline.get("frac_at_hwmon_clock") is not None:
+            roofline["frac_at_delivered_clock"] = roofline["frac_at_hwmon_clock"]  # (no probe in this run: the power management's figure stands in)
         line = {
             "metric": "body-body interactions/s, all-pairs N-body step (reference convention N^2 per step)",
             "value": value,
@@ -687,11 +733,20 @@ def main():
             "warmup": args.warmup,
             "settle_steps": settle_steps,  # untimed steps before the warm-up steps (--settle-seconds: the card's clock ramp from idle)
             "ms_per_step": elapsed / args.steps * 1e3,
+            # host wall clock to ENQUEUE a timed step (max over the ranks; last_step_by_the_library: nb_comm_last_enqueue_ms of rank 0's last step)
+            "host_enqueue_ms_per_step": host_enqueue_ms,
+            "host_enqueue": {"ms_per_step": host_enqueue_ms, "last_step_by_the_library_ms": lib_enqueue_ms,
+                             "what": "perf_counter around the K step calls of the timed loop, before anything is waited for (an upper bound: a launch blocks when the device queue is full); "
+                                     "one process per GPU: each rank enqueues its own step"},
             "higher_is_better": True,
             "scaling": "strong",
             # true when this line was NOT produced by the exchange asked for (the launcher's retries, or a collective in-rank
             # fallback at bring-up): such a value must not pass for a number of the C-ABI RCCL path
             "exchange_fallback": bool(exchange_fallback),
+            # WHICH exchange produced `value`, in one word a reader of the parsed line cannot miss: "rccl-tiles" is the product's own path
+            # (nb_comm_init_rank + nb_sharded_step_*); everything else is a fall-back or an A/B and must not be credited as that path
+            "exchange_path": "none" if world == 1 else ("rccl-tiles" if capi_rank is not None else
+                                                         "staged" if args.exchange in ("staged", "host", "host-tiles") else ("torch" if system.exchange == "tiles" else "allgather")),
             "vs_baseline": None,
             "dtype": "f64" if args.fp64 else "f32",
             "data": "synthetic",
@@ -784,6 +839,24 @@ def main():
             mine["stream_ms_per_step"] = float(f"{stream_ms_per_step:.5g}")
             dist.all_gather_object(seen, mine)
             extra["ranks_seen"] = seen
+            # how many ranks stepped through a communicator bound to a real RCCL (== n_gpus for a line of the native path), and which RCCL
+            with_rccl = [r for r in seen if isinstance(r, dict) and (r.get("rccl_version") or 0) > 0 and "fake" not in (r.get("rccl_library") or "")]
+            extra["rccl_ranks_seen"] = len(with_rccl)
+            extra["rccl_version"] = with_rccl[0]["rccl_version"] if with_rccl else None
+            extra["defaults_provisional"] = ("the multi-GPU defaults (an RCCL group per position round + one tail group; the diagonal as two launches, the second one last; reaction "
+                                             "rounds in ready order) were chosen on ONE GPU with a loopback rank -- no link latency, no peer to be late; diagnostics.step_ms times "
+                                             "the alternatives in this very job: choose from them")
+            if not args.no_diagnostics and args.mode == "fast" and not args.rehearse_one_gpu:
+                # the N = 1 figure of THIS process tree: rank 0 steps the whole system alone on its GPU while the others wait at the
+                # barrier -- "does N = 1 of a scaling series agree with the single-GPU bench" is then answerable from this one record
+                fence()
+                try:
+                    extra["single_gpu_same_process"] = single_gpu_reference(pkg, n, dtype, mode, pos0, vel0) if rank == 0 else None
+                except Exception as exc:  # noqa: BLE001
+                    extra["single_gpu_same_process"] = {"error": repr(exc)}
+                fence()
+                if rank == 0 and isinstance(extra["single_gpu_same_process"], dict) and extra["single_gpu_same_process"].get("value"):
+                    extra["single_gpu_same_process"]["speedup_of_this_line"] = round(value / extra["single_gpu_same_process"]["value"], 3)
             if not args.no_diagnostics:
                 extra["diagnostics"] = multi_gpu_diagnostics(pkg, lib, dist, torch, args, capi_rank, system, sharded, launch, fence, step, finish, lend, stream_ptr,
                                                              rank, world, n, dtype, mode, dt, damping, bufs if capi_rank is not None else None,
@@ -816,6 +889,13 @@ def main():
             lib.nb_stream_destroy(own_stream)
     if distributed:
         dist.destroy_process_group()
+    if rccl_init_hung:
+        # A daemon thread is still blocked inside ncclCommInitRank (or ncclCommDestroy).  A normal interpreter shutdown would run the
+        # static destructors of HIP and RCCL under it -- a hang or an abort AFTER a valid line, and the 30 s `leave` timer is a daemon thread
+        # that no longer fires once finalisation has begun.  The line is out and the process group is gone: leave now.
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)
 
 
 

@@ -224,6 +224,12 @@ def fractions(n, fp64, layout, ms, pair=None):
     return round(frac, 4), round((36 if fp64 else 24) * pair_evaluations(pair) / (ms * 1e-3) / (peak * 1e12), 4)
 
 
+# what every fp64 entry of the line says about its peak (round-5 review: 78.6 is a public figure, not a measurement)
+FP64_PEAK_NOTE = {"fp64_peak_tflops": FP64_VECTOR_PEAK_TFLOPS,
+                  "fp64_peak_source": "public MI355X spec (half the packed-fp32 rate at 2.4 GHz); NOT confirmed on the box",
+                  "fp64_issue_peak_tflops": round(1024 * 64 * 2 * 2.4e9 / 4.41 / 1e12, 1),
+                  "fp64_issue_peak_source": "profiles/round2_fp64_issue_probes.txt: v_fma_f64 issues in 4.41 cycles per wave64 on a SIMD (not 4) -> 1024 SIMDs x 64 lanes x 2 flop x 2.4 GHz / 4.41"}
+
 CONFIG_WARMUP_S = 0.25  # other_configs: steps run (untimed) for at least this long before a config is timed
 GRAPH_SIZES = (16384, 65536)  # ... and these pairwise entries are also timed as hipGraph replays
 
@@ -312,6 +318,16 @@ def other_configs(pkg, lib, headline):
             pmc = pmc_summary(n, fp64, mode_name, layout, plan_dict(pkg, n, dtype, layout) if cap is None else None)
             out.append({"workload": what, "bodies": n, "dtype": "f64" if fp64 else "f32", "mode": mode_name, "layout": layout, "steps": steps, "warmup_steps": warmed,
                         "ms_per_step": float(f"{ms:.5g}"), "frac_algorithmic": frac, "executed_frac": executed, "valu_busy": None if not pmc else pmc.get("valu_busy")})
+            if layout == "pairwise":
+                # (said per entry, so that nobody reads a fraction above 1 as utilisation: the count is the reference's, the work is half of it)
+                out[-1]["frac_algorithmic_counts"] = "N^2 directed interactions (reference convention); the kernel evaluates each PAIR once = half of them: executed_frac is the utilisation figure"
+            if fp64:
+                out[-1].update(FP64_PEAK_NOTE)
+            if what == "configs[1]":
+                # BASELINE configs[1] says "LDS tile = 256 bodies": no shipping FAST kernel stages a tile of bodies j in LDS
+                out[-1]["lds_tile"] = None
+                out[-1]["why"] = ("no staged tile: the pairwise kernel rotates bodies j through the wavefront (DPP), the one-sided kernel streams them through the scalar unit; "
+                                  "a staged 256-body LDS tile measured slower -- profiles/round2_scalar_stream_ab.txt, profiles/round4_lds_tile_experiment.txt; --blockSize stays a hint")
             if graph_ms is not None:
                 out[-1]["hipgraph_ms_per_step"] = float(f"{graph_ms:.5g}")
                 out[-1]["hipgraph_gain"] = round(ms / graph_ms - 1.0, 4)
@@ -358,7 +374,47 @@ def rank_projection(pkg, lib, n, dtype, dt, damping, single_ms):
     # a third-party library does may cost this process its headline line.
     if np.dtype(dtype) == np.float32:
         out["loopback"] = loopback_projection(n, single_ms)
+        out["host_enqueue"] = host_enqueue_projection(n, out["loopback"])
     return out
+
+
+def host_enqueue_projection(n, loopback, timeout_s=60):
+    """What the HOST needs to enqueue one step of an 8-rank job (round 6), measured on this one GPU with the real RCCL, in child processes:
+    one rank's whole step (the loopback rank: what each process of `bench.py --gpus 8`, and each thread of the crew that steps the devices of
+    `nbody --numdevices 8`, enqueues -- in parallel with the others), and the whole world's step in ONE process (the lab's in-process world:
+    eight ranks that share one RCCL communicator, so its RCCL groups are issued by one thread -- the crew only takes the kernels and
+    events), with the crew and with the calling thread alone.  Labelled projections, never `value`."""
+    import json
+    import subprocess
+
+    got = {"what": "host wall clock (ms) to enqueue ONE step of 8 ranks at this body count, real RCCL, one GPU; a step whose enqueue takes longer than its kernels is host-bound.  "
+                   "one_rank_*: a loopback rank, in a torch process (torch's own HIP runtime and RCCL: what a rank of `bench.py --gpus 8` is) and in a plain process (ROCm's: "
+                   "what a thread of the crew behind `nbody --numdevices 8` is)",
+           "one_rank_of_8_torch_process_ms": None, "one_rank_of_8_plain_process_ms": None, "in_process_world_8_ranks": {}}
+    try:
+        got["one_rank_of_8_torch_process_ms"] = loopback["ranks"]["8"].get("host_enqueue_ms")
+    except (KeyError, TypeError):
+        pass
+    tool = os.path.join(ROOT, "tools", "graph_capture_probe.py")
+    env = dict(os.environ)
+    for name in ("NBODY_RCCL_LIB", "FAKE_RCCL_IPC", "NCCL_DEBUG", "NBODY_HIP_LIB"):
+        env.pop(name, None)
+    try:
+        done = subprocess.run([sys.executable, tool, "--worlds", "loopback", "--what", "none", "--bodies", str(n), "--world", "8", "--steps", "30"], capture_output=True, text=True, timeout=timeout_s, env=env)
+        got["one_rank_of_8_plain_process_ms"] = next(json.loads(text) for text in done.stdout.splitlines() if text.startswith("{"))["eager_host_enqueue_ms_per_step"]
+    except (subprocess.TimeoutExpired, StopIteration, KeyError, ValueError) as exc:
+        got["error"] = f"loopback rank in a plain process: {exc!r}"
+    for key, threads in (("crew_ms", "1"), ("calling_thread_alone_ms", "0")):
+        try:
+            done = subprocess.run([sys.executable, tool, "--worlds", "inprocess", "--what", "none", "--bodies", str(n), "--world", "8", "--steps", "30"],
+                                  capture_output=True, text=True, timeout=timeout_s, env={**env, "NBODY_STEP_THREADS": threads})
+            row = next(json.loads(text) for text in done.stdout.splitlines() if text.startswith("{"))
+            got["in_process_world_8_ranks"][key] = row["eager_host_enqueue_ms_per_step"]
+            got["in_process_world_8_ranks"]["stream_ms_per_step_all_8_ranks_on_one_gpu"] = row["eager_stream_ms_per_step"]
+        except (subprocess.TimeoutExpired, StopIteration, KeyError, ValueError) as exc:
+            got["error"] = f"in-process world ({key}): {exc!r}"
+            break
+    return got
 
 
 def loopback_projection(n, single_ms, worlds=(2, 4, 8), timeout_s=180):
@@ -387,7 +443,8 @@ def loopback_projection(n, single_ms, worlds=(2, 4, 8), timeout_s=180):
             step, alone = row.get("step_pairwise_late1_group_per_round"), row.get("kernels_alone_pairwise_late1")
             if step:
                 got["ranks"][str(row["nominal_world"])] = {"step_ms": step, "kernels_alone_ms": alone, "exposed_exchange_ms": None if alone is None else round(step - alone, 4),
-                                                           "speedup_excl_link_time": round(single_ms / step, 2)}
+                                                           "speedup_excl_link_time": round(single_ms / step, 2),
+                                                           "host_enqueue_ms": row.get("host_enqueue_ms_pairwise_late1_group_per_round")}
                 got["rccl_version"], got["rccl_library"] = row.get("rccl_version"), row.get("rccl_library")
         if done.returncode != 0 or not rows:
             got["error"] = f"{world} ranks: exit status {done.returncode}" + (": " + done.stderr.strip().splitlines()[-1][:300] if done.stderr.strip() else "")
@@ -395,26 +452,59 @@ def loopback_projection(n, single_ms, worlds=(2, 4, 8), timeout_s=180):
     return got
 
 
-def pair_kernel_split(pkg, lib, step, stream, reps=10):
+def delivered_clock(words):
+    """{"mhz": median, ...} from the words pair_forces_clocked left (two u64 per workgroup: its lifetime in shader cycles and in ticks of the
+    constant 100 MHz counter), None when no workgroup wrote any"""
+    w = np.asarray(words, dtype=np.uint64).reshape(-1, 2)
+    mhz = sorted(100.0 * float(c) / float(t) for c, t in zip(w[:, 0], w[:, 1]) if t and c)
+    if not mhz:
+        return None
+    cycles = sorted(float(c) for c, t in zip(w[:, 0], w[:, 1]) if t and c)
+    return {"what": "the clock pair_forces REALLY ran at, read inside the kernel after the timed region: every workgroup of pair_forces_clocked (the same kernel + four "
+                    "scalar instructions) notes its lifetime on the shader-cycle counter (s_memtime) and on the constant 100 MHz counter (s_memrealtime); "
+                    "MHz = 100 x cycles / ticks, median over the workgroups of the last launch (nb_set_pair_clock_words).  The power management's own figure "
+                    "(hwmon sclk) reads higher and lags; a probe launched BEHIND the kernel reads the unloaded clock (profiles/round6_delivered_clock.txt)",
+            "mhz": round(mhz[len(mhz) // 2], 1), "mhz_p10": round(mhz[len(mhz) // 10], 1), "mhz_p90": round(mhz[(len(mhz) * 9) // 10], 1), "workgroups": len(mhz),
+            "workgroup_mcycles_median": round(cycles[len(cycles) // 2] * 1e-6, 4)}
+
+
+def pair_kernel_split(pkg, lib, step, stream, reps=10, grid_blocks=0):
     """Average duration of the two kernels of the pairwise step, each on its own: pair_forces (the dominant kernel) and pair_finish,
     from HIP events on the launch stream -- one before the step, one the library records BETWEEN the two launches
-    (nb_set_pair_probe_event, tuning header), one after.  Taken after the timed region."""
+    (nb_set_pair_probe_event, tuning header), one after.  Taken after the timed region.  Round 6: then `reps` more steps with
+    pair_forces_clocked in pair_forces' place (nb_set_pair_clock_words; grid_blocks = the launch's workgroups, 0 = skip): the clock
+    the kernel really ran at.  Returns (forces ms, finish ms, delivered clock dict or None)."""
     # The reps are queued back to back (an event triple per rep, the probe event switched on the host before each call) and read
     # after ONE synchronisation: a synchronisation per rep idled the chip between steps, and the forces kernel then read 0.5 % slower
     # than the timed steps it belongs to.
     events = [(pkg.Event(), pkg.Event(), pkg.Event()) for _ in range(reps)]
+    words = pkg.DeviceBuffer(grid_blocks * 16) if grid_blocks else None
+    clock = None
     try:
         for before, between, after in events:
             pkg.check(lib.nb_set_pair_probe_event(between.h), "nb_set_pair_probe_event")
             before.record(stream)
             step()
             after.record(stream)
+        pkg.check(lib.nb_set_pair_probe_event(None), "nb_set_pair_probe_event")
+        if words is not None:  # (queued right behind: the chip stays under the same load)
+            pkg.check(lib.nb_memset(words.ptr, 0, grid_blocks * 16, stream), "nb_memset")
+            pkg.check(lib.nb_set_pair_clock_words(words.ptr, grid_blocks * 16), "nb_set_pair_clock_words")
+            for _ in range(reps):
+                step()
+            pkg.check(lib.nb_set_pair_clock_words(None, 0), "nb_set_pair_clock_words")
+            host = np.zeros(grid_blocks * 2, np.uint64)
+            pkg.check(lib.nb_d2h(host.ctypes.data_as(ctypes.c_void_p), words.ptr, host.nbytes, stream), "nb_d2h")  # (blocking on the stream: everything above is done)
+            clock = delivered_clock(host)
         events[-1][2].synchronize()
     finally:
         pkg.check(lib.nb_set_pair_probe_event(None), "nb_set_pair_probe_event")
+        pkg.check(lib.nb_set_pair_clock_words(None, 0), "nb_set_pair_clock_words")
+        if words is not None:
+            words.free()
     forces = sum(before.elapsed_ms(between) for before, between, _ in events)
     finish = sum(between.elapsed_ms(after) for _, between, after in events)
-    return forces / reps, finish / reps
+    return forces / reps, finish / reps, clock
 
 
 def cpu_baseline(n, dtype, pos0, vel0, sample_bodies):
@@ -429,10 +519,13 @@ def cpu_baseline(n, dtype, pos0, vel0, sample_bodies):
     sample = sample_bodies or max(8, min(n, int(2.0e10 // n) // 8 * 8))
     base = {}
     # OpenMP leg: the reference's fp32 loop forks INSIDE the j loop (bodysystemcpu.cpp:156-168), i.e. one fork/join per body j --
-    # it is slow by construction, so it gets a smaller sample and at most the box's CPU share (16 threads per GPU).
+    # it is slow by construction, so it gets a smaller sample and at most 16 threads (`host_cores` in the line: what the box offers).
     for key, omp, smp in (("one_thread", False, sample), ("openmp", True, max(8, sample // 16 // 8 * 8))):
         orc = O.Oracle(openmp=omp)
         if omp:
+            # SURVEY 8(d) says "all host cores"; this loop forks once per body j (262 144 fork/joins per pass), so MORE threads are SLOWER:
+            # 64 threads on a 256-core box took 17 s for 1/16 of the sample (round 6).  16 threads -- a one-GPU share of this pool -- and
+            # `host_cores` in the line says what the box had.
             orc.set_num_threads(min(16, os.cpu_count() or 1))
         ms = orc.benchmark_partial(pos_h, smp)
         base[key] = {"value": smp * float(n) / (ms * 1e-3), "cores": orc.num_threads() if omp else 1, "ms": ms, "sample_bodies_i": smp}
@@ -443,12 +536,37 @@ def cpu_baseline(n, dtype, pos0, vel0, sample_bodies):
         "unit": "interactions/s",
         "cores": 1,
         "kind": "port",
+        "host_cores": os.cpu_count(),  # what the box offers this process (the OpenMP leg uses at most 16 of them: see above; `cores` = threads of the headline figure)
         "sample": f"force pass of BodySystemCPU::update (oracle/ port) for the first {sample} bodies i against all {n} bodies j = {sample * n:.3g} "
                   f"interactions; 1 thread is how the reference ships",
         "openmp": base["openmp"],
         "config0": {"what": "BASELINE configs[0]: 1024 bodies, fp32, 100 steps of the CPU path, no warm-up (compute_cpu.cpp:72-88), 1 thread",
                     "ms_total": float(f"{ms0:.5g}"), "interactions_per_s": 1024.0 * 1024.0 * 100 / (ms0 * 1e-3), "gflops": 20 * 1024.0 * 1024.0 * 100 / (ms0 * 1e-3) * 1e-9},
     }
+
+
+def single_gpu_reference(pkg, n, dtype, mode, pos0, vel0, steps=10, warm_s=0.25):
+    """The single-GPU step of the same system on THIS rank's GPU (nb_integrate_ws_* with its own workspace, the null stream), timed with
+    events after `warm_s` of untimed steps: the N = 1 figure an N > 1 line carries along."""
+    system = pkg.BodySystemHIP(n, 256, pkg.NBodyParams(), dtype, pos0, vel0, mode=mode, workspace=True)
+    try:
+        dt = np.dtype(dtype).type(np.float32(0.016))
+        until = time.perf_counter() + warm_s
+        while time.perf_counter() < until:
+            for _ in range(4):
+                system.update(dt)
+            system.synchronize()
+        e0, e1 = pkg.Event(), pkg.Event()
+        e0.record(None)
+        for _ in range(steps):
+            system.update(dt)
+        e1.record(None)
+        e1.synchronize()
+        ms = e0.elapsed_ms(e1) / steps
+    finally:
+        system.free()
+    return {"what": "rank 0 alone on its GPU, the whole system, nb_integrate_ws_* (events, after the timed region; the other ranks wait)", "steps": steps,
+            "ms_per_step": float(f"{ms:.5g}"), "value": float(n) * n / (ms * 1e-3)}
 
 
 CONFIG3_BODIES = 1048576  # BASELINE.json configs[3]: 1 048 576 bodies over the GPUs of one node

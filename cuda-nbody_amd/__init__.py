@@ -188,10 +188,12 @@ TUNING_SIGNATURES = {
     "nb_comm_pair_work_f32": (_ci, [_vp, _cu, _P(ctypes.c_ulonglong), _P(_ci)]),
     "nb_comm_pair_work_f64": (_ci, [_vp, _cu, _P(ctypes.c_ulonglong), _P(_ci)]),
     "nb_comm_last_enqueue_ms": (_ci, [_vp, _P(_cd)]),
+    "nb_set_pair_clock_words": (_ci, [_vp, _sz]),
 }
 
 # include/nbody_hip_lab.h: exported by libnbody_hip_lab.so only
 LAB_SIGNATURES = {
+    "nb_clock_probe_launch": (_ci, [_vp, _ci, _cu, _vp]),
     "nb_set_alloc_limit": (_ci, [_sz]),
     "nb_comm_selftest_open": (_ci, [_P(_vp), _vp]),
     "nb_comm_loopback_open": (_ci, [_P(_vp), _vp, _ci, _ci]),

@@ -27,6 +27,8 @@ std::atomic<double> g_softening_sq_f64{0.0};
 std::atomic<int> g_ovr_i{0}, g_ovr_s{0}, g_ovr_tile{0};
 std::atomic<int> g_pair_r{0}, g_pair_s{0}, g_pair_c{0}, g_pair_min{0};  // overrides of the pairwise plan (0 = automatic)
 std::atomic<void*> g_pair_probe{nullptr};                               // nb_set_pair_probe_event
+std::atomic<unsigned long long*> g_clock_words{nullptr};                // nb_set_pair_clock_words
+std::atomic<size_t>              g_clock_bytes{0};
 std::atomic<int>   g_pair_slices{0};                                    // nb_set_pair_slices_override (0 = automatic)
 
 
@@ -297,6 +299,10 @@ size_t device_memory_budget() {
     return g_total_memory[dev].load();
 }
 hipEvent_t pair_probe_event() { return static_cast<hipEvent_t>(g_pair_probe.load(std::memory_order_relaxed)); }
+unsigned long long* pair_clock_words(size_t* bytes) {
+    *bytes = g_clock_bytes.load(std::memory_order_relaxed);
+    return g_clock_words.load(std::memory_order_relaxed);
+}
 std::atomic<size_t>& alloc_limit() {  // nb_alloc requests above this are made to fail IN THE RUNTIME (0: none); only the lab library has a setter
     static std::atomic<size_t> limit{0};
     return limit;
@@ -558,6 +564,14 @@ int nb_set_memory_budget(size_t bytes) {
 
 int nb_set_pair_probe_event(nb_event_t event) {
     g_pair_probe.store(event);
+    return 0;
+}
+
+int nb_set_pair_clock_words(void* device_words, size_t bytes) {
+    if ((device_words == nullptr) != (bytes == 0) || (reinterpret_cast<std::uintptr_t>(device_words) % sizeof(unsigned long long)) != 0) return NB_ERR_INVALID_ARGUMENT;
+    g_clock_bytes.store(0);
+    g_clock_words.store(static_cast<unsigned long long*>(device_words));
+    g_clock_bytes.store(bytes);
     return 0;
 }
 

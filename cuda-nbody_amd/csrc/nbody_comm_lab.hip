@@ -6,7 +6,7 @@
 //   * a LOOPBACK rank: rank r of a nominal G-rank communicator whose ncclComm has one rank (nb_comm_loopback_open);
 //   * an IN-PROCESS world: all G ranks in one process on one device sharing one real ncclComm (nb_comm_inprocess_open_all);
 //   * a new second compute stream on demand (nb_comm_replace_side_stream: how much does its placement matter?);
-//   * the allocation-failure hook of the out-of-memory tests (nb_set_alloc_limit).
+//   * the allocation-failure hook of the out-of-memory tests (nb_set_alloc_limit), a clock probe kernel (nb_clock_probe_launch).
 // It reaches into the product through nbody_comm_internal.h (hidden symbols of the same shared object) and adds no code path to
 // it: a loopback rank is a Comm with self_peers set, an in-process world is G such Comms that share their ncclComm and exchange
 // stream -- the product's exchange issues its calls in one canonical order whoever the peers are.
@@ -15,12 +15,41 @@
 #include "nbody_comm_internal.h"
 #include "rand_stream_guard.h"
 
+#include <cstdint>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <vector>
 
 using namespace nbc;
+
+// nb_clock_probe_launch (lab header): a clock read from the chip itself -- a wave stamps the shader-cycle
+// counter (s_memtime) and the constant 100 MHz counter (s_memrealtime) around a short spin; cycles / time is the clock, whatever
+// the power management's tables (sysfs pp_dpm_sclk / hwmon freq1_input) say.  Built to read the clock a dense kernel ran at from right
+// behind it -- and measured NOT to: launched microseconds after pair_forces it reads 2.43 GHz where the kernel's own stamps say 2.20
+// (profiles/round6_delivered_clock.txt): the chip raises its clock as soon as the load is gone.  Kept as the experiment it was; the
+// product reads the clock INSIDE the kernel (pair_forces_clocked).  Per workgroup four words: {shader cycles, 100 MHz ticks, XCC_ID, HW_ID}.
+__global__ void clock_probe(unsigned long long* words, unsigned long long ticks) {
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime();
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long       r1 = r0;
+    float                    x  = static_cast<float>(threadIdx.x);
+    while (r1 - r0 < ticks) {
+#pragma unroll
+        for (int k = 0; k < 64; ++k) x = __builtin_fmaf(x, 1.0000001f, 0.5f);
+        r1 = __builtin_amdgcn_s_memrealtime();
+    }
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime();
+    r1                          = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0) {
+        unsigned long long* out = words + static_cast<size_t>(blockIdx.x) * 4;
+        out[0] = c1 - c0, out[1] = r1 - r0;
+        out[2] = static_cast<unsigned>(__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20));   // XCC_ID
+        out[3] = static_cast<unsigned>(__builtin_amdgcn_s_getreg((15 << 11) | (0 << 6) | 4));   // HW_ID[15:0]
+    }
+    if (x == 12345.678f) words[0] = 0;  // (keeps the chain alive)
+}
+
 
 extern "C" {
 
@@ -210,6 +239,15 @@ int nb_comm_replace_side_stream(nb_comm_t comm) {  // (experiments: how much doe
     return static_cast<int>(create_side_stream(&c->aux));
 }
 
+
+int nb_clock_probe_launch(void* device_words, int workgroups, unsigned microseconds, nb_stream_t stream) {
+    if (device_words == nullptr || workgroups < 1 || workgroups > 1024 || microseconds == 0 || microseconds > 100000u) return NB_ERR_INVALID_ARGUMENT;
+    if ((reinterpret_cast<std::uintptr_t>(device_words) % sizeof(unsigned long long)) != 0) return NB_ERR_INVALID_ARGUMENT;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(clock_probe, dim3(static_cast<unsigned>(workgroups)), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), static_cast<unsigned long long*>(device_words),
+                       static_cast<unsigned long long>(microseconds) * 100ull);
+    return static_cast<int>(hipGetLastError());
+}
 
 int nb_set_alloc_limit(size_t bytes) {
     nb::alloc_limit().store(bytes);

@@ -169,6 +169,10 @@ hipEvent_t pair_probe_event();
 // bytes (0 = no limit).  libnbody_hip.so has no way to set it; the lab library's nb_set_alloc_limit does (defined in nbody_capi.hip).
 std::atomic<size_t>& alloc_limit();
 
+// nb_set_pair_clock_words (tuning header): device memory for the in-kernel clock reading (pair_forces_clocked: any launch of the
+// R = 8, S = 8 geometry whose workgroups fit), and its size in bytes; nullptr = none (defined in nbody_capi.hip)
+unsigned long long* pair_clock_words(size_t* bytes);
+
 // nb_set_pair_plan_override: 0 = automatic (defined in nbody_capi.hip; the multi-GPU layer honours it for its tiles too)
 void pair_plan_overrides(int* vectors_per_lane, int* waves, int* splits);
 

@@ -50,11 +50,23 @@
 
 #ifdef NB_PAIR_STAMPS
 // Diagnostic build only (tools/build_pair_variant.sh stamps "-DNB_PAIR_STAMPS", read by tools/pair_stamps.py): per wave of the LAST
-// pair_forces launch, {start, entry of the unit loop, its exit} in s_memtime ticks + where the hardware put the wave.
-__device__ unsigned long long nb_pair_stamps[8192 * 6];
+// pair_forces launch, {start, entry of the unit loop, its exit} in s_memtime ticks + where the hardware put the wave + (round 6) start
+// and exit on the constant 100 MHz counter (s_memrealtime): exit - start on the two counters is the IN-KERNEL clock (tools/inkernel_clock.py).
+__device__ unsigned long long nb_pair_stamps[8192 * 8];
 extern "C" __attribute__((visibility("default"))) int nb_debug_read_pair_stamps(void* host, size_t bytes) {
     return static_cast<int>(hipMemcpyFromSymbol(host, HIP_SYMBOL(nb_pair_stamps), bytes, 0, hipMemcpyDeviceToHost));
 }
+#endif
+
+// The workspace planes (reaction sums, i-side sums) are written once by pair_forces and read once by pair_finish / pair_reduce.  With
+// -DNB_PAIR_NONTEMPORAL (tools/build_pair_variant.sh; the A/B of round 6: profiles/round6_nontemporal_ab.txt) those accesses carry the
+// non-temporal hint, so that the streaming planes do not evict the 4 MiB position array from each XCD's L2.  Without the flag: plain accesses.
+#ifdef NB_PAIR_NONTEMPORAL
+#define NB_WS_STORE(ptr, value) __builtin_nontemporal_store((value), (ptr))
+#define NB_WS_LOAD(ptr) __builtin_nontemporal_load(ptr)
+#else
+#define NB_WS_STORE(ptr, value) (*(ptr) = (value))
+#define NB_WS_LOAD(ptr) (*(ptr))
 #endif
 
 namespace nb {
@@ -99,347 +111,20 @@ template <typename T> __device__ __forceinline__ bool usable_unit(T m) {
 // vector instructions per directed interaction) takes 256 VGPRs at two waves per SIMD (one 8-wave workgroup per CU), or ~168 with
 // spills outside the rotation loops at three (one 12-wave workgroup per CU: used where twelve waves divide a block's units evenly).
 template <int R, int S> constexpr int kPairWavesPerSimd = R <= 4 ? 4 : (S == 12 ? 3 : 2);
-template <typename T, int R, int S> __global__ __launch_bounds__(64 * S) __attribute__((amdgpu_waves_per_eu(kPairWavesPerSimd<R, S>, kPairWavesPerSimd<R, S>))) void pair_forces(PairArgs<T> s) {
-    using LT            = Lane<T>;
-    using vec4          = typename LT::vec4;
-    using vec           = typename LT::vec;
-    using bits          = typename LT::bits;
-    constexpr int W     = LT::W;
-    constexpr int I     = R * W;    // bodies i per lane
-    constexpr int BLOCK = 64 * I;   // bodies per block
-    constexpr int TB    = I;        // 64-body tiles per block
-#ifndef NB_PAIR_UNR
-#define NB_PAIR_UNR 4
-#endif
-#ifndef NB_PAIR_RB
-#define NB_PAIR_RB 2
-#endif
-    constexpr int UNR   = NB_PAIR_UNR;  // steps per trip of the rotation loop
-
-    extern __shared__ __attribute__((aligned(32))) unsigned char smem_raw[];
-#ifdef NB_PAIR_STAMPS
-    const unsigned long long stamp_start = __builtin_amdgcn_s_memtime();
-#endif
-
-    const vec4* __restrict__ old_pos = reinterpret_cast<const vec4*>(s.old_pos);
-    const int      tid  = threadIdx.x;
-    const int      wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int      lane = tid & 63;
-    const unsigned a    = blockIdx.x / s.splits;  // the block whose bodies i this workgroup holds
-    const unsigned c    = blockIdx.x % s.splits;
-
-
-    // bodies i of this lane: block_base + k*64 + lane (coalesced across the wave); a body beyond the range sits on its last body with mass 0
-    const unsigned block_base = s.i_begin + a * BLOCK;
-    const unsigned i_end      = s.i_begin + s.i_count;
-    vec            px[R], py[R], pz[R], ax[R], ay[R], az[R];
-    // Is the block ONE species -- every body i real and of the same mass m_block?  (Wave-uniform answer: each wave holds the whole block.)
-    const T    m_block    = old_pos[block_base < i_end ? block_base : i_end - 1].w;  // (uniform address)
-    const bits block_bits = __builtin_bit_cast(bits, m_block);
-    bool       same       = true;
-#pragma unroll
-    for (int k = 0; k < I; ++k) {
-        const unsigned i = block_base + k * 64 + lane;
-        const vec4     p = old_pos[i < i_end ? i : i_end - 1];
-        LT::set(px[k / W], k % W, p.x);
-        LT::set(py[k / W], k % W, p.y);
-        LT::set(pz[k / W], k % W, p.z);
-        same = same && i < i_end && __builtin_bit_cast(bits, p.w) == block_bits;
-    }
-    const bool block_uniform = __builtin_amdgcn_ballot_w64(!same) == 0 && usable_unit(m_block);
-#pragma unroll
-    for (int r = 0; r < R; ++r) ax[r] = ay[r] = az[r] = LT::splat(0);
-    vec eps2 = LT::splat(s.eps2);
-    LT::keep_in_vgpr(eps2);
-    const typename LT::Consts consts = LT::make_consts();
-
-    // ---- LDS: [S][3*I][64] second-level sums (fp32) -- later the fold buffer -- then the progress words ---------------------
-    constexpr size_t kSumBytes = static_cast<size_t>(S) * 3 * I * 64 * sizeof(T);
-    T* const         sums      = reinterpret_cast<T*>(smem_raw);
-    unsigned* const  balance   = reinterpret_cast<unsigned*>(smem_raw + kSumBytes);
-    unsigned* const  simd_count = balance;                                            // [4] waves of this workgroup per SIMD
-    volatile unsigned* progress = reinterpret_cast<volatile unsigned*>(balance + 4);  // [4][8] units done, by SIMD and slot
-    if (tid < 36) balance[tid] = tid < 4 ? 0u : 0xffffffffu;
-    __syncthreads();
-    // SIMD-mate balancing as in nbody_fast.hip: the arbiter is oldest-first, s_setprio outranks age -- a wave level with the
-    // slowest wave of its SIMD (same workgroup) runs at priority 3, one that is ahead at 0; the unit -> wave map stays static.
-    const unsigned simd = static_cast<unsigned>(__builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4));  // HW_REG_HW_ID[5:4] = SIMD_ID
-    unsigned       slot = 0;
-    if (lane == 0) slot = atomicAdd(&simd_count[simd], 1u);
-    slot = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(slot))) & 7u;
-    volatile unsigned* const mine = progress + simd * 8;
-    unsigned                 done = 0;
-    if (lane == 0) mine[slot] = 0;
-
-    // fp32: a register sum collects at most kFlush tiles (1 024 bodies j), then joins the lane's second-level sum in LDS
-    constexpr bool     kTwoLevel = sizeof(T) == 4;
-    constexpr unsigned kFlush    = 16;
-    T* const           second    = sums + static_cast<size_t>(wave) * (3 * I * 64) + lane;
-    if constexpr (kTwoLevel) {
-#pragma unroll
-        for (int q = 0; q < 3 * I; ++q) second[q * 64] = 0;
-    }
-    // The register sums are kept in units of `unit`: the mass of the species whose tiles the wave is working through (a tile of
-    // ONE species runs the loop without a mass multiply; when the species changes the sums are re-expressed once: 3R multiplies
-    // per change, a handful per step for a galaxy file).  The second-level sums and everything stored are in absolute units.
-    T unit = T(1);
-    auto flush = [&]() {
-#pragma unroll
-        for (int k = 0; k < I; ++k) {
-            second[(0 * I + k) * 64] = __builtin_fma(LT::get(ax[k / W], k % W), unit, second[(0 * I + k) * 64]);
-            second[(1 * I + k) * 64] = __builtin_fma(LT::get(ay[k / W], k % W), unit, second[(1 * I + k) * 64]);
-            second[(2 * I + k) * 64] = __builtin_fma(LT::get(az[k / W], k % W), unit, second[(2 * I + k) * 64]);
-        }
-#pragma unroll
-        for (int r = 0; r < R; ++r) ax[r] = ay[r] = az[r] = LT::splat(0);
-    };
-    auto change_unit = [&](T to) {  // (wave-uniform)
-        const vec ratio = LT::splat(unit / to);
-#pragma unroll
-        for (int r = 0; r < R; ++r) ax[r] = ax[r] * ratio, ay[r] = ay[r] * ratio, az[r] = az[r] * ratio;
-        unit = to;
-    };
-
-    // ---- the units of this wave ------------------------------------------------------------------------------------------
-    const unsigned NB      = s.blocks;
-    const unsigned Q       = NB / 2;
-    const bool     even    = (NB & 1u) == 0;
-    const bool     diag    = s.diag != 0;
-    const unsigned j_end   = s.j_begin + s.j_count;
-    const unsigned n_units = diag ? (s.unit_count != 0 ? s.unit_count : (Q + 1) * TB) : (s.j_count + 63) / 64;  // (a diagonal launch may take a RANGE of the tournament's units: PairArgs::unit_begin)
-    const unsigned G       = s.splits * S;
-    // Which units are this wave's.  s.deal == 2 (what launch_pair_tile takes when the LDS allows): the first floor(n_units / (C*S)) * C*S
-    // units are dealt whole, unit u to slot u mod (C*S) = c*S + wave -- every wave the same number --, and each of the units left over
-    // (the "tail": fewer than C*S) goes to ONE workgroup (tail unit t to workgroup t mod C) which runs it as FOUR QUARTERS of sixteen
-    // rotation steps, one per SIMD (quarter p on a wave with wave % 4 == p, the workgroup's tail units taking turns between the
-    // S/4 waves of a SIMD): a quarter's lanes load the tile rotated by 16p lanes, so that sixteen steps bring lane l exactly the
-    // bodies that the steps 16p .. 16p+15 of a whole unit would have, and the four partial reaction sums of a body meet in LDS
-    // (fixed order) before one store.  (The waves 0-3 of a workgroup sit on four different SIMDs and wave w + 4 on the SIMD of
-    // wave w -- in all 256 workgroups of a launch, by the stamps of tools/pair_stamps.py, profiles/round4_wave_exit_stamps.txt; only the
-    // balance rests on that, not the result.)  Every SIMD of a block's workgroups then carries the same load to a quarter of a unit:
-    // 16 384 bodies are 33 units per 8-wave workgroup -- 8.25 per SIMD instead of 9 for the one that held the wave with five.
-    // s.deal == 0 / 1: every unit whole, unit u to slot u mod (C*S), the slots blocked (c*S + wave) or interleaved (wave*C + c: the
-    // waves with one unit more are the low wave ids of EVERY workgroup; round 4's first answer to the remainder, kept for launches
-    // whose LDS has no room for the quarters' sums).
-    const bool     quartered = s.deal == 2;
-    const unsigned g         = s.deal == 1 ? static_cast<unsigned>(wave) * s.splits + c : c * S + static_cast<unsigned>(wave);
-    const unsigned dealt     = quartered ? n_units / G * G : n_units;                                   // units below this are dealt whole
-    const unsigned n_whole   = g < dealt ? (dealt - g + G - 1) / G : 0;                                 // ... u = g, g + G, ...
-    const unsigned wg_tail   = (n_units - dealt) > c ? (n_units - dealt - c + s.splits - 1) / s.splits : 0;  // tail units of this workgroup (<= S)
-    constexpr unsigned kPerSimd = S / 4;                                                              // waves of a workgroup per SIMD
-    const unsigned my_quarter = static_cast<unsigned>(wave) & 3u, my_turn = static_cast<unsigned>(wave) >> 2;
-    const unsigned n_quarters = wg_tail > my_turn ? (wg_tail - my_turn + kPerSimd - 1) / kPerSimd : 0;
-    const unsigned n_items    = n_whole + n_quarters;
-    auto item_tail = [&](unsigned it) { return my_turn + (it - n_whole) * kPerSimd; };                  // which of the workgroup's tail units
-    auto item_unit = [&](unsigned it) { return s.unit_begin + (it < n_whole ? g + it * G : dealt + c + item_tail(it) * s.splits); };  // (absolute: the tile and the offset q follow from it)
-    auto item_shift = [&](unsigned it) { return it < n_whole ? 0u : 16u * my_quarter; };
-
-    auto tile_first = [&](unsigned u) {
-        if (!diag) return s.j_begin + u * 64;
-        unsigned jb = a + u / TB;
-        if (jb >= NB) jb -= NB;
-        return s.j_begin + jb * BLOCK + (u % TB) * 64;
-    };
-    auto load_tile = [&](unsigned u, unsigned shift) {  // lane l takes the tile's body (l - shift) mod 64
-        const unsigned j = tile_first(u) + ((static_cast<unsigned>(lane) - shift) & 63u);
-        vec4           p = old_pos[j < j_end ? j : j_end - 1];
-        if (j >= j_end) p.w = 0;
-        return p;
-    };
-
-    // one rotation step: the lane's bodies i against the body j it holds right now; then the body j and its sums move on.
-    // Written stage by stage over the R vectors (all differences, all squared distances, ...): R independent chains.
-    // MJ: the bodies j of the tile differ in mass (m_j / unit travels with the body and multiplies the i side);
-    // MI: the bodies i of the block differ in mass (their masses multiply the reaction side)
-    auto step = [&]<bool MI, bool MJ>(T& jx, T& jy, T& jz, T& jm, vec& rx, vec& ry, vec& rz, const vec (&mi)[R]) {
-        constexpr int RB = R < NB_PAIR_RB ? R : NB_PAIR_RB;  // vectors per stage block (more in flight at once spills at R = 4)
-        const vec     bx = LT::splat(jx), by = LT::splat(jy), bz = LT::splat(jz);
-        vec           mj = bx;
-        if constexpr (MJ) mj = LT::splat(jm);  // m_j / unit
-#pragma unroll
-        for (int h = 0; h < R; h += RB) {
-            vec dx[RB], dy[RB], dz[RB], w[RB];
-#pragma unroll
-            for (int r = 0; r < RB; ++r) dx[r] = bx - px[h + r], dy[r] = by - py[h + r], dz[r] = bz - pz[h + r];
-#pragma unroll
-            for (int r = 0; r < RB; ++r) w[r] = LT::fma(dx[r], dx[r], eps2);
-#pragma unroll
-            for (int r = 0; r < RB; ++r) w[r] = LT::fma(dy[r], dy[r], w[r]);
-#pragma unroll
-            for (int r = 0; r < RB; ++r) w[r] = LT::fma(dz[r], dz[r], w[r]);
-#pragma unroll
-            for (int r = 0; r < RB; ++r) w[r] = LT::template coupling_rel<true>(eps2, w[r], consts);  // d2^(-3/2)
-#pragma unroll
-            for (int r = 0; r < RB; ++r) {
-                vec wi = w[r], wj = w[r];
-                if constexpr (MJ) wi = mj * w[r];
-                if constexpr (MI) wj = mi[h + r] * w[r];
-                ax[h + r] = LT::fma(dx[r], wi, ax[h + r]), ay[h + r] = LT::fma(dy[r], wi, ay[h + r]), az[h + r] = LT::fma(dz[r], wi, az[h + r]);
-                rx = LT::fma(dx[r], wj, rx), ry = LT::fma(dy[r], wj, ry), rz = LT::fma(dz[r], wj, rz);
-            }
-        }
-        // the body j and everything that belongs to it move on by one lane
-        jx = rotate(jx), jy = rotate(jy), jz = rotate(jz);
-        if constexpr (MJ) jm = rotate(jm);
-        rx = rotate(rx), ry = rotate(ry), rz = rotate(rz);
-    };
-    auto rotation_steps = [&]<bool MI, bool MJ>(int trips, T& jx, T& jy, T& jz, T& jm, vec& rx, vec& ry, vec& rz, const vec (&mi)[R]) {  // trips x UNR steps: 64 for a unit, 16 for a quarter
-#pragma unroll 1
-        for (int it = 0; it < trips; ++it) {
-#pragma unroll
-            for (int v = 0; v < UNR; ++v) step.template operator()<MI, MJ>(jx, jy, jz, jm, rx, ry, rz, mi);
-        }
-    };
-
-#ifdef NB_PAIR_STAMPS
-    const unsigned long long stamp_loop = __builtin_amdgcn_s_memtime();
-#endif
-    // the sums of the quarters, per tail unit of the workgroup: [wg_tail <= S][quarter][component][body of the tile]
-    T* const tail_sums = reinterpret_cast<T*>(smem_raw + kSumBytes + 256);
-    vec4     cur       = n_items > 0 ? load_tile(item_unit(0), item_shift(0)) : vec4{};
-    for (unsigned item = 0; item < n_items; ++item) {
-        const unsigned u     = item_unit(item);
-        const unsigned shift = item_shift(item);
-        const bool     whole = item < n_whole;
-        const vec4     next  = (item + 1) < n_items ? load_tile(item_unit(item + 1), item_shift(item + 1)) : cur;  // in flight across the steps below
-#ifndef NB_NO_BALANCE
-        {
-            unsigned least = done;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) least = min(least, mine[q]);  // unsynchronised reads: a stale value only delays a priority change
-            if (static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(least))) >= done) {
-                __builtin_amdgcn_s_setprio(3);
-            } else {
-                __builtin_amdgcn_s_setprio(0);
-            }
-        }
-#endif
-        const unsigned q     = u / TB;  // (diag: the block offset)
-        const unsigned first = tile_first(u);
-        const unsigned j     = first + ((static_cast<unsigned>(lane) - shift) & 63u);  // the body this lane holds at the start
-        // Is the tile ONE species -- every body j real and of one usable mass?  Then no mass multiplies the i side: the wave's
-        // i-side sums are in units of the tile's mass.  Likewise the block: its mass multiplies the reaction sums when they are stored.
-        const T    m_tile       = first_lane(cur.w);
-        const bool tile_uniform = usable_unit(m_tile) && __builtin_amdgcn_ballot_w64(!(j < j_end && __builtin_bit_cast(bits, cur.w) == __builtin_bit_cast(bits, m_tile))) == 0;
-        T   jx = cur.x, jy = cur.y, jz = cur.z, jm = 0;
-        vec rx = LT::splat(0), ry = LT::splat(0), rz = LT::splat(0);
-        if (tile_uniform && __builtin_bit_cast(bits, m_tile) != __builtin_bit_cast(bits, unit)) change_unit(m_tile);
-        if (!tile_uniform) jm = cur.w / unit;  // mixed masses: m_j / unit travels with the body j
-        const T   scale = block_uniform ? m_block : T(1);  // what the reaction sums are still to be multiplied by
-        const int trips = whole ? 64 / UNR : 16 / UNR;
-        if (block_uniform) {
-            vec none[R] = {};  // (these loops never read the masses of the bodies i)
-            if (tile_uniform) rotation_steps.template operator()<false, false>(trips, jx, jy, jz, jm, rx, ry, rz, none);
-            else rotation_steps.template operator()<false, true>(trips, jx, jy, jz, jm, rx, ry, rz, none);
-        } else {
-            vec mi[R];  // the masses of the bodies i: only these paths hold them, and only while they run
-#pragma unroll
-            for (int k = 0; k < I; ++k) {
-                const unsigned i = block_base + k * 64 + lane;
-                LT::set(mi[k / W], k % W, i < i_end ? old_pos[i].w : T(0));
-            }
-            if (tile_uniform) rotation_steps.template operator()<true, false>(trips, jx, jy, jz, jm, rx, ry, rz, mi);
-            else rotation_steps.template operator()<true, true>(trips, jx, jy, jz, jm, rx, ry, rz, mi);
-        }
-        // 64 steps on: every sum is back in the lane of its body j.  Keep the reaction only when the partner does not list the pair too.
-        const bool     symmetric = diag ? (q != 0 && !(even && q == Q)) : (s.keep != 0);
-        const unsigned slot_of   = diag ? q - 1 : a;
-        if (whole) {
-            if (symmetric && j < j_end) {
-                T* const out = s.react + static_cast<size_t>(slot_of) * 3 * s.react_plane + (j - s.react_origin);
-                out[0]                                      = both_halves(rx) * scale;
-                out[static_cast<size_t>(s.react_plane)]     = both_halves(ry) * scale;
-                out[2 * static_cast<size_t>(s.react_plane)] = both_halves(rz) * scale;
-            }
-        } else if (symmetric) {
-            // a quarter: sixteen steps on the lane holds the body that started sixteen lanes back; its sums wait in LDS for the other three
-            const unsigned m   = (static_cast<unsigned>(lane) - shift - 16u) & 63u;
-            T* const       out = tail_sums + (static_cast<size_t>(item_tail(item)) * 4 + my_quarter) * 3 * 64 + m;
-            out[0] = both_halves(rx), out[64] = both_halves(ry), out[128] = both_halves(rz);
-        }
-        cur = next;
-        ++done;
-        if constexpr (kTwoLevel) {
-            if (done % kFlush == 0) flush();
-        }
-        if (lane == 0) mine[slot] = done;
-    }
-    if (lane == 0) mine[slot] = 0xffffffffu;  // finished: never the one the others defer to
-    __builtin_amdgcn_s_setprio(0);
-#ifdef NB_PAIR_STAMPS
-    {
-        const unsigned long long stamp_done = __builtin_amdgcn_s_memtime();
-        const unsigned           hw         = static_cast<unsigned>(__builtin_amdgcn_s_getreg((15 << 11) | (0 << 6) | 4));   // HW_ID[15:0]
-        const unsigned           xcc        = static_cast<unsigned>(__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20));   // XCC_ID
-        const unsigned           w          = blockIdx.x * S + static_cast<unsigned>(wave);
-        if (lane == 0 && w < 8192) {
-            nb_pair_stamps[w * 6 + 0] = stamp_start, nb_pair_stamps[w * 6 + 1] = stamp_loop, nb_pair_stamps[w * 6 + 2] = stamp_done;
-            nb_pair_stamps[w * 6 + 3] = (static_cast<unsigned long long>(xcc) << 32) | hw;
-            nb_pair_stamps[w * 6 + 4] = (static_cast<unsigned long long>(wave) << 32) | done;
-            nb_pair_stamps[w * 6 + 5] = (static_cast<unsigned long long>(simd) << 32) | slot;
-        }
-    }
-#endif
-    {  // absolute units from here on
-        const vec to_absolute = LT::splat(unit);
-#pragma unroll
-        for (int r = 0; r < R; ++r) ax[r] = ax[r] * to_absolute, ay[r] = ay[r] * to_absolute, az[r] = az[r] * to_absolute;
-    }
-    if constexpr (kTwoLevel) {
-#pragma unroll
-        for (int k = 0; k < I; ++k) {
-            LT::set(ax[k / W], k % W, second[(0 * I + k) * 64] + LT::get(ax[k / W], k % W));
-            LT::set(ay[k / W], k % W, second[(1 * I + k) * 64] + LT::get(ay[k / W], k % W));
-            LT::set(az[k / W], k % W, second[(2 * I + k) * 64] + LT::get(az[k / W], k % W));
-        }
-    }
-
-    // fold the S partial sums (waves 1..S-1 -> wave 0) through LDS, fixed order; the second-level sums are done with
-    __syncthreads();
-    // the tail units of the workgroup: a body's four quarter sums, in quarter order, then the one store a whole unit would have made
-    for (unsigned k = static_cast<unsigned>(wave); k < wg_tail; k += S) {
-        const unsigned u         = s.unit_begin + dealt + c + k * s.splits;
-        const unsigned q         = u / TB;
-        const bool     symmetric = diag ? (q != 0 && !(even && q == Q)) : (s.keep != 0);
-        const unsigned j         = tile_first(u) + lane;
-        if (!symmetric || j >= j_end) continue;
-        const T        scale     = block_uniform ? m_block : T(1);
-        const T* const in        = tail_sums + static_cast<size_t>(k) * 4 * 3 * 64 + lane;
-        T* const       out       = s.react + static_cast<size_t>(diag ? q - 1 : a) * 3 * s.react_plane + (j - s.react_origin);
-#pragma unroll
-        for (int comp = 0; comp < 3; ++comp) out[static_cast<size_t>(comp) * s.react_plane] = (((in[comp * 64] + in[(3 + comp) * 64]) + in[(6 + comp) * 64]) + in[(9 + comp) * 64]) * scale;
-    }
-    T* const red = sums;  // [(S-1)][3][I][64]
-    if (wave > 0) {
-#pragma unroll
-        for (int k = 0; k < I; ++k) {
-            red[(((wave - 1) * 3 + 0) * I + k) * 64 + lane] = LT::get(ax[k / W], k % W);
-            red[(((wave - 1) * 3 + 1) * I + k) * 64 + lane] = LT::get(ay[k / W], k % W);
-            red[(((wave - 1) * 3 + 2) * I + k) * 64 + lane] = LT::get(az[k / W], k % W);
-        }
-    }
-    __syncthreads();
-    if (wave != 0) return;
-#pragma unroll 1
-    for (int w = 1; w < S; ++w) {
-#pragma unroll
-        for (int k = 0; k < I; ++k) {
-            LT::set(ax[k / W], k % W, LT::get(ax[k / W], k % W) + red[(((w - 1) * 3 + 0) * I + k) * 64 + lane]);
-            LT::set(ay[k / W], k % W, LT::get(ay[k / W], k % W) + red[(((w - 1) * 3 + 1) * I + k) * 64 + lane]);
-            LT::set(az[k / W], k % W, LT::get(az[k / W], k % W) + red[(((w - 1) * 3 + 2) * I + k) * 64 + lane]);
-        }
-    }
-    T* const self = s.self + static_cast<size_t>(s.self_first + c) * 3 * s.self_plane;
-#pragma unroll
-    for (int k = 0; k < I; ++k) {
-        const unsigned i = block_base + k * 64 + lane;
-        if (i >= i_end) continue;
-        const size_t at = i - s.self_origin;
-        self[at]                                         = LT::get(ax[k / W], k % W);
-        self[static_cast<size_t>(s.self_plane) + at]     = LT::get(ay[k / W], k % W);
-        self[2 * static_cast<size_t>(s.self_plane) + at] = LT::get(az[k / W], k % W);
-    }
-}
+#define NB_PAIR_KERNEL pair_forces
+#define NB_PAIR_CLOCK_PARAM
+#define NB_PAIR_CLOCKED 0
+#include "nbody_pair_forces.inc"
+#undef NB_PAIR_KERNEL
+#undef NB_PAIR_CLOCK_PARAM
+#undef NB_PAIR_CLOCKED
+#define NB_PAIR_KERNEL pair_forces_clocked
+#define NB_PAIR_CLOCK_PARAM , unsigned long long* clock_words
+#define NB_PAIR_CLOCKED 1
+#include "nbody_pair_forces.inc"
+#undef NB_PAIR_KERNEL
+#undef NB_PAIR_CLOCK_PARAM
+#undef NB_PAIR_CLOCKED
 
 // The three component sums over `slots` reaction planes, q ascending, as four interleaved running sums (shorter chains, smaller
 // rounding error), wave w of the 256-thread workgroup taking q = w, w+4, ...; the caller combines (t0 + t1) + (t2 + t3).
@@ -454,7 +139,7 @@ template <typename T> __device__ __forceinline__ void quarter_sums(const T* r, s
         for (int u = 0; u < 8; ++u) {
             const bool there = (q + 4 * u) < full;
 #pragma unroll
-            for (int c = 0; c < 3; ++c) v[c][u] = there ? r[(static_cast<size_t>(q + 4 * u) * 3 + c) * plane] : T(0);
+            for (int c = 0; c < 3; ++c) v[c][u] = there ? NB_WS_LOAD(r + (static_cast<size_t>(q + 4 * u) * 3 + c) * plane) : T(0);
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
@@ -465,7 +150,7 @@ template <typename T> __device__ __forceinline__ void quarter_sums(const T* r, s
     if (wave == 0) {
         for (unsigned k = full; k < slots; ++k) {  // the odd slots join t0
 #pragma unroll
-            for (int c = 0; c < 3; ++c) t[c] += r[(static_cast<size_t>(k) * 3 + c) * plane];
+            for (int c = 0; c < 3; ++c) t[c] += NB_WS_LOAD(r + (static_cast<size_t>(k) * 3 + c) * plane);
         }
     }
 }
@@ -501,7 +186,7 @@ template <typename T> __global__ __launch_bounds__(256) void pair_finish(FinishA
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
 #pragma unroll
-                    for (int comp = 0; comp < 3; ++comp) x[i][comp] = (c0 + i) < set.slots ? s.self[(static_cast<size_t>(set.slot + c0 + i) * 3 + comp) * s.self_plane + k] : T(0);
+                    for (int comp = 0; comp < 3; ++comp) x[i][comp] = (c0 + i) < set.slots ? NB_WS_LOAD(s.self + (static_cast<size_t>(set.slot + c0 + i) * 3 + comp) * s.self_plane + k) : T(0);
                 }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -573,8 +258,23 @@ template <typename T, int R, int S> hipError_t launch_rs(const PairArgs<T>& args
     if (lds_bytes > 64u * 1024u) {
         if (const auto err = allow_large_lds<&pair_forces<T, R, S>>(); err != hipSuccess) return err;
     }
+    unsigned long long* clock_words = nullptr;
+    if constexpr (R == 8 && S == 8) {  // nb_set_pair_clock_words: two 64-bit words per workgroup of this launch, when there is room for them
+        size_t capacity = 0;
+        unsigned long long* lent = pair_clock_words(&capacity);
+        if (lent != nullptr && capacity >= static_cast<size_t>(grid) * 16) clock_words = lent;
+        if (lds_bytes > 64u * 1024u && clock_words != nullptr) {
+            if (const auto err = allow_large_lds<&pair_forces_clocked<T, R, S>>(); err != hipSuccess) return err;
+        }
+    }
     if (prepare_only) return hipSuccess;
     (void)hipGetLastError();  // a launch reports ITS OWN error: the call returns, and clears, the thread's last error whatever left it (a refused allocation, say)
+    if constexpr (R == 8 && S == 8) {
+        if (clock_words != nullptr) {
+            hipLaunchKernelGGL((pair_forces_clocked<T, R, S>), dim3(grid), dim3(64 * S), lds_bytes, stream, args, clock_words);
+            return hipGetLastError();
+        }
+    }
     hipLaunchKernelGGL((pair_forces<T, R, S>), dim3(grid), dim3(64 * S), lds_bytes, stream, args);
     return hipGetLastError();
 }

@@ -57,6 +57,12 @@ NB_API int nb_comm_self_transfer_f32(nb_comm_t comm, const float* src, float* ds
 NB_API int nb_comm_replace_side_stream(nb_comm_t comm);
 
 
+/* A clock read from the chip itself: `workgroups` single-wave workgroups (consecutive ones land on different XCDs) each stamp the
+ * shader-cycle counter (s_memtime) and the constant 100 MHz counter (s_memrealtime) around a spin of `microseconds` and write four 64-bit
+ * words -- {shader cycles, 100 MHz ticks, XCC_ID, HW_ID} -- to device_words[4 * workgroup] (caller-owned device memory).  MHz = 100 *
+ * cycles / ticks.  An experiment (tools/inkernel_clock.py): launched right behind a dense kernel it does NOT read that kernel's clock. */
+NB_API int nb_clock_probe_launch(void* device_words, int workgroups, unsigned microseconds, nb_stream_t stream);
+
 /* Tests of the out-of-memory fall-backs (halve the workspace and ask again; step without one): every nb_alloc request above
  * `bytes` is refused BY THE RUNTIME (the request is replaced by one no device can serve), 0 = no limit.  The CLI's
  * --alloc-limit-mib sets it when the lab library is the one in the process (LD_PRELOAD), and says so when it is not. */

@@ -95,6 +95,16 @@ NB_API int nb_comm_last_enqueue_ms(nb_comm_t comm, double* milliseconds);
  * bench.py times the two kernels of the headline step separately with it, after the timed region. */
 NB_API int nb_set_pair_probe_event(nb_event_t event);
 
+/* The clock the headline kernel REALLY runs at.  While device memory is lent here (16 bytes per workgroup of the launch: nb_pair_plan_t.grid_blocks;
+ * NULL, 0 takes it back), the one-GPU pairwise step launches pair_forces_clocked instead of pair_forces -- the same kernel with four
+ * scalar instructions more: every workgroup notes its lifetime in shader cycles (s_memtime) and in ticks of the constant 100 MHz counter
+ * (s_memrealtime) as two 64-bit words at device_words[2 * workgroup].  Clock in MHz = 100 * cycles / ticks (median over the
+ * workgroups).  Only the geometry of the headline sizes has the variant (8 vectors per lane, 8 waves: 65 536 bodies and more in fp32);
+ * other launches ignore the words.  bench.py reads it after its timed region: the power management's own figure (hwmon) reads higher
+ * and lags, and nothing launched BEHIND the kernel can tell -- the chip raises its clock within microseconds of the kernel's exit
+ * (profiles/round6_delivered_clock.txt). */
+NB_API int nb_set_pair_clock_words(void* device_words, size_t bytes);
+
 /* The device memory the library assumes when it decides whether a workspace is affordable (at most a third of it is ever asked
  * for): 0 = the device's own total; tests of the guard set a small figure. */
 NB_API int nb_set_memory_budget(size_t bytes);

@@ -9,5 +9,5 @@ S=cuda-nbody_amd/csrc
 # built before a header change mixes struct layouts (round 4's GPU memory fault was exactly that, in the main build)
 make -s -j8 -C $S
 /opt/rocm/bin/hipcc -O3 -std=c++20 --offload-arch=gfx950 -fPIC -fvisibility=hidden -w $2 -c $S/nbody_pair.hip -o expv/pair_$1.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o expv/libnbody_hip_$1.so $S/nbody_strict.o $S/nbody_fast.o expv/pair_$1.o $S/nbody_capi.o $S/nbody_comm.o -ldl
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o expv/libnbody_hip_$1.so $S/nbody_strict.o $S/nbody_fast.o expv/pair_$1.o $S/nbody_capi.o $S/nbody_comm.o -ldl -lpthread
 rm -f expv/pair_$1.o

@@ -27,11 +27,11 @@ for _ in range(20):
     s.update(np.float32(0.016))
 s.synchronize()
 waves = pl.grid_blocks * pl.waves_per_block
-raw = np.zeros(8192 * 6, np.uint64)
+raw = np.zeros(8192 * 8, np.uint64)
 fn = ctypes.CDLL(pkg.LIB_PATH).nb_debug_read_pair_stamps
 fn.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
 assert fn(raw.ctypes.data_as(ctypes.c_void_p), raw.nbytes) == 0
-st = raw.reshape(8192, 6)[:min(waves, 8192)]
+st = raw.reshape(8192, 8)[:min(waves, 8192)]
 hw = (st[:, 3] & 0xffff).astype(int)
 # s_memtime counters have different origins in different parts of the chip: take times relative to the first wave of the same CU
 xcc_reg = (st[:, 3] >> 32).astype(int)

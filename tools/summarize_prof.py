@@ -53,8 +53,18 @@ if "GRBM_GUI_ACTIVE" in counters:
     d["effective_clock_GHz"] = counters["GRBM_GUI_ACTIVE"] / 8 / avg_ns  # summed over the 8 XCDs
     cycles = counters["GRBM_GUI_ACTIVE"] / 8
     if "SQ_ACTIVE_INST_VALU" in counters:
-        # SQ_ACTIVE_INST_* count quad-cycles summed over all SIMDs (256 CUs x 4)
-        d["valu_busy_fraction"] = counters["SQ_ACTIVE_INST_VALU"] * 4 / (cycles * 1024)
+        # SQ_ACTIVE_INST_* count quad-cycles summed over all SIMDs (256 CUs x 4); GRBM_GUI_ACTIVE comes from ANOTHER pass (another launch, another
+        # clock): kept for the record only
+        d["valu_busy_vs_grbm_of_another_pass"] = counters["SQ_ACTIVE_INST_VALU"] * 4 / (cycles * 1024)
+if "SQ_ACTIVE_INST_VALU" in counters and "SQ_BUSY_CYCLES" in counters:
+    # Numerator and denominator of ONE pass (round-5 review: the figure above divided by a GRBM_GUI_ACTIVE of another launch and read 1.011):
+    # SQ_BUSY_CYCLES sums the busy cycles of the 32 shader engines (4 per XCD), SQ_ACTIVE_INST_VALU quad-cycles over the 1 024 SIMDs.  With two
+    # waves per SIMD the windows in which each has a vector instruction active can overlap, so the raw quotient can pass 1: it is kept as
+    # `valu_busy_raw`, and `valu_busy_fraction` says min(raw, 1) -- read a capped value as ">= 0.99".
+    raw = counters["SQ_ACTIVE_INST_VALU"] * 4 / (counters["SQ_BUSY_CYCLES"] / 32 * 1024)
+    d["valu_busy_raw"] = raw
+    d["valu_busy_fraction"] = min(raw, 1.0)
+    d["valu_busy_counts"] = "SQ_ACTIVE_INST_VALU x 4 / (SQ_BUSY_CYCLES / 32 x 1024 SIMDs), same --pmc pass; capped at 1 (the active windows of a SIMD's two waves overlap)"
 if "SQ_INSTS_VALU" in counters:
     d["valu_wave_instructions_per_launch"] = counters["SQ_INSTS_VALU"]
 # the launch plan and commit the counters belong to (bench.py only quotes `traffic` from a summary whose plan matches its own)
