@@ -27,14 +27,18 @@ def newest(pattern):
 
 stats = newest(f"{src}/trace/*/*_kernel_stats.csv")
 shutil.copy(stats, f"{prefix}_kernel_stats.csv")
-kernel_row = next(r for r in csv.DictReader(open(stats)) if KERNEL in r["Name"])
+def is_kernel(name):
+    """the kernel asked for -- not its clock-reading twin (pair_forces_clocked: ten launches after bench.py's timed region)"""
+    return KERNEL in name and (("_clocked" in KERNEL) or "_clocked" not in name)
+
+kernel_row = next(r for r in csv.DictReader(open(stats)) if is_kernel(r["Name"]))
 
 counters = {}
 meta = {}
 for f in [newest(os.path.join(d, "*", "*_counter_collection.csv")) for d in sorted(glob.glob(f"{src}/pmc_*")) if os.path.isdir(d)]:
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
-        if KERNEL in r["Kernel_Name"]:
+        if is_kernel(r["Kernel_Name"]):
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
             meta = {k: r[k] for k in ("Kernel_Name", "Grid_Size", "Workgroup_Size", "LDS_Block_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "Scratch_Size")}
     for k, v in agg.items():
