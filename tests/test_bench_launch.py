@@ -374,7 +374,7 @@ def test_line_takes_counters_only_from_a_profile_of_the_same_launch_plan(pkg):
     plan = plan_dict(pkg, 262144, np.float32, "pairwise")
     assert plan["layout"] == "pairwise" and plan["bodies_per_lane"] == 16 and plan["grid"] == 256 and plan["workspace_bytes"] == 402653184
     got = pmc_summary(262144, False, "fast", "pairwise", plan)
-    assert got["source"].startswith("profiles/round5_n262144_f32_pairwise_pmc_summary.json") and 0.9 < got["valu_busy"] < 1.0 and got["hbm_bytes_per_launch"] > 8e8
+    assert got["source"].startswith("profiles/round6_n262144_f32_pairwise_pmc_summary.json") and 0.9 < got["valu_busy"] <= 1.0 and got["hbm_bytes_per_launch"] > 8e8
     finish = pmc_summary(262144, False, "fast", "pairwise", plan, kernel="_finish")
     assert "finish" in finish["source"] and finish["hbm_bytes_per_launch"] > 4e8 and finish["valu_busy"] < 0.5  # the HBM-bound kernel of the path
     other = dict(plan, workgroups_per_block=2)
