@@ -699,7 +699,9 @@ class StepCrew {
         if (n > workers_.size() + 1) return NB_ERR_INVALID_ARGUMENT;
         results_.assign(n, 0);
         job_ = &fn, job_size_ = n;
-        pending_.store(static_cast<int>(n) - 1, std::memory_order_release);
+        // EVERY thread of the crew answers every ticket, also one with nothing to do in this job: a thread that woke late must not meet
+        // the NEXT job's description under the ticket of this one
+        pending_.store(static_cast<int>(workers_.size()), std::memory_order_release);
         {
             std::lock_guard<std::mutex> lock(mutex_);  // (the ticket changes under the lock: a worker about to sleep cannot miss it)
             ticket_.fetch_add(1, std::memory_order_release);
@@ -730,7 +732,7 @@ class StepCrew {
             seen = ticket_.load(std::memory_order_acquire);
             if (quit_) return;
             if (k < job_size_) results_[k] = (*job_)(k);
-            if (k < job_size_) pending_.fetch_sub(1, std::memory_order_acq_rel);
+            pending_.fetch_sub(1, std::memory_order_acq_rel);
         }
     }
 
