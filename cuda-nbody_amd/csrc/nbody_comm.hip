@@ -662,8 +662,8 @@ template <typename T> int reaction_exchange(const std::vector<Comm*>& locals, co
 // ---- the crew: who enqueues a step over several local ranks ---------------------------------------------------------------------
 // One process driving G devices (nb_comm_init_all: `nbody --numdevices G`, BodySystemHIPSharded -- the process model SURVEY 8(e)
 // names) used to enqueue every rank's kernels, events and RCCL calls from the calling thread: 0.13-0.19 ms per rank and step
-// (measured, a loopback rank of 8 at 262 144 bodies: profiles/round6_graph_capture_and_host_enqueue.txt), i.e. ~1.2 ms for 8 ranks against a
-// 1.3 ms step -- host-bound.  Capturing a rank's step into a hipGraph was tried first (same file): RCCL's send/recv groups ARE
+// (measured, a loopback rank of 8 at 262 144 bodies: profiles/round6_graph_capture_and_host_enqueue.txt; eight ranks in one process:
+// 0.7-0.9 ms) against a 1.3 ms step -- host-bound.  Capturing a rank's step into a hipGraph was tried first (same file): RCCL's send/recv groups ARE
 // captured and replay (the position exchange alone: 3 us of host time per replay; the one-sided step: 4 us per step at the same
 // stream time), but the pairwise step replays in 2.41 ms instead of 1.28 -- the graph runs the two compute streams' branches one
 // after the other, the very figure of two streams on one hardware queue -- and two pairwise steps in one capture end in a

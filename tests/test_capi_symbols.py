@@ -110,6 +110,9 @@ def test_round5_hooks_reject_bad_arguments_on_the_host(pkg):
     assert lib.nb_comm_last_enqueue_ms(None, ctypes.byref(ms)) == 10001
     assert lib.nb_comm_side_stream_collisions(None, ctypes.byref(word)) == 10001 and lib.nb_comm_settle_side_stream(None, None) == 10001
     assert lib.nb_set_late_diagonal(-1) == 10001
+    # round 6: the in-kernel clock words -- a pointer without a size (or the reverse) and a misaligned pointer are argument errors; NULL, 0 takes them back
+    assert lib.nb_set_pair_clock_words(None, 16) == 10001 and lib.nb_set_pair_clock_words(ctypes.c_void_p(0x1000), 0) == 10001
+    assert lib.nb_set_pair_clock_words(ctypes.c_void_p(0x1004), 64) == 10001 and lib.nb_set_pair_clock_words(None, 0) == 0
 
 
 LAB_ARGUMENT_CHECKS = """

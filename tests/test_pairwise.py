@@ -185,6 +185,56 @@ def test_pair_graph_replay_equals_the_step_loop(gpu, oracle):
     a.free(), b.free()
 
 
+@pytest.mark.parametrize("n,dtype", [(65536, np.float32), (262144, np.float64), (16384, np.float32)])
+def test_clocked_variant_of_the_forces_kernel_changes_no_bit(gpu, oracle, n, dtype):
+    """Round 6: while nb_set_pair_clock_words lends device memory, the one-GPU pairwise step launches pair_forces_clocked in pair_forces'
+    place -- the same kernel text (csrc/nbody_pair_forces.inc, included twice) + four scalar instructions: every workgroup notes its
+    lifetime on the shader-cycle counter and on the constant 100 MHz counter.  It is what bench.py reads the delivered clock from, so
+    it must compute what pair_forces computes, bit for bit; the words must be plausible (a clock between 1.0 and 2.6 GHz, a lifetime
+    that matches the kernel's duration); geometries without the variant (R < 8: 16 384 bodies) ignore the words and leave them alone;
+    too few bytes for the launch's workgroups: ignored as well."""
+    lib = gpu.lib()
+    pos0, vel0 = oracle.startup_state(n, dtype)
+    plan = gpu.pair_plan(n, dtype)
+    has_variant = plan.waves_per_block == 8 and plan.bodies_per_lane == (16 if dtype == np.float32 else 8) and plan.slices == 1
+    assert has_variant == (n >= 65536)
+    dt = dtype(np.float32(0.016))
+    plain = gpu.BodySystemHIP(n, 256, gpu.NBodyParams(), dtype, pos0, vel0, mode=gpu.NB_MODE_FAST, workspace=True)
+    clocked = gpu.BodySystemHIP(n, 256, gpu.NBodyParams(), dtype, pos0, vel0, mode=gpu.NB_MODE_FAST, workspace=True)
+    words = gpu.DeviceBuffer(plan.grid_blocks * 16)
+    gpu.check(lib.nb_memset(words.ptr, 0, plan.grid_blocks * 16, None))
+    try:
+        for _ in range(3):
+            plain.update(dt)
+        gpu.check(lib.nb_set_pair_clock_words(words.ptr, plan.grid_blocks * 16 - 16), "nb_set_pair_clock_words")  # one workgroup short: not used
+        clocked.update(dt)
+        gpu.check(lib.nb_device_synchronize())
+        assert not words.download(np.zeros(plan.grid_blocks * 2, np.uint64)).any()
+        gpu.check(lib.nb_set_pair_clock_words(words.ptr, plan.grid_blocks * 16), "nb_set_pair_clock_words")
+        e0, e1 = gpu.Event(), gpu.Event()
+        gpu.check(lib.nb_set_pair_probe_event(e1.h))
+        clocked.update(dt)
+        e0.record(None)
+        clocked.update(dt)
+        gpu.check(lib.nb_device_synchronize())
+        forces_ms = e0.elapsed_ms(e1)
+    finally:
+        gpu.check(lib.nb_set_pair_probe_event(None))
+        gpu.check(lib.nb_set_pair_clock_words(None, 0), "nb_set_pair_clock_words")
+    assert clocked.get_position().tobytes() == plain.get_position().tobytes() and clocked.get_velocity().tobytes() == plain.get_velocity().tobytes()
+    got = words.download(np.zeros(plan.grid_blocks * 2, np.uint64)).reshape(-1, 2)
+    if has_variant:
+        cycles, ticks = got[:, 0].astype(np.float64), got[:, 1].astype(np.float64)
+        assert (ticks > 0).all() and (cycles > 0).all()
+        mhz = 100.0 * cycles / ticks
+        assert 1000 < np.median(mhz) < 2600, np.median(mhz)
+        rounds = -(-plan.grid_blocks // 256)  # (eight-wave workgroups: one per CU at a time -- 512 workgroups of the fp64 plan take two rounds)
+        assert 0.5 * forces_ms < rounds * np.median(ticks) / 1e5 <= 1.05 * forces_ms  # a workgroup's lifetime in ms (100 MHz ticks) x rounds against the kernel's duration by events
+    else:
+        assert not got.any()
+    plain.free(), clocked.free(), words.free()
+
+
 @pytest.mark.parametrize("n,dtype", [(262144, np.float32), (1048576, np.float32), (262144, np.float64)])
 def test_pair_full_size_sampled_forces_and_momentum(gpu, oracle, n, dtype):
     """BASELINE sizes: accelerations of 512 sampled bodies against the fp64 direct sum, and a size-independent property the
