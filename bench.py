@@ -846,7 +846,7 @@ def main():
             extra["defaults_provisional"] = ("the multi-GPU defaults (an RCCL group per position round + one tail group; the diagonal as two launches, the second one last; reaction "
                                              "rounds in ready order) were chosen on ONE GPU with a loopback rank -- no link latency, no peer to be late; diagnostics.step_ms times "
                                              "the alternatives in this very job: choose from them")
-            if not args.no_diagnostics and args.mode == "fast" and not args.rehearse_one_gpu:
+            if not args.no_diagnostics and args.mode == "fast":
                 # the N = 1 figure of THIS process tree: rank 0 steps the whole system alone on its GPU while the others wait at the
                 # barrier -- "does N = 1 of a scaling series agree with the single-GPU bench" is then answerable from this one record
                 fence()

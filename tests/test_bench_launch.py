@@ -334,6 +334,9 @@ def test_n_rank_line_rehearsed_on_one_gpu_through_the_capi(ranks):
     assert line["exchange_path"] == "rccl-tiles" and line["rccl_ranks_seen"] == 0 and line["rccl_version"] is None
     assert 0 < line["host_enqueue_ms_per_step"] and line["host_enqueue"]["last_step_by_the_library_ms"] > 0
     assert "ONE GPU" in line["defaults_provisional"]
+    # ... and the N = 1 figure of this very process tree (rank 0 alone on its GPU after the timed region, the others waiting at the barrier)
+    single = line["single_gpu_same_process"]
+    assert single["value"] > 0 and single["ms_per_step"] > 0 and abs(single["speedup_of_this_line"] - line["value"] / single["value"]) < 0.01
     assert line["config"]["exchange_grouping"].startswith("one RCCL group per position round")  # (round 5's default: measured, profiles/round5_exchange_contention.jsonl)
     seen = line["ranks_seen"]
     assert [r["rank"] for r in seen] == list(range(ranks)) and all(r["world"] == ranks and r["pairwise"] and not r["one_group"] and r["workspace_bytes"] > 0 for r in seen)
