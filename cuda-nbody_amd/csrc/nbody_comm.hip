@@ -15,7 +15,7 @@
 // FAST with a workspace lent to every rank (round 3): each pair of bodies is evaluated once across the ranks too -- see
 // pair_sharded_step below; the position exchange stays as described, a second leg carries reaction sums to their owners.
 //
-// What round 5 measured with the REAL RCCL on one GPU (profiles/round5_*; the hooks are in the tuning header: a self-loop with every
+// What round 5 measured with the REAL RCCL on one GPU (profiles/round5_*; the hooks are the lab library's, nbody_hip_lab.h: a self-loop with every
 // byte checked, a LOOPBACK rank that steps as rank r of a nominal G-rank communicator) and what it changed here: a group per round
 // is the default (exchange_tiles); the tiles no kernel waits for travel as one more group; a rank's diagonal is two launches, the
 // second one LAST, with every reaction round enqueued before it (pair_rank_tiles); the second compute stream is probed against the
@@ -109,7 +109,7 @@ bool default_one_group() {  // NBODY_EXCHANGE_ONE_GROUP=1 flips the default of n
 // run side by side with the caller's (the same step 1.77 ms either way); a CU-masked stream is one more hardware queue each.  So
 // the stream is made at the caller's priority and PROBED the first time the two meet -- against the caller's stream, and against
 // the NULL stream (RCCL works there: a second stream on the null stream's queue costs 25 %, a caller on it 40 %: see
-// note_caller_stream below): two ~40 us spin kernels, one on each, started together; had they run one after the other, another
+// note_stream below): two ~40 us spin kernels, one on each, started together; had they run one after the other, another
 // stream is made (the collided ones are kept until the communicator goes, so that the pool moves on) -- up to eight times.
 __global__ void queue_probe_spin(unsigned long long ticks, unsigned* sink) {
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz, whatever the shader clock

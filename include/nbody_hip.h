@@ -194,7 +194,10 @@ NB_API int nb_integrate_shard_f64(double* new_positions, const double* old_posit
  *  of the exchange of new_positions -- everything asynchronous; the caller ping-pongs the two position arrays exactly
  *  as with nb_integrate_*.  Process models: one process per GPU (nb_comm_unique_id on rank 0, ship the 128 bytes to
  *  the others by any means, nb_comm_init_rank on each) or one process driving several GPUs (nb_comm_init_all +
- *  the *_all step, which takes one array of each kind per local device).  RCCL is loaded on first use. -------------- */
+ *  the *_all step, which takes one array of each kind per local device; its local ranks are enqueued in parallel by a crew of
+ *  persistent threads, one per rank -- each issuing its own rank's RCCL groups, RCCL's thread-per-device model -- so the host needs
+ *  what ONE rank needs whatever the number of devices; NBODY_STEP_THREADS=0: the calling thread alone, same bits).
+ *  RCCL is loaded on first use. ------------------------------------------------------------------------------------------------- */
 #define NB_COMM_ID_BYTES 128
 typedef void* nb_comm_t;
 NB_API int nb_comm_unique_id(void* id /* NB_COMM_ID_BYTES */);
@@ -206,8 +209,10 @@ NB_API int nb_comm_info(nb_comm_t comm, int* rank, int* world_size, int* device)
  * a few hardware queues; RCCL puts work of its own on the null stream, and a rank that computes on the null stream or on a stream
  * that shares its queue -- about one created stream in three -- steps ~40 % slower (measured with the real RCCL next to the force
  * kernels, profiles/round5_hw_queue_collision.txt).  This one is probed to be clear of that queue.  Any stream works; this one is fast.
- * (The library looks at the stream a rank steps on ONCE per stream -- two 40 us spin kernels and a synchronisation of that stream and of
- * the null stream inside the first nb_sharded_step_* that sees it -- to be able to say so: nb_comm_caller_stream_placement, tuning header.) */
+ * (The library looks at any OTHER stream a rank steps on once per stream -- two 40 us spin kernels and a synchronisation of that stream and
+ * of the null stream inside the first nb_sharded_step_* that sees it, never while the stream is capturing, not at all with
+ * NBODY_AUX_PROBE=0 -- to be able to say so: nb_comm_caller_stream_placement, tuning header.  The placement of a stream made here is not looked at again; the rank's second
+ * compute stream is settled beside it once, at the first pairwise step with two or more partners.) */
 NB_API int nb_comm_stream_create(nb_comm_t comm, nb_stream_t* stream);
 /* ... the same without a communicator, on the current device: for a host that runs an RCCL of its own next to these kernels. */
 NB_API int nb_stream_create_placed(nb_stream_t* stream);
