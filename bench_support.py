@@ -389,7 +389,7 @@ def host_enqueue_projection(n, loopback, timeout_s=60):
 
     got = {"what": "host wall clock (ms) to enqueue ONE step of 8 ranks at this body count, real RCCL, one GPU; a step whose enqueue takes longer than its kernels is host-bound.  "
                    "one_rank_*: a loopback rank, in a torch process (torch's own HIP runtime and RCCL: what a rank of `bench.py --gpus 8` is) and in a plain process (ROCm's: "
-                   "what a thread of the crew behind `nbody --numdevices 8` is)",
+                   "what a thread of the crew behind `nbody --numdevices 8` is); read over the first 8 steps of a stretch (40 steps in a torch process run into a full device queue)",
            "one_rank_of_8_torch_process_ms": None, "one_rank_of_8_plain_process_ms": None, "in_process_world_8_ranks": {}}
     try:
         got["one_rank_of_8_torch_process_ms"] = loopback["ranks"]["8"].get("host_enqueue_ms")
