@@ -31,6 +31,7 @@
 
 #include "nbody_comm_internal.h"
 #include "rand_stream_guard.h"
+#include "step_crew.h"
 
 #include <hip/hip_runtime.h>
 
@@ -676,77 +677,7 @@ template <typename T> int reaction_exchange(const std::vector<Comm*>& locals, co
 // round -- one group over all local ranks -- by the calling thread between the phases.  The crew spins for up to ~0.3 ms between
 // phases and steps, then sleeps on a condition variable.
 // NBODY_STEP_THREADS=0: the calling thread does everything (A/B timings; the same calls in the same per-rank order, so the
-// same bits -- tested).
-class StepCrew {
- public:
-    explicit StepCrew(const std::vector<Comm*>& group) {
-        for (size_t k = 1; k < group.size(); ++k) workers_.emplace_back([this, k, device = group[k]->device] { work(k, device); });
-    }
-    ~StepCrew() {
-        {
-            std::lock_guard<std::mutex> lock(mutex_);
-            quit_ = true;
-            ++ticket_;
-        }
-        wake_.notify_all();
-        for (auto& t : workers_) t.join();
-    }
-    StepCrew(const StepCrew&)            = delete;
-    StepCrew& operator=(const StepCrew&) = delete;
-
-    // fn(k) for k = 0 .. n-1, k = 0 on the calling thread, the others on the crew; returns the first non-zero result
-    int run(size_t n, const std::function<int(size_t)>& fn) {
-        if (n > workers_.size() + 1) return NB_ERR_INVALID_ARGUMENT;
-        results_.assign(n, 0);
-        job_ = &fn, job_size_ = n;
-        // EVERY thread of the crew answers every ticket, also one with nothing to do in this job: a thread that woke late must not meet
-        // the NEXT job's description under the ticket of this one
-        pending_.store(static_cast<int>(workers_.size()), std::memory_order_release);
-        {
-            std::lock_guard<std::mutex> lock(mutex_);  // (the ticket changes under the lock: a worker about to sleep cannot miss it)
-            ticket_.fetch_add(1, std::memory_order_release);
-        }
-        if (sleepers_.load(std::memory_order_acquire) != 0) wake_.notify_all();
-        results_[0] = fn(0);
-        for (int spins = 0; pending_.load(std::memory_order_acquire) != 0; ++spins)
-            if (spins > 2000) std::this_thread::yield();
-        for (int r : results_)
-            if (r != 0) return r;
-        return 0;
-    }
-
- private:
-    void work(size_t k, int device) {
-        (void)hipSetDevice(device);
-        unsigned long long seen = 0;
-        for (;;) {
-            const auto idle_since = std::chrono::steady_clock::now();
-            while (ticket_.load(std::memory_order_acquire) == seen) {
-                if (std::chrono::steady_clock::now() - idle_since > std::chrono::microseconds(300)) {
-                    std::unique_lock<std::mutex> lock(mutex_);
-                    sleepers_.fetch_add(1, std::memory_order_acq_rel);
-                    wake_.wait(lock, [&] { return ticket_.load(std::memory_order_acquire) != seen; });
-                    sleepers_.fetch_sub(1, std::memory_order_acq_rel);
-                }
-            }
-            seen = ticket_.load(std::memory_order_acquire);
-            if (quit_) return;
-            if (k < job_size_) results_[k] = (*job_)(k);
-            pending_.fetch_sub(1, std::memory_order_acq_rel);
-        }
-    }
-
-    std::vector<std::thread>           workers_;
-    std::mutex                         mutex_;
-    std::condition_variable            wake_;
-    std::atomic<unsigned long long>    ticket_{0};
-    std::atomic<int>                   pending_{0}, sleepers_{0};
-    const std::function<int(size_t)>*  job_      = nullptr;
-    size_t                             job_size_ = 0;
-    std::vector<int>                   results_;
-    bool                               quit_ = false;
-};
-
+// same bits -- tested).  The crew itself is csrc/step_crew.h: plain C++, run under ThreadSanitizer on the CPU (tests/step_crew_tsan.cpp).
 // no two of these ranks share an RCCL communicator (ranks that do -- the lab's in-process world -- cannot call into it concurrently,
 // and their transfers are matched by the order of ONE thread's calls)
 bool ranks_own_their_transport(const std::vector<Comm*>& locals) {
@@ -754,6 +685,8 @@ bool ranks_own_their_transport(const std::vector<Comm*>& locals) {
         if (c->shared_nccl) return false;
     return true;
 }
+
+static_assert(StepCrew::kTooManyRanks == NB_ERR_INVALID_ARGUMENT, "step_crew.h spells the code without the header");
 
 bool crew_enabled() {
     static const bool on = [] {
@@ -768,7 +701,9 @@ int for_each_rank(const std::vector<Comm*>& locals, const std::function<int(size
     if (locals.size() > 1 && crew_enabled()) {
         Comm* owner = locals.front()->group.front();
         if (!owner->crew) {
-            auto crew = std::make_shared<StepCrew>(owner->group);
+            std::vector<int> devices;
+            for (const Comm* c : owner->group) devices.push_back(c->device);
+            auto crew = std::make_shared<StepCrew>(owner->group.size() - 1, [devices](size_t k) { (void)hipSetDevice(devices[k]); });
             for (Comm* c : owner->group) c->crew = crew;
         }
         return static_cast<StepCrew*>(owner->crew.get())->run(locals.size(), fn);

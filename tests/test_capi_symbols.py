@@ -147,6 +147,22 @@ def test_lab_hooks_reject_bad_arguments_on_the_host():
     assert done.returncode == 0 and "lab ok" in done.stdout, done.stderr[-2000:]
 
 
+def test_step_crew_under_thread_sanitizer(tmp_path):
+    """The crew of threads that enqueues the local ranks of a multi-GPU step (csrc/step_crew.h: plain C++, so that this can run on a host
+    without a GPU) under ThreadSanitizer: 20 000 jobs of varying size on eight threads -- every k of a job exactly once, no data race on
+    the job's description or on memory handed through it, the first failure reported, sleeping workers woken, destruction joins.  The
+    test has teeth: with a worker that answers only the tickets of jobs it takes part in (the crew's first form) it reports data races
+    and a function run twice."""
+    exe = tmp_path / "step_crew_tsan"
+    build = subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=thread", "-pthread", os.path.join(ROOT, "tests", "step_crew_tsan.cpp"), "-o", str(exe)],
+                           capture_output=True, text=True)
+    assert build.returncode == 0, build.stderr[-3000:]
+    run = subprocess.run([str(exe), "20000"], capture_output=True, text=True, timeout=300, env={**os.environ, "TSAN_OPTIONS": "halt_on_error=1"})
+    assert run.returncode == 0 and "step crew ok" in run.stdout and "ThreadSanitizer" not in run.stderr, (run.stdout[-500:], run.stderr[-3000:])
+    comm = open(os.path.join(ROOT, "cuda-nbody_amd", "csrc", "nbody_comm.hip")).read()
+    assert '#include "step_crew.h"' in comm and "class StepCrew" not in comm  # (the product uses THIS class, not a copy of it)
+
+
 def test_strict_translation_unit_has_no_fused_multiply_add():
     """The strict kernels must keep separate mul/add (bit-parity with the CPU path): the only v_fma in that
     object are inside the IEEE divide/sqrt expansions, never a contracted a*b+c of ours.  Checked structurally:
