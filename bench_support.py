@@ -667,6 +667,23 @@ def multi_gpu_diagnostics(pkg, lib, dist, torch, args, capi_rank, system, sharde
             pkg.check(lib.nb_set_late_diagonal(1), "nb_set_late_diagonal")
             capi_rank.set_workspace(work_t.data_ptr(), work_bytes)
         assert capi_rank.pairwise()
+        # (3c) round 6: BOTH compute streams ending on local work (nb_set_late_diagonal(2): the second stream's last rectangle cut, half of the
+        # late diagonal as its last kernel) -- slower on one GPU (profiles/round6_cut_rectangle_ab.txt), timed here on real links.  It wants a
+        # few planes more than the shipping order: every rank lends a second, larger workspace for the duration (the call is collective)
+        bigger = None
+        try:
+            pkg.check(lib.nb_set_late_diagonal(2), "nb_set_late_diagonal")
+            need = capi_rank.workspace_bytes()
+            bigger = lend(need) if need > work_bytes else work_t
+            capi_rank.set_workspace(bigger.data_ptr() if bigger is not None else None, need if bigger is not None else 0)
+            if capi_rank.pairwise():
+                steps["pairwise_both_streams_end_on_local_work_" + ("one_group" if was_one_group else "group_per_round")] = timed(step, reps)
+        finally:
+            pkg.check(lib.nb_set_late_diagonal(1), "nb_set_late_diagonal")
+            capi_rank.set_workspace(work_t.data_ptr(), work_bytes)
+            torch.cuda.synchronize()
+            del bigger
+        assert capi_rank.pairwise()
     # (4) the other layout: every rank takes its workspace back (the call is collective) -> the one-sided tile schedule
     if was_pairwise:
         capi_rank.set_workspace(None, 0)

@@ -265,6 +265,7 @@ int make_resources(Comm* c) {
     err = create_side_stream(&c->aux);  // (probed against a caller's stream the first time the two meet: note_stream)
     if (err == hipSuccess) err = hipEventCreateWithFlags(&c->aux_begin, hipEventDisableTiming);
     if (err == hipSuccess) err = hipEventCreateWithFlags(&c->aux_done, hipEventDisableTiming);
+    if (err == hipSuccess) err = hipEventCreateWithFlags(&c->cut_ready, hipEventDisableTiming);
     if (err != hipSuccess) return static_cast<int>(err);
     c->one_group = default_one_group();
     if (c->world > 1) {
@@ -292,6 +293,7 @@ void free_resources(Comm* c) {
     if (c->ready) (void)hipEventDestroy(c->ready);
     if (c->aux_begin) (void)hipEventDestroy(c->aux_begin);
     if (c->aux_done) (void)hipEventDestroy(c->aux_done);
+    if (c->cut_ready) (void)hipEventDestroy(c->cut_ready);
     if (c->aux) (void)hipStreamDestroy(c->aux);
     for (hipStream_t s : c->aux_retired) (void)hipStreamDestroy(s);
     if (c->stream && c->owns_stream) (void)hipStreamDestroy(c->stream);
@@ -432,12 +434,13 @@ template <> struct Api<double> {
 std::atomic<int> g_late_diagonal{1};  // the lab's nb_set_late_diagonal: 0 = the diagonal as ONE launch, first (the order up to round 4), for A/B timings
 
 template <typename T> PairShard plan_pair_shard(unsigned num_bodies, int G, int min_slice, size_t budget) {
-    const bool late_diagonal = g_late_diagonal.load() != 0;
+    const int  diagonal_mode = g_late_diagonal.load();
+    const bool late_diagonal = diagonal_mode != 0;
     constexpr unsigned W = sizeof(T) == 4 ? 2 : 1;
     PairShard          p;
     if (G < 2 || num_bodies % static_cast<unsigned>(G)) return p;
     p.ni = num_bodies / static_cast<unsigned>(G);
-    if (p.ni < static_cast<unsigned>(min_slice > 0 ? min_slice : 2048) || G / 2 > nb::kMaxRecv || G / 2 + 2 > nb::kMaxSelfSets) return p;
+    if (p.ni < static_cast<unsigned>(min_slice > 0 ? min_slice : 2048) || G / 2 > nb::kMaxRecv || G / 2 + 4 > nb::kMaxSelfSets) return p;
     int ovr_r = 0, ovr_s = 0, ovr_c = 0;
     nb::pair_plan_overrides(&ovr_r, &ovr_s, &ovr_c);  // (tuning sweeps: tools/pair_rank_probe.py)
     // R = 8 from slices of 32 768 bodies (round 4, one rank's kernels alone on one GPU: 65 536-body slices 2.54 -> 2.45 ms, 32 768-body
@@ -471,10 +474,28 @@ template <typename T> PairShard plan_pair_shard(unsigned num_bodies, int G, int 
         // time -- measured (profiles/round5_exchange_contention.jsonl): 32 768-body slices -1.1 %, 65 536 -0.5 %, 131 072 +0.2 ... +0.7 %
         const unsigned first = late_diagonal && offsets >= 2 && p.ni <= 65536u ? (offsets + 1) / 2 : offsets;
         p.early_units = first * tiles, p.late_units = (offsets - first) * tiles;
+        // Round 6, nb_set_late_diagonal(2): with two balanced streams one of them always ended on a rectangle, whose fold and send then
+        // left bare (~0.04 ms of a 1.28 ms step at 8 ranks).  No deal of WHOLE pieces ends both streams on local work (8 ranks: own =
+        // 1.5 + d1, second = 2 + d2 rectangles with d1 + d2 = 0.5 of diagonal: balance forces d2 = 0), so one rectangle is cut: the
+        // second stream takes half of the late offsets as ITS last kernel, and gives the same amount of work -- the first cut_tiles
+        // tiles of bodies j of its last rectangle -- to the step's own stream.  An offset is `tiles` units per block, a tile of bodies j
+        // of a rectangle one unit per block: cut_tiles = offsets moved x tiles.  Even G with the SPLIT rectangle last on the second
+        // stream (6 ranks) and odd G (its second stream carries less and ends early anyway) keep round 5's deal.  Built, correct, and
+        // measured SLOWER on one GPU (profiles/round6_cut_rectangle_ab.txt: 8 ranks 1.312 against 1.294 ms per step, 4 ranks 2.474 /
+        // 2.449 -- two more launches cost the kernels 0.7-0.9 %, and ~40 us pieces do not hide the hop): NOT the default; bench.py's
+        // N > 1 diagnostics time it on real links, where the hop is longer than a loopback transfer's.
+        const unsigned late_offsets = offsets - first, last_on_second = (p.H & 1u) ? p.H : p.H - 1;
+        if (diagonal_mode == 2 && p.even && p.H >= 2 && late_offsets >= 2 && last_on_second != p.H) {  // (an odd world's second stream ends early anyway)
+            const unsigned moved = late_offsets / 2;
+            p.late_aux_units = moved * tiles, p.late_units -= p.late_aux_units;
+            p.cut_round = last_on_second, p.cut_tiles = moved * tiles;
+            if (p.cut_tiles * 2 > (p.ni + 63) / 64) p.late_units += p.late_aux_units, p.late_aux_units = 0, p.cut_round = 0, p.cut_tiles = 0;  // (a rectangle too small to cut)
+        }
     }
     p.diag      = {R, S, splits(p.early_units)};
     p.diag_late = {R, S, p.late_units != 0 ? splits(p.late_units) : 0u};
     p.rect = {R, S, splits((p.ni + 63) / 64)};
+    if (p.cut_round != 0) p.diag_late_aux = {R, S, splits(p.late_aux_units)}, p.rect_cut = {R, S, std::min(splits(p.cut_tiles), p.rect.splits)};
     p.rect_upper = p.rect;
     if (p.even && p.blocks >= 2 && (p.ni + 63) / 64 >= p.rect.splits * 2 * static_cast<unsigned>(S) * 2) p.rect_upper.splits = p.rect.splits * 2;
     {   // The reaction rounds leave in the order their sums become ready, not in the order of the partners: the exchange stream is a
@@ -484,17 +505,20 @@ template <typename T> PairShard plan_pair_shard(unsigned num_bodies, int G, int 
         // rectangle (the step's own stream starts with the early diagonal: a quarter, or a half when the diagonal is one launch; odd
         // partners run on the second stream from two partners on).  A function of G alone: the same order on every rank.
         double at_own = p.late_units != 0 ? 0.25 : 0.5, at_second = 0.0, done[nb::kMaxRecv + 1] = {};
+        const double cut = p.cut_round != 0 ? static_cast<double>(p.cut_tiles) / ((p.ni + 63) / 64) : 0.0;  // (the part of the cut rectangle that runs on the step's own stream)
         for (unsigned s = 1; s <= p.H; ++s) {
             const double cost = (p.even && s == p.H) ? 0.5 : 1.0;
             double&      at   = (p.H >= 2 && (s & 1u) != 0) ? at_second : at_own;
-            at += cost, done[s] = at;
+            if (s == p.cut_round) at_own += cut, at += cost - cut, done[s] = std::max(at, at_own);
+            else at += cost, done[s] = at;
         }
         for (unsigned k = 0; k < p.H; ++k) p.send_order[k] = k + 1;
         std::stable_sort(p.send_order, p.send_order + p.H, [&](unsigned a, unsigned b) { return done[a] < done[b]; });
     }
     const size_t plane3 = 3 * static_cast<size_t>(p.plane);
     p.self_at    = 0;
-    p.react_d_at = p.self_at + (p.diag.splits + p.diag_late.splits + static_cast<size_t>(p.H - 1) * p.rect.splits + p.rect_upper.splits) * plane3;  // (the last rectangle is the one that may be split)
+    p.extra_self_first = p.diag.splits + p.diag_late.splits + (p.H - 1) * p.rect.splits + p.rect_upper.splits;  // (the last rectangle is the one that may be split)
+    p.react_d_at = p.self_at + (static_cast<size_t>(p.extra_self_first) + p.diag_late_aux.splits + p.rect_cut.splits) * plane3;
     p.react_r_at = p.react_d_at + p.diag_slots * plane3;
     p.send_at    = p.react_r_at + 2 * p.blocks * plane3;  // (two regions: the rectangles alternate between two streams)
     p.recv_at    = p.send_at + p.H * plane3;
@@ -531,6 +555,12 @@ int pair_rank_tiles(Comm* c, unsigned r, int G, const PairShard& plan, T* work, 
             if (const auto err = nb::launch_pair_tile<T>(a, plan.diag_late, stream); err != hipSuccess) return static_cast<int>(err);
             if (c != nullptr) c->trace += "forces diagonal-late\n";
             f.self_set[f.n_self++] = {plan.diag.splits, plan.diag_late.splits, 0u, ni};
+            if (plan.late_aux_units != 0) {  // ... and the second stream's last kernel is local work too (round 6: plan_pair_shard; without a second stream: here)
+                a.self_first = plan.extra_self_first, a.unit_begin = plan.early_units + plan.late_units, a.unit_count = plan.late_aux_units;
+                if (const auto err = nb::launch_pair_tile<T>(a, plan.diag_late_aux, aux != nullptr ? aux : stream); err != hipSuccess) return static_cast<int>(err);
+                if (c != nullptr) c->trace += "forces diagonal-late second stream\n";
+                f.self_set[f.n_self++] = {plan.extra_self_first, plan.diag_late_aux.splits, 0u, ni};
+            }
         }
         if (aux != nullptr) {  // the finish kernel (on `stream`) needs the second stream's sums too
             auto err = hipEventRecord(aux_done, aux);
@@ -574,13 +604,33 @@ int pair_rank_tiles(Comm* c, unsigned r, int G, const PairShard& plan, T* work, 
             if (r < p) a.j_count = plan.half;
             else a.i_begin = own + plan.half, a.i_count = ni - plan.half;
         }
+        const unsigned blocks_i = (a.i_count + plan.block - 1) / plan.block;
+        unsigned       sent     = 0;  // bodies j of this rectangle whose sums are in the send buffer already (the cut-off part)
+        if (s == plan.cut_round && other) {
+            // the CUT rectangle: its first cut_tiles tiles of bodies j run on the step's own stream (own region of reaction planes, own
+            // i-side planes, own fold into the first part of the send array); the rest follows below on the second stream
+            const unsigned part = std::min(plan.cut_tiles * 64u, a.j_count);
+            if (c != nullptr && waiting) {
+                if (const auto err = hipStreamWaitEvent(stream, c->arrived[p], 0); err != hipSuccess) return static_cast<int>(err);
+            }
+            nb::PairArgs<T> b = a;
+            b.react = work + plan.react_r_at, b.j_count = part, b.react_origin = b.j_begin;
+            b.self_first = plan.extra_self_first + plan.diag_late_aux.splits;
+            if (const auto err = nb::launch_pair_tile<T>(b, plan.rect_cut, stream); err != hipSuccess) return static_cast<int>(err);
+            f.self_set[f.n_self++] = {b.self_first, plan.rect_cut.splits, b.i_begin - own, b.i_count};
+            if (const auto err = nb::launch_pair_reduce<T>(b.react, plan.plane, blocks_i, work + plan.send_at + (s - 1) * plane3, plan.plane, part, stream); err != hipSuccess) return static_cast<int>(err);
+            if (c != nullptr) {
+                if (const auto err = hipEventRecord(c->cut_ready, stream); err != hipSuccess) return static_cast<int>(err);
+                c->trace += "forces rectangle " + std::to_string(s) + " cut-off part\nfold " + std::to_string(s) + " cut-off part\n";
+            }
+            sent = part, a.j_begin += part, a.j_count -= part;
+        }
         a.react_origin = a.j_begin;
         a.self_first   = plan.diag.splits + plan.diag_late.splits + (s - 1) * plan.rect.splits;
         const nb::PairGeom& geom = (plan.even && s == plan.H && !(r < p)) ? plan.rect_upper : plan.rect;
         if (const auto err = nb::launch_pair_tile<T>(a, geom, on); err != hipSuccess) return static_cast<int>(err);
         f.self_set[f.n_self++] = {a.self_first, geom.splits, a.i_begin - own, a.i_count};
-        const unsigned blocks_i = (a.i_count + plan.block - 1) / plan.block;
-        if (const auto err = nb::launch_pair_reduce<T>(a.react, plan.plane, blocks_i, work + plan.send_at + (s - 1) * plane3, plan.plane, a.j_count, on); err != hipSuccess) return static_cast<int>(err);
+        if (const auto err = nb::launch_pair_reduce<T>(a.react, plan.plane, blocks_i, work + plan.send_at + (s - 1) * plane3 + sent, plan.plane, a.j_count, on); err != hipSuccess) return static_cast<int>(err);
         if (c != nullptr) {
             if (const auto err = hipEventRecord(c->react_ready[s], on); err != hipSuccess) return static_cast<int>(err);
             c->trace += "forces rectangle " + std::to_string(s) + "\nfold " + std::to_string(s) + "\n";
@@ -602,7 +652,7 @@ int pair_rank_tiles(Comm* c, unsigned r, int G, const PairShard& plan, T* work, 
 inline void pair_rank_work(const PairShard& plan, unsigned r, int G, unsigned long long* evaluations, int* launches) {
     const unsigned long long block = plan.block;
     unsigned long long       sum   = static_cast<unsigned long long>(plan.blocks) * (plan.blocks / 2 + 1) * block * block;  // the diagonal's tournament
-    int                      count = plan.late_units != 0 ? 2 : 1;
+    int                      count = (plan.late_units != 0 ? 2 : 1) + (plan.cut_round != 0 ? 2 : 0);
     for (unsigned s = 1; s <= plan.H; ++s) {
         const unsigned p = (r + s) % static_cast<unsigned>(G);
         unsigned       i_count = plan.ni, j_count = plan.ni;
@@ -633,7 +683,9 @@ template <typename T> int reaction_exchange(const std::vector<Comm*>& locals, co
         const unsigned s = plan.send_order[k];
         for (Comm* c : locals) {
             DeviceScope scope(c->device);
-            if (const auto err = hipStreamWaitEvent(c->stream, c->react_ready[s], 0); err != hipSuccess) return static_cast<int>(err);
+            auto err = hipStreamWaitEvent(c->stream, c->react_ready[s], 0);
+            if (err == hipSuccess && s == plan.cut_round) err = hipStreamWaitEvent(c->stream, c->cut_ready, 0);  // (the part of the cut rectangle folded on the step's own stream)
+            if (err != hipSuccess) return static_cast<int>(err);
         }
         const int shift = static_cast<int>(s);
         int       rc    = lib->GroupStart();
@@ -1208,7 +1260,7 @@ int nb_emulate_pair_rank_f64(double* new_positions, const double* old_positions,
 int nb_comm_reaction_exchange_f32(nb_comm_t comm, unsigned num_bodies, nb_stream_t stream) { return reaction_exchange_only<float>(comm, num_bodies, stream); }
 int nb_comm_reaction_exchange_f64(nb_comm_t comm, unsigned num_bodies, nb_stream_t stream) { return reaction_exchange_only<double>(comm, num_bodies, stream); }
 int nb_set_late_diagonal(int on) {
-    if (on != 0 && on != 1) return NB_ERR_INVALID_ARGUMENT;
+    if (on < 0 || on > 2) return NB_ERR_INVALID_ARGUMENT;
     g_late_diagonal.store(on);
     return 0;
 }

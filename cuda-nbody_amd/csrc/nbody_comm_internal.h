@@ -77,6 +77,7 @@ struct Comm {
     std::vector<hipStream_t> placed;       // streams handed out by nb_comm_stream_create: probed to be clear of the null stream's queue when they were made
     std::vector<hipEvent_t> react_ready;   // [world/2 + 1] pairwise step: "the reaction sums for partner s are in the send buffer" (compute stream)
     std::vector<hipEvent_t> react_arrived; // [world/2 + 1] ... "round s of the reaction exchange is done" (exchange stream)
+    hipEvent_t  cut_ready = nullptr;       // ... "the cut-off part of the cut rectangle is folded into the send buffer too" (the step's own stream; PairShard::cut_round)
     std::vector<Comm*> group;              // all local ranks of this communicator (just {this} with one process per GPU)
     std::string trace;                     // what the rank's last pairwise step enqueued, in host order (nb_comm_last_step_trace: tests read the order)
     double      last_enqueue_ms = 0;       // host wall clock of the last nb_sharded_step_* call this rank took part in (the whole call: what the HOST needs to enqueue a step)
@@ -128,10 +129,16 @@ struct PairShard {
     unsigned     ni = 0, block = 0, blocks = 0, plane = 0, half = 0, H = 0, diag_slots = 0;
     unsigned     send_order[nb::kMaxRecv] = {};  // the reaction rounds s = 1 .. H in the order their rectangles' folds are expected to complete (send_order[k] = s)
     unsigned     early_units = 0, late_units = 0;  // the diagonal's units per block as two launches: block offsets q < q_split first, the rest LAST (late_units == 0: one launch)
+    // round 6 (nb_set_late_diagonal(2)): BOTH compute streams end on local work -- the late units are dealt to the two streams (late_units
+    // = what the step's own stream takes, late_aux_units = the second stream's), and the last rectangle that runs on the second stream is
+    // CUT by bodies j: its first cut_tiles tiles run on the step's own stream (as much work as the second stream took over)
+    unsigned     late_aux_units = 0, cut_round = 0, cut_tiles = 0;
+    nb::PairGeom diag_late_aux{}, rect_cut{};
+    unsigned     extra_self_first = 0;  // first i-side plane of {the second stream's late diagonal, the cut-off part of the rectangle}
     bool         even = false;
     size_t       self_at = 0, react_d_at = 0, react_r_at = 0, send_at = 0, recv_at = 0, elements = 0;  // offsets in T
 };
-extern std::atomic<int> g_late_diagonal;   // 1 (default): the diagonal as two launches, the second one last; the lab's nb_set_late_diagonal(0) = one launch, first
+extern std::atomic<int> g_late_diagonal;   // nb_set_late_diagonal: 0 = one launch, first; 1 = two launches, the second one last; 2 = 1 + both streams end on local work (cut rectangle)
 extern std::atomic<int> g_pair_shard_min;  // nb_comm_set_pair_min_slice: tests run the pairwise step on small slices
 
 enum RankPart { kWholeStep = 0, kBeforeSends = 1, kAfterSends = 2 };

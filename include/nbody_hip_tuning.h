@@ -39,8 +39,11 @@ NB_API int nb_comm_set_pair_min_slice(int min_bodies_per_rank);
 /* A rank's diagonal (its own slice against itself) in a pairwise multi-GPU step: 1 (default) = two launches (for slices up to 65 536
  * bodies: beyond, the hop it hides is under 0.3 % of a step and the second launch costs as much), the first half of the
  * block offsets first and the rest as the rank's LAST force kernel, so that the last reaction sums travel under local work;
- * 0 = one launch, first (the order up to round 4) -- for A/B timings.  Process-global like the plan overrides; with one process
- * per GPU every rank must set the same (nb_comm_set_workspace checks it).  Summation order, hence the last bits, differ. */
+ * 0 = one launch, first (the order up to round 4); 2 (round 6) = as 1, and the SECOND compute stream ends on local work too: it takes
+ * half of the late offsets as its last kernel and hands the same amount of work -- the first tiles of bodies j of its last rectangle --
+ * to the step's own stream (worlds of 4, 8, 12, 16 ranks; measured slower on one GPU, profiles/round6_cut_rectangle_ab.txt: for A/B
+ * timings on real links).  Process-global like the plan overrides; with one process per GPU every rank must set the same
+ * (nb_comm_set_workspace checks it).  Summation order, hence the last bits, differ between the three. */
 NB_API int nb_set_late_diagonal(int on);
 
 /* Tuning / projection hook (bench.py --emulate-gpus): exactly the kernels that rank `rank` of a `world_size`-rank pairwise step

@@ -7,7 +7,7 @@ library resolves RCCL, which happens once per process -- hence a process of its 
 
 `ws`: every rank is lent the workspace nb_comm_workspace_bytes_* asks for (FAST then takes the pairwise step across the ranks).
 Environment: WORKER_ONE_GROUP=0|1 -> nb_comm_set_exchange_grouping on every communicator (unset: the library's default);
-WORKER_LATE_DIAGONAL=0|1 -> nb_set_late_diagonal; WORKER_REAL_RCCL=1 -> the `all` case over the REAL RCCL (an in-process world: libnbody_hip_lab.so);
+WORKER_LATE_DIAGONAL=0|1|2 -> nb_set_late_diagonal; WORKER_REAL_RCCL=1 -> the `all` case over the REAL RCCL (an in-process world: libnbody_hip_lab.so);
 WORKER_NO_WORKSPACE_RANK=k -> rank k lends nothing (nb_comm_set_workspace(comm, NULL, 0)): the layout must then be one-sided on
 EVERY rank.  The output holds `layout` (nb_comm_layout_* per rank) and `setup_counters` (what the transport had seen before the
 first step: nb_comm_set_workspace's exchange with one process -- here: thread -- per rank).

@@ -354,7 +354,8 @@ def test_n_rank_line_rehearsed_on_one_gpu_through_the_capi(ranks):
     executed = line["roofline"]["executed"]
     assert executed["pair_evaluations_per_step_this_rank"] == seen[0]["pair_work"]["pair_evaluations_per_step"] and 0 < executed["frac"] < 1
     diag = line["diagnostics"]
-    assert set(diag["step_ms"]) == {"pairwise_one_group", "pairwise_group_per_round", "one_sided_one_group", "one_sided_group_per_round", "pairwise_diagonal_first_group_per_round"}
+    assert set(diag["step_ms"]) == {"pairwise_one_group", "pairwise_group_per_round", "one_sided_one_group", "one_sided_group_per_round", "pairwise_diagonal_first_group_per_round",
+                                    "pairwise_both_streams_end_on_local_work_group_per_round"}  # (round 6: the cut rectangle, timed beside the shipping order)
     assert diag["headline_was"] == "pairwise_group_per_round"
     assert len(diag["by_rank"]["pairwise_kernels_alone_ms"]) == ranks and all(v > 0 for v in diag["by_rank"]["pairwise_kernels_alone_ms"])
     assert all(v > 0 for v in diag["step_ms"].values())

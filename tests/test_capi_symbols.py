@@ -456,9 +456,15 @@ def test_pair_shard_plan_without_gpu(pkg):
     # bodies i) --, H = 4 partners, 15 diagonal slots.  Round 5: the diagonal is two launches (offsets q = 0 .. 8 first, 9 .. 16 last),
     # each with its own C = 4 planes of i-side sums; nb_set_late_diagonal(0) is the single launch of before
     assert rc == 0 and b8 == ((4 + 4 + 3 * 4 + 8) + 15 + 2 * 32 + 4 + 4) * 3 * 32768 * 4
-    assert lib.nb_set_late_diagonal(2) == 10001 and lib.nb_set_late_diagonal(0) == 0
+    six = need(262144 // 8 * 6, 6)
+    assert lib.nb_set_late_diagonal(3) == 10001 and lib.nb_set_late_diagonal(0) == 0
     try:
         assert need(262144, 8) == (0, ((4 + 3 * 4 + 8) + 15 + 2 * 32 + 4 + 4) * 3 * 32768 * 4)
+        # round 6, nb_set_late_diagonal(2): the late offsets 9 .. 16 dealt to BOTH streams (9 .. 12 / 13 .. 16) and rectangle 3 -- the second
+        # stream's last -- cut at 4 x 16 = 64 tiles of bodies j: C = 4 planes more for the second stream's diagonal piece, 4 for the cut-off part
+        assert lib.nb_set_late_diagonal(2) == 0
+        assert need(262144, 8) == (0, ((4 + 4 + 3 * 4 + 8 + 4 + 4) + 15 + 2 * 32 + 4 + 4) * 3 * 32768 * 4)
+        assert six[0] == 0 and need(262144 // 8 * 6, 6) == six  # (6 ranks: the split rectangle is the second stream's last -- the shipping deal)
     finally:
         assert lib.nb_set_late_diagonal(1) == 0
     rc, b2 = need(262144, 2)

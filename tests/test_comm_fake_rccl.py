@@ -279,6 +279,43 @@ def test_reaction_sends_are_enqueued_before_the_last_force_kernel(tmp_path, orac
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("world", [4, 8, 6, 5])
+def test_both_compute_streams_can_end_on_local_work(tmp_path, oracle, world):
+    """Round 6: nb_set_late_diagonal(2) -- the second compute stream takes half of the late diagonal offsets as ITS last
+    kernel and hands the same amount of work, the first tiles of bodies j of its last rectangle, to the step's own stream (own reaction
+    planes, own fold into the first part of the send array, the send waiting for both folds).  Measured slower on one GPU
+    (profiles/round6_cut_rectangle_ab.txt) and NOT the default; selectable for A/B timings on real links, so it must be right: every rank
+    the same positions, as close to the CPU path as the shipping order, the crew and the calling thread alone the same bits, every send
+    enqueued before the late kernels; worlds it does not apply to (6 ranks: the split rectangle is the second stream's last; odd worlds:
+    the second stream ends early anyway) keep the shipping deal bit for bit."""
+    n, steps = world * 4096, 3
+    pos0, vel0 = oracle.startup_state(n, np.float32)
+    ref_p, ref_v = pos0.copy(), vel0.copy()
+    oracle.update(ref_p, ref_v, np.float32(0.016), steps=steps)
+    ships = _run(tmp_path, "all", pos0, vel0, world, steps, "fast", workspace=True)
+    cut = _run(tmp_path, "all", pos0, vel0, world, steps, "fast", workspace=True, WORKER_LATE_DIAGONAL="2")
+    assert list(cut["layout"]) == [1] * world
+    for k in range(world):
+        assert cut[f"pos_{k}"].tobytes() == cut["pos_0"].tobytes()
+    trace = bytes(cut["trace_0"]).decode().split("\n")[:-1]
+    if world in (6, 5):
+        assert cut["pos_0"].tobytes() == ships["pos_0"].tobytes() and not any("cut-off" in t or "second stream" in t for t in trace)
+        return
+    H, s_cut = world // 2, world // 2 - 1
+    assert cut["pos_0"].tobytes() != ships["pos_0"].tobytes() and np.all(cut["workspace_bytes"] > ships["workspace_bytes"])
+    assert np.abs(cut["pos_0"] - ref_p).max() <= 1.5 * np.abs(ships["pos_0"] - ref_p).max() + 1e-7 and np.abs(cut["pos_0"] - ref_p).max() < 2e-5
+    alone = _run(tmp_path, "all", pos0, vel0, world, steps, "fast", workspace=True, WORKER_LATE_DIAGONAL="2", NBODY_STEP_THREADS="0")
+    assert alone["pos_0"].tobytes() == cut["pos_0"].tobytes()
+    assert trace[0] == "forces diagonal-early" and trace[-3:] == ["forces diagonal-late", "forces diagonal-late second stream", "finish"], trace
+    assert f"forces rectangle {s_cut} cut-off part" in trace and f"fold {s_cut} cut-off part" in trace
+    assert trace.index(f"fold {s_cut} cut-off part") < trace.index(f"send reaction {s_cut}") and trace.index(f"fold {s_cut}") < trace.index(f"send reaction {s_cut}")
+    assert max(trace.index(t) for t in trace if t.startswith("send")) < trace.index("forces diagonal-late")
+    assert sum(t.startswith("forces") for t in trace) == 2 + H + 2
+    sends, recvs = cut["counters"][0], cut["counters"][1]
+    assert sends == recvs == (world - 1 + H) * world * steps  # (the same transfers: the cut is inside a rank)
+
+
+@pytest.mark.gpu
 def test_pairwise_step_across_ranks_one_thread_per_rank(tmp_path, oracle):
     n, steps, world = 4096, 4, 4
     pos0, vel0 = oracle.startup_state(n, np.float32)

@@ -7,7 +7,8 @@ pair_forces for the chip as they would on a node; only the xGMI transfer time is
 
     kernels_alone_*      nb_emulate_pair_rank_f32 (pairwise) / the one-sided tile kernels: the same kernels, no communicator, no exchange
     step_*               the loopback step, all G-1 position rounds in ONE RCCL group / a group per round;
-                         late1 / late0: the diagonal as two launches, the second one last (nb_set_late_diagonal) / one launch, first
+                         late2 / late1 / late0 (nb_set_late_diagonal): the diagonal's late half dealt to BOTH streams and the second stream's last rectangle cut (round 6) /
+                         the diagonal as two launches, the second one last / one launch, first
     *_one_sided          no workspace lent (the one-sided tile schedule)
     *_exchange_alone     the position exchange / the reaction leg on an otherwise idle chip
 
@@ -97,7 +98,7 @@ def main():
             bufs[0].upload(pos0), bufs[1].upload(pos0), bufs[2].upload(vel0)
             job = pkg.ShardedRank(None, G, r, [bufs[0].ptr.value, bufs[1].ptr.value], bufs[2].ptr.value, bufs[3].ptr.value, n, dtype, pkg.NB_MODE_FAST, 256, stream, comm=comm)
             need = 0
-            for late in (1, 0):  # (the two forms of the diagonal want different numbers of planes: lend the larger amount to both)
+            for late in (2, 1, 0):  # (the forms of the diagonal want different numbers of planes: lend the largest amount to all)
                 pkg.check(lib.nb_set_late_diagonal(late))
                 need = max(need, job.workspace_bytes())
             pkg.check(lib.nb_set_late_diagonal(1))
@@ -124,7 +125,7 @@ def main():
             # phase: label -> (configure arguments, what one repetition does, what ends the timed stretch)
             phases = {}
             if work is not None:
-                for late in (1, 0):
+                for late in (2, 1, 0):
                     for og in (True, False):
                         phases[f"step_pairwise_late{late}_{'one_group' if og else 'group_per_round'}"] = (("pairwise", og, late), step, job.finish)
                     phases[f"kernels_alone_pairwise_late{late}"] = (("pairwise", True, late), emulate, None)
