@@ -258,7 +258,9 @@ def test_default_line_carries_every_baseline_config():
     assert clock["mhz_p10"] <= clock["mhz"] <= clock["mhz_p90"]
     assert abs(roof["frac_at_delivered_clock"] - roof["step_frac"] * 2400.0 / clock["mhz"]) < 1e-9 and roof["frac_at_delivered_clock"] < 1.25  # (algorithmic flop: may pass 1, see frac_counts)
     assert abs(roof["pair_forces_mcycles"] - roof["pair_forces_ms"] * clock["mhz"] * 1e-3) < 1e-6 and 15 < roof["pair_forces_mcycles"] < 30
-    assert abs(clock["workgroup_mcycles_median"] - roof["pair_forces_mcycles"]) < 0.05 * roof["pair_forces_mcycles"]  # one workgroup per CU: it lives as long as the kernel
+    # one workgroup per CU: the median workgroup lives 20.71 Mcycles on every box met; the launch as events time it (ramp, tail, the slowest
+    # XCD's workgroups) is 2-7 % longer
+    assert 20.3 < clock["workgroup_mcycles_median"] < 21.2 and clock["workgroup_mcycles_median"] <= roof["pair_forces_mcycles"] < 1.12 * clock["workgroup_mcycles_median"]
     assert line["exchange_path"] == "none" and 0 < line["host_enqueue_ms_per_step"] < line["ms_per_step"] + 1.0
     # algorithmic HBM bytes are the bodies in and out; the workspace traffic is stated next to them
     assert roof["algorithmic_hbm_bytes_per_launch"] == 64 * 262144
