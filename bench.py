@@ -586,7 +586,8 @@ def main():
     ev0, ev1 = pkg.Event(), pkg.Event()
     t0 = time.perf_counter()
     ev0.record(stream_ptr)
-    head = min(args.steps, 8)  # the host's own enqueue time is read over the first few steps: later the loop may run into a full device queue
+    head = max(1, min(args.steps, 8))  # the host's own enqueue time is read over the first few steps: later the loop may run into a full device queue
+    enqueued = t0
     for k in range(args.steps):
         step()
         if k == head - 1:
