@@ -610,6 +610,7 @@ def main():
     # into a full device queue and read 0.63 ms per step where 8 read 0.13; a step whose enqueue takes longer than its kernels is bound by
     # the host).  The library's own figure for the last step stands next to it.
     host_enqueue_ms = (enqueued - t0) / head * 1e3
+    host_enqueue_ms_this_rank = host_enqueue_ms  # (the line's figure is the MAX over the ranks; ranks_seen[] keeps each rank's own)
     lib_enqueue_ms = None
     if capi_rank is not None:
         ms = ctypes.c_double(0)
@@ -841,6 +842,7 @@ def main():
                 mine["pair_work"] = None if work is None else {"pair_evaluations_per_step": work[0], "force_launches_per_step": work[1]}
             mine["pci"] = pci_address(torch, local_rank)
             mine["stream_ms_per_step"] = float(f"{stream_ms_per_step:.5g}")
+            mine["host_enqueue_ms_per_step"] = float(f"{host_enqueue_ms_this_rank:.5g}")
             dist.all_gather_object(seen, mine)
             extra["ranks_seen"] = seen
             # how many ranks stepped through a communicator bound to a real RCCL (== n_gpus for a line of the native path), and which RCCL

@@ -347,6 +347,7 @@ def test_n_rank_line_rehearsed_on_one_gpu_through_the_capi(ranks):
     # the rank executed per step and how long its own stream took
     assert all(r["rccl_version"] == 0 and "fake_rccl" in r["rccl_library"] for r in seen)
     assert all(r["pci"] == seen[0]["pci"] and r["stream_ms_per_step"] > 0 for r in seen)  # (the rehearsal: one card)
+    assert all(0 < r["host_enqueue_ms_per_step"] <= line["host_enqueue_ms_per_step"] * 1.001 for r in seen)  # (round 6: every rank's own enqueue time; the line's is their maximum)
     # ... and on what kind of stream it stepped: one from nb_comm_stream_create, never the null stream (-1 / 0 / 1; with several processes
     # on ONE card the spin-kernel probe behind the flag is noise, so only its presence is held here -- the flag itself: test_sharded_gpu.py)
     assert all(r["caller_stream_badly_placed"] in (-1, 0, 1) and r["side_stream_collisions"] >= -1 for r in seen)
